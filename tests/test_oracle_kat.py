@@ -1,0 +1,216 @@
+"""Pins the CPU oracle (oracle/pyref) with every oracle-free known answer
+available for this path plus identities over
+the ceremony file the reference's own tests load (src/kzg/setup.rs:299-303).
+The reference's golden vectors (consensus-spec-tests) are an empty submodule in
+this checkout, hence "parity unpinned" in the oracle header."""
+import hashlib
+import json
+
+import pytest
+
+from oracle.pyref import blob as oblob
+from oracle.pyref import bls, domain, poly
+from oracle.pyref.setup import KzgError, Setup
+
+from conftest import TRUSTED_SETUP
+
+R = bls.R
+P = bls.P
+GEN48 = bytes.fromhex(
+    "97f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb"
+)
+INF48 = bytes([0xC0]) + bytes(47)
+
+
+def be32(v):
+    return int(v).to_bytes(32, "big")
+
+
+# ---- reference unit tests restated (src/bls.rs:604-612, src/math.rs:80-113) ---
+def test_fr_one_and_max_constants():
+    # Fr::ONE / Fr::MAX limbs are 1 and r-1 in Montgomery form (R = 2^256)
+    one = [0x00000001FFFFFFFE, 0x5884B7FA00034802, 0x998C4FEFECBC4FF5, 0x1824B159ACC5056F]
+    mx = [18446744060824649731, 18102478225614246908, 11073656695919314959, 6613806504683796440]
+    val = lambda l: sum(x << (64 * i) for i, x in enumerate(l))
+    assert val(one) == (1 << 256) % R
+    assert val(mx) == (R - 1) * (1 << 256) % R
+    assert (R - 1 + 1) % R == 0
+
+
+def test_bit_reversal_is_involution_and_rejects_non_pow2():
+    import random
+
+    rnd = random.Random(1)
+    xs = [rnd.randrange(1 << 16) for _ in range(4096)]
+    assert domain.bit_reversal_permutation(domain.bit_reversal_permutation(xs)) == xs
+    with pytest.raises(AssertionError):
+        domain.bit_reversal_permutation([0] * 4095)
+
+
+def test_primitive_root_of_unity():
+    w = domain.primitive_root_of_unity(4096)
+    assert w == 0x564C0A11A0F704F4FC3E8ACFE0F8245F0AD1347B378FBF96E206DA11A5D36306
+    assert w * pow(w, 4095, R) % R == 1
+    assert pow(w, 2048, R) == R - 1
+    brp = domain.bit_reversal_permutation(domain.roots_of_unity(4096))
+    assert brp[0] == 1 and brp[1] == R - 1
+    assert brp[2] == 0x8D51CCCE760304D0EC030002760300000001000000000000
+    digest = hashlib.sha256(b"".join(be32(x) for x in brp)).hexdigest()
+    assert digest == "1d815dd2fcaae4382dad24b89c046c2ece81a6554455ce76eaf754b285ed0792"
+
+
+def test_fr_pow_reference_quirk_q2():
+    assert bls.fr_pow_reference(5, 0) == 5  # src/bls.rs:169-187 returns x for power 0
+    assert bls.fr_pow_reference(5, 1) == 5
+    for e in (2, 3, 7, 4096, 65537):
+        assert bls.fr_pow_reference(5, e) == pow(5, e, R)
+
+
+# ---- fixture file -----------------------------------------------------------
+def test_trusted_setup_digests():
+    raw = open(TRUSTED_SETUP, "rb").read()
+    assert hashlib.sha256(raw).hexdigest() == "0229b43f4fac9b17374809520eb621b5ee1a7f74547e7d36918e7d4b122e178d"
+    d = json.loads(raw)
+    g1 = b"".join(bytes.fromhex(s[2:]) for s in d["g1_lagrange"])
+    assert hashlib.sha256(g1).hexdigest() == "52c7615a9bd3eb20df67eb5a81ee701c96787c82a5ff638740b54fbadfde960b"
+    assert bytes.fromhex(d["g2_monomial"][0][2:]) == bls.g2_compress(bls.G2_GEN)
+
+
+def test_generators_and_encoding_roundtrip():
+    assert bls.g1_is_on_curve(bls.G1_GEN) and bls.g1_in_subgroup(bls.G1_GEN)
+    assert bls.g2_is_on_curve(bls.G2_GEN) and bls.g2_in_subgroup(bls.G2_GEN)
+    assert bls.g1_compress(bls.G1_GEN) == GEN48
+    assert bls.g1_decompress(GEN48) == bls.G1_GEN
+    assert bls.g1_compress(None) == INF48 and bls.g1_decompress(INF48) is None
+    q = bls.g1_mul(bls.G1_GEN, 0xDEADBEEF)
+    assert bls.g1_decompress(bls.g1_compress(q)) == q
+    nq = bls.g1_neg(q)
+    assert bls.g1_decompress(bls.g1_compress(nq)) == nq
+    assert bls.g1_compress(q)[0] & 0x20 != bls.g1_compress(nq)[0] & 0x20
+    h = bls.g2_mul(bls.G2_GEN, 0xC0FFEE)
+    assert bls.g2_decompress(bls.g2_compress(h)) == h
+
+
+def test_setup_sample_subgroup_and_sum_is_generator(oracle_setup):
+    pts = oracle_setup.g1_lagrange_brp
+    for i in (0, 1, 2, 3, 1234, 4095):
+        assert bls.g1_in_subgroup(pts[i])
+    for q in oracle_setup.g2_monomial[:3]:
+        assert bls.g2_is_on_curve(q) and bls.g2_in_subgroup(q)
+    # sum_i L_i(tau) = 1  =>  sum of all Lagrange points = G1 generator (8c item 2)
+    acc = (1, 1, 0)
+    for pt in pts:
+        acc = bls._jac_add(acc, bls._jac_from_affine(pt))
+    assert bls._jac_to_affine(acc) == bls.G1_GEN
+
+
+def test_pairing_bilinear_and_ceremony_consistency(oracle_setup):
+    a, b = 0x1234567, 0x89ABCDEF01
+    assert bls.verify_pairings(
+        (bls.g1_mul(bls.G1_GEN, a * b), bls.G2_GEN), (bls.g1_mul(bls.G1_GEN, a), bls.g2_mul(bls.G2_GEN, b))
+    )
+    assert not bls.verify_pairings(
+        (bls.g1_mul(bls.G1_GEN, a * b + 1), bls.G2_GEN), (bls.g1_mul(bls.G1_GEN, a), bls.g2_mul(bls.G2_GEN, b))
+    )
+    # [tau]_1 = commitment to p(x) = x (blob e_i = omega_brp[i]); the ceremony's
+    # G2 side must agree:  e([tau]_1, G2) == e(G1, [tau]_2).  This ties the MSM,
+    # the BRP convention, the roots of unity and the pairing to independent data.
+    tau1 = oblob.commitment(oracle_setup.roots_of_unity_brp, oracle_setup)
+    assert bls.verify_pairings((tau1, bls.G2_GEN), (bls.G1_GEN, oracle_setup.g2_monomial[1]))
+    assert not bls.verify_pairings((tau1, bls.G2_GEN), (bls.G1_GEN, oracle_setup.g2_monomial[2]))
+
+
+# ---- SURVEY 8(c) items 2-6 ---------------------------------------------------
+def test_commitment_known_answers(oracle_setup):
+    d = json.load(open(TRUSTED_SETUP))
+    ones = be32(1) * 4096
+    assert bls.g1_compress(oracle_setup.blob_to_commitment(ones)) == GEN48
+    assert bls.g1_compress(oracle_setup.blob_to_commitment(bytes(131072))) == INF48
+    for i in (0, 1, 2, 3, 4095):
+        blob = bytearray(131072)
+        blob[32 * i + 31] = 1
+        want = bytes.fromhex(d["g1_lagrange"][domain.bit_reversal_permutation_index(i, 4096)][2:])
+        assert bls.g1_compress(oracle_setup.blob_to_commitment(bytes(blob))) == want
+
+
+def test_pippenger_matches_naive_sum(oracle_setup):
+    import random
+
+    rnd = random.Random(7)
+    pts = oracle_setup.g1_lagrange_brp[:24]
+    sc = [rnd.randrange(R) for _ in pts]
+    assert bls.g1_lincomb_pippenger(pts, sc) == bls.g1_lincomb(pts, sc)
+
+
+def test_challenge_known_answers():
+    z0 = oblob.challenge([0] * 4096, None)
+    assert z0 == 0x04B7B22AF63D2B2F1CED8D550560E5D1E4B01E355903DEE22781E87826856096
+    z1 = oblob.challenge([1] * 4096, bls.G1_GEN)
+    assert z1 == 0x1240EE945BA588D3E81CE99DC1395E712C2C230DAEDAC7276EB31A371F17B564
+
+
+def test_constant_and_identity_polynomials(oracle_setup):
+    z = 0x1234567890ABCDEF
+    c = 0x55AA
+    y, pi = poly.prove([c] * 4096, z, oracle_setup)
+    assert y == c and pi is None  # constant blob: proof = infinity
+    roots = oracle_setup.roots_of_unity_brp
+    assert poly.evaluate(roots, z, oracle_setup) == z  # p(x) = x
+    assert poly.evaluate(roots, roots[5], oracle_setup) == roots[5]  # in-domain shortcut
+
+
+# ---- rejection cases -------------------------------------
+def test_rejections(oracle_setup):
+    blob = bytearray(131072)
+    blob[0:32] = be32(R)
+    with pytest.raises(oblob.BlobError) as e:
+        oracle_setup.blob_to_commitment(bytes(blob))
+    assert e.value.kind == "InvalidFieldElement"
+    for ln in (131071, 131073, 0):
+        with pytest.raises(oblob.BlobError) as e:
+            oracle_setup.blob_to_commitment(bytes(ln))
+        assert e.value.kind == "InvalidLen"
+    with pytest.raises(bls.ECGroupError) as e:  # compressed bit clear
+        bls.g1_decompress(bytes([GEN48[0] & 0x7F]) + GEN48[1:])
+    assert e.value.kind == "InvalidEncoding"
+    with pytest.raises(bls.ECGroupError) as e:  # x >= p
+        bls.g1_decompress(bytes([0x80 | 0x1A]) + bytes([0xFF] * 47))
+    assert e.value.kind == "InvalidEncoding"
+    with pytest.raises(bls.ECGroupError) as e:  # infinity with the sign bit set
+        bls.g1_decompress(bytes([0xE0]) + bytes(47))
+    assert e.value.kind == "InvalidEncoding"
+    # find an x with no square root -> NotOnCurve, and an on-curve point outside G1
+    x = 1
+    while bls._fp_sqrt(x**3 + 4) is not None:
+        x += 1
+    with pytest.raises(bls.ECGroupError) as e:
+        bls.g1_decompress(bytes([0x80]) + x.to_bytes(48, "big")[1:])
+    assert e.value.kind == "NotOnCurve"
+    x = 1
+    while True:
+        y = bls._fp_sqrt(x**3 + 4)
+        if y is not None and not bls.g1_in_subgroup((x, y)):
+            break
+        x += 1
+    with pytest.raises(bls.ECGroupError) as e:
+        bls.g1_decompress(bls.g1_compress((x, y)))
+    assert e.value.kind == "NotInGroup"
+
+
+# ---- algebraic closure ------------------------------------
+def test_prove_verify_closure_small_batch(oracle_setup):
+    from oracle.pyref import synth
+
+    blobs = [synth.blob_bytes(synth.DEFAULT_SEED, b) for b in range(2)]
+    cs = [bls.g1_compress(oracle_setup.blob_to_commitment(b)) for b in blobs]
+    ps = [bls.g1_compress(oracle_setup.blob_proof(b, c)) for b, c in zip(blobs, cs)]
+    assert oracle_setup.verify_blob_proof(blobs[0], cs[0], ps[0])
+    assert oracle_setup.verify_blob_proof_batch(blobs, cs, ps)
+    assert not oracle_setup.verify_blob_proof_batch(blobs, cs, [ps[1], ps[0]])
+    assert not oracle_setup.verify_blob_proof(blobs[0], cs[0], ps[1])
+    assert oracle_setup.verify_blob_proof_batch([], [], [])  # pairing of two infinities == 1
+    bad = bytearray(blobs[0])
+    bad[31] ^= 1
+    assert not oracle_setup.verify_blob_proof(bytes(bad), cs[0], ps[0])
+    with pytest.raises(KzgError):
+        oracle_setup.verify_blob_proof_batch([bytes(5)], cs[:1], ps[:1])
