@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on MI355X.
+
+One "step" = one pass of the hot path over one batch of synthetic blobs that
+are already resident in HBM: `blob_to_kzg_commitment` on 4096 blobs per GPU
+(BASELINE.json configs[1]).  With --gpus N the driver launches N ranks (one per
+GPU); every rank commits its own 4096 blobs (weak scaling, blobs are
+independent) and the 48-byte commitments are all-gathered with RCCL.
+
+Prints ONE JSON line on rank 0 (contract in the task description) carrying
+`roofline` (dominant kernel k_msm_fixed, HIP-event timed inside the library on
+the stream it runs on) and `cpu_baseline` (the C port of the reference's CPU
+algorithm, oracle/cport, timed on the host cores on a bounded sample).
+Secondary workloads (`compute_blob_kzg_proof`, `verify_blob_kzg_proof_batch`)
+are reported under "extra" and are not part of `value`.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BYTES_PER_BLOB = 131072
+ALG_BYTES_COMMIT = 131072 + 48  # blob in + commitment out
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+SEED = 0x4844
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=4096, help="blobs per GPU per step (BASELINE configs[1]: 4096)")
+    ap.add_argument("--window-bits", type=int, default=int(os.environ.get("KATETH_AMD_WINDOW_BITS", "0")))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary proof/verify workloads")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="blobs in the CPU baseline sample (0 = auto, ~10-30 s)")
+    return ap.parse_args()
+
+
+def cpu_baseline(sample_blobs, setup_path):
+    """oracle/cport (C port of kateth's CPU path: Pippenger c=10 signed digits as
+    blst uses) timed on the host cores, rank 0 only.  Checker code: never the
+    thing measured as `value`."""
+    so = os.path.join(ROOT, "oracle", "cport", "libkzg_cport.so")
+    if not os.path.exists(so):
+        return None
+    lib = ctypes.CDLL(so)
+    from oracle.cport import binding
+
+    return binding.time_commitment(lib, setup_path, sample_blobs, SEED)
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    assert torch.cuda.is_available(), "bench.py needs an MI355X; the engine has no CPU fallback"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import kateth_amd
+
+    setup_path = os.path.join(ROOT, "tests", "golden", "trusted_setup_4096.json")
+    t0 = time.time()
+    setup = kateth_amd.Setup.load_json(setup_path, device=local_rank, window_bits=args.window_bits)
+    t_setup = time.time() - t0
+
+    n = args.batch
+    d_blobs = torch.empty(n * BYTES_PER_BLOB, dtype=torch.uint8, device=dev)
+    d_out = torch.empty(n * 48, dtype=torch.uint8, device=dev)
+    d_status = torch.empty(n, dtype=torch.int32, device=dev)
+    gathered = torch.empty(world * n * 48, dtype=torch.uint8, device=dev) if world > 1 else None
+    stream = torch.cuda.current_stream().cuda_stream
+    setup.synth_blobs_dev(SEED, rank * n, n, d_blobs.data_ptr(), stream)
+
+    def step():
+        setup.blob_to_commitment_batch_dev(d_blobs.data_ptr(), n, d_out.data_ptr(), d_status.data_ptr(), stream)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, d_out)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    setup.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof = setup.profile_end()
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert int(d_status.abs().sum()) == 0, "synthetic blobs must all be valid"
+
+    # ---- correctness spot check of the timed output against the oracle golden vectors
+    if rank == 0:
+        golden = json.load(open(os.path.join(ROOT, "tests", "golden", "kzg_vectors.json")))
+        out = d_out[: 48 * len(golden["blobs"])].cpu().numpy().tobytes()
+        for rec in golden["blobs"]:
+            b = rec["index"]
+            if b < n:
+                assert out[48 * b:48 * b + 48].hex() == rec["commitment"], "GPU commitment != oracle golden vector"
+
+    blobs_per_s = world * n * args.steps / elapsed
+    result = {
+        "metric": "blobs/sec for blob_to_kzg_commitment (n=4096 field elements per blob)",
+        "value": blobs_per_s,
+        "unit": "blobs/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u32 limbs (381-bit Fp / 255-bit Fr Montgomery integer arithmetic)",
+        "data": "synthetic: element(b,i)=SHA-256(seed||b||i) mod r, generated on device, resident in HBM",
+        "config": {
+            "workload": "blob_to_kzg_commitment batch=%d blobs per GPU (BASELINE configs[1])" % n,
+            "blobs_per_gpu": n,
+            "window_bits": setup.window_bits,
+            "table_gib": setup.table_bytes / 2**30,
+            "parallelism": "blob-sharded x%d, RCCL all-gather of 48-B commitments" % world,
+            "setup_s": t_setup,
+        },
+    }
+    if rank == 0:
+        k_ms = prof["msm_ms"] / max(1, prof["msm_launches"])
+        alg_bytes = ALG_BYTES_COMMIT * n  # per launch: one launch processes the rank's whole batch
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else None
+        adds_per_blob = prof["adds_per_blob"]
+        result["roofline"] = {
+            "kernel": "k_msm_fixed",
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
+            "traffic": None,
+            "kernel_ms": k_ms,
+            "launches": prof["msm_launches"],
+            "algorithmic_bytes_per_blob": ALG_BYTES_COMMIT,
+            "note": "integer-ALU bound, not HBM bound: see valu_* fields and DESIGN.md section 5",
+            "table_gather_bytes_per_blob": adds_per_blob * 96,
+            "valu_fp_mul_per_s": (adds_per_blob * 10 * n / (k_ms * 1e-3)) if k_ms > 0 else None,
+            "valu_fp_mul_peak_per_s": prof.get("fp_mul_peak_per_s"),
+        }
+        if result["roofline"]["valu_fp_mul_peak_per_s"]:
+            result["roofline"]["valu_frac"] = result["roofline"]["valu_fp_mul_per_s"] / result["roofline"]["valu_fp_mul_peak_per_s"]
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                result["cpu_baseline"] = cpu_baseline(args.cpu_sample, setup_path)
+            except Exception as err:  # the baseline is reporting only; never hide the GPU number
+                result["cpu_baseline"] = {"value": None, "error": repr(err)}
+        print(json.dumps(result), flush=True)
+    setup.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

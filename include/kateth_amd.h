@@ -1,0 +1,178 @@
+/*
+ * kateth_amd -- MI355X (gfx950) EIP-4844 KZG engine: C ABI.
+ *
+ * This is the drop-in boundary for kateth's hot path.  kateth has no FFI of its
+ * own below its public Rust API other than the per-operation blst calls
+ * (src/bls.rs:8-19), which are too fine-grained to put a GPU behind, so the
+ * entry points here are batch-level and sit directly under the crate's public
+ * methods; each one names the reference function it
+ * replaces.  Byte layouts are exactly the reference's wire formats: a blob is
+ * 4096 x 32-byte big-endian field elements (src/blob.rs:23-37), a commitment or
+ * proof is a 48-byte ZCash-compressed G1 point (src/bls.rs:491-531), a field
+ * element is 32 bytes big-endian (src/bls.rs:130-149).
+ *
+ * Plain C: pointers and sizes only.  Nothing unwinds across this boundary.
+ * A kzg_ctx is immutable after creation and may be used from several host
+ * threads at once (calls serialise on an internal lock around the GPU
+ * workspace), matching `&self` + `Arc<Setup>` in the reference
+ * (src/kzg/setup.rs:323).
+ *
+ * Return value of every call: 0 on success, a positive KZG_ERR_* code when an
+ * input is rejected the way the reference returns Err, a negative KZG_FAIL_*
+ * code for a runtime (HIP / allocation / argument) failure.
+ */
+#ifndef KATETH_AMD_H
+#define KATETH_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KZG_FIELD_ELEMENTS_PER_BLOB 4096
+#define KZG_BYTES_PER_FIELD_ELEMENT 32
+#define KZG_BYTES_PER_BLOB 131072 /* Blob::<4096>::BYTES, src/blob.rs:24 */
+#define KZG_BYTES_PER_G1 48       /* P1::COMPRESSED, src/bls.rs:552 */
+#define KZG_BYTES_PER_G2 96       /* P2::COMPRESSED, src/bls.rs:569 */
+#define KZG_SETUP_G1_POINTS 4096  /* Setup<4096, 65>, benches/kzg.rs:12 */
+#define KZG_SETUP_G2_POINTS 65
+
+/* per-item / per-call rejection codes; they rebuild the reference's enums */
+#define KZG_OK 0
+#define KZG_ERR_BLOB_INVALID_LEN 1           /* blob::Error::InvalidLen            src/blob.rs:9   */
+#define KZG_ERR_BLOB_INVALID_FIELD_ELEMENT 2 /* blob::Error::InvalidFieldElement   src/blob.rs:8   */
+#define KZG_ERR_EC_INVALID_ENCODING 3        /* ECGroupError::InvalidEncoding      src/bls.rs:29  */
+#define KZG_ERR_EC_NOT_ON_CURVE 4            /* ECGroupError::NotOnCurve           src/bls.rs:31  */
+#define KZG_ERR_EC_NOT_IN_GROUP 5            /* ECGroupError::NotInGroup           src/bls.rs:30  */
+#define KZG_ERR_FF_INVALID_ENCODING 6        /* FiniteFieldError::InvalidEncoding  src/bls.rs:23  */
+#define KZG_ERR_FF_NOT_IN_FIELD 7            /* FiniteFieldError::NotInFiniteField src/bls.rs:24  */
+
+#define KZG_FAIL_ARGUMENT (-1)
+#define KZG_FAIL_HIP (-2)
+#define KZG_FAIL_NO_DEVICE (-3)
+#define KZG_FAIL_SETUP_G1 (-4) /* LoadSetupError::Bls on a g1_lagrange point, src/kzg/setup.rs:59-64 */
+#define KZG_FAIL_SETUP_G2 (-5) /* LoadSetupError::Bls on a g2_monomial point, src/kzg/setup.rs:67-72 */
+
+typedef struct kzg_ctx kzg_ctx;
+
+typedef struct kzg_config {
+  int32_t device;      /* HIP device ordinal this context lives on */
+  int32_t window_bits; /* fixed-base MSM window c in [4,16]; 0 = default.  Table = 4096 * ceil(256/c) * 2^(c-1) * 96 B of HBM */
+  int32_t flags;       /* reserved, must be 0 */
+  int32_t reserved;
+} kzg_config;
+
+/* Thread-local text for the last negative return on this thread ("" if none). */
+const char* kzg_last_error(void);
+
+/*
+ * Replaces Setup::<4096,65>::load_json after JSON/hex parsing
+ * (src/kzg/setup.rs:52-81): decompresses and subgroup-checks the 4096 G1
+ * Lagrange points and the 65 G2 monomial points (given in FILE order),
+ * bit-reversal-permutes G1, derives the 4096 roots of unity (src/math.rs:16-29)
+ * and builds the resident device tables.
+ *   g1_lagrange : 4096 * 48 bytes      g2_monomial : 65 * 96 bytes
+ */
+int32_t kzg_ctx_create(const uint8_t* g1_lagrange, const uint8_t* g2_monomial, const kzg_config* cfg, kzg_ctx** out);
+void kzg_ctx_destroy(kzg_ctx* ctx);
+
+/* introspection for benches / tests */
+int32_t kzg_ctx_window_bits(const kzg_ctx* ctx);
+uint64_t kzg_ctx_table_bytes(const kzg_ctx* ctx);
+
+/*
+ * Replaces Setup::blob_to_commitment + Compress::compress for n blobs
+ * (src/kzg/setup.rs:167-171, src/blob.rs:26-53, src/bls.rs:491-503).
+ *   blobs  : n * 131072 bytes          out48  : n * 48 bytes
+ *   status : n * int32 ; 0 or KZG_ERR_BLOB_INVALID_FIELD_ELEMENT per blob
+ *            (a rejected blob's 48 output bytes are zeroed)
+ * Host-pointer form copies in/out; the *_dev form takes HIP device pointers
+ * resident on ctx's device and enqueues on `hip_stream` (a hipStream_t, NULL =
+ * default stream) without synchronising.
+ * `blob_len` lets the caller forward a wrong-length slice the way the Rust
+ * shim would: blob_len != 131072 -> every status = KZG_ERR_BLOB_INVALID_LEN.
+ */
+int32_t kzg_blob_to_commitment_batch(const kzg_ctx* ctx, const uint8_t* blobs, uint64_t n, uint8_t* out48, int32_t* status);
+int32_t kzg_blob_to_commitment_batch_dev(const kzg_ctx* ctx, const void* d_blobs, uint64_t n, void* d_out48, void* d_status, void* hip_stream);
+
+/*
+ * Replaces Setup::blob_proof + compress for n (blob, commitment) pairs
+ * (src/kzg/setup.rs:177-183, src/blob.rs:55-97, src/kzg/poly.rs:10-71).
+ *   status : per item 0, KZG_ERR_BLOB_*, or KZG_ERR_EC_* for the commitment
+ */
+int32_t kzg_compute_blob_proof_batch(const kzg_ctx* ctx, const uint8_t* blobs, const uint8_t* commitments48, uint64_t n, uint8_t* out48, int32_t* status);
+int32_t kzg_compute_blob_proof_batch_dev(const kzg_ctx* ctx, const void* d_blobs, const void* d_commitments48, uint64_t n, void* d_out48, void* d_status, void* hip_stream);
+
+/*
+ * Replaces Setup::proof for n (blob, z) pairs (src/kzg/setup.rs:185-194):
+ *   z32 : n * 32 bytes big-endian ; out_proof48 : n * 48 ; out_y32 : n * 32
+ *   status : per item 0, KZG_ERR_BLOB_*, KZG_ERR_FF_NOT_IN_FIELD for z
+ */
+int32_t kzg_compute_proof_batch(const kzg_ctx* ctx, const uint8_t* blobs, const uint8_t* z32, uint64_t n, uint8_t* out_proof48, uint8_t* out_y32, int32_t* status);
+
+/*
+ * Replaces Setup::verify_blob_proof_batch (src/kzg/setup.rs:247-275).
+ * Returns KZG_OK with *ok = 0/1, or -- like the reference's first-error-wins
+ * collect (src/kzg/setup.rs:259-271: all blobs, then all commitments, then all
+ * proofs) -- the KZG_ERR_* of the first rejected input, *ok = 0.
+ * n == 0 -> *ok = 1.  The length-equality assert of the reference
+ * (src/kzg/setup.rs:256-257) stays in the caller: the ABI takes a single n.
+ */
+int32_t kzg_verify_blob_proof_batch(const kzg_ctx* ctx, const uint8_t* blobs, const uint8_t* commitments48, const uint8_t* proofs48, uint64_t n, int32_t* ok);
+int32_t kzg_verify_blob_proof_batch_dev(const kzg_ctx* ctx, const void* d_blobs, const void* d_commitments48, const void* d_proofs48, uint64_t n, int32_t* ok, void* hip_stream);
+
+/* Replaces Setup::verify_blob_proof (src/kzg/setup.rs:208-221): one item. */
+int32_t kzg_verify_blob_proof(const kzg_ctx* ctx, const uint8_t* blob, const uint8_t* commitment48, const uint8_t* proof48, int32_t* ok);
+
+/* Replaces Setup::verify_proof (src/kzg/setup.rs:96-113). */
+int32_t kzg_verify_proof(const kzg_ctx* ctx, const uint8_t* proof48, const uint8_t* commitment48, const uint8_t* z32, const uint8_t* y32, int32_t* ok);
+
+/*
+ * Multi-GPU batch verification: each rank reduces its
+ * shard to two G1 partial sums; rank 0 adds the partials of all ranks and runs
+ * the single pairing check.
+ *   partial_dev : checks this rank's n_local items whose global indices start
+ *                 at first_index within a batch of n_total; writes 2 * 96 bytes
+ *                 (affine, big-endian x||y, all-zero = infinity) to out192 and
+ *                 the first local error (code, local index) to err2.
+ *   finish      : given world * 192 bytes of partials, returns *ok.
+ * `batch_seed32` is the shared 32-byte transcript digest that seeds the random
+ * linear combination; see DESIGN.md (batch challenge).
+ */
+int32_t kzg_verify_blob_proof_batch_partial_dev(const kzg_ctx* ctx, const void* d_blobs, const void* d_commitments48, const void* d_proofs48,
+                                                uint64_t n_local, uint64_t first_index, uint64_t n_total, const uint8_t* batch_seed32,
+                                                uint8_t* out192, int32_t* err2, void* hip_stream);
+int32_t kzg_verify_batch_finish(const kzg_ctx* ctx, const uint8_t* partials192, uint64_t world, int32_t* ok);
+
+/*
+ * Synthetic-input generator used by bench.py and the parity tests
+ * (counterpart of Blob::random, src/blob.rs:66-76, but seeded):
+ *   element(b, i) = SHA-256(seed_le64 || b_le64 || i_le32) mod r, 32 B big-endian
+ * Fills n blobs with indices first_index .. first_index+n-1 into d_blobs.
+ */
+int32_t kzg_synth_blobs_dev(const kzg_ctx* ctx, uint64_t seed, uint64_t first_index, uint64_t n, void* d_blobs, void* hip_stream);
+
+/*
+ * Device micro-benchmarks (measurement support for bench.py's roofline object):
+ * runs `iters` dependent Fp Montgomery multiplications per lane on `lanes`
+ * lanes and returns the elapsed milliseconds measured with HIP events.
+ */
+int32_t kzg_microbench_fp_mul(const kzg_ctx* ctx, uint64_t lanes, uint64_t iters, float* ms);
+
+/*
+ * Kernel timing for bench.py's `roofline` object: between begin and end every
+ * launch of the dominant kernel (k_msm_fixed) is bracketed by HIP events on the
+ * stream it is launched on.  end() synchronises those events and returns the
+ * summed kernel milliseconds and the number of launches.
+ */
+int32_t kzg_profile_begin(const kzg_ctx* ctx);
+int32_t kzg_profile_end(const kzg_ctx* ctx, double* msm_ms_total, uint64_t* msm_launches);
+/* mixed additions the fixed-base MSM performs per blob: ceil(256/c) * 4096 */
+uint64_t kzg_ctx_adds_per_blob(const kzg_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KATETH_AMD_H */

@@ -1,0 +1,364 @@
+// kateth_amd engine: context, workspace and the C-ABI entry points of
+// include/kateth_amd.h.  All per-blob arithmetic runs in the HIP kernels of the
+// .cuh files next to this one; the host only orchestrates launches (and, for
+// verification, runs the single two-pairing check per call -- pairing.hpp).
+// There is NO CPU compute fallback: without a HIP device every entry point
+// fails with KZG_FAIL_NO_DEVICE / KZG_FAIL_HIP.
+#include <hip/hip_runtime.h>
+
+#include <string.h>
+
+#include <mutex>
+#include <new>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/kateth_amd.h"
+#include "blob_kernels.cuh"
+#include "msm_fixed.cuh"
+#include "setup_kernels.cuh"
+
+using namespace kzg;
+
+// ---------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+extern "C" const char* kzg_last_error(void) { return g_last_error.c_str(); }
+
+static int32_t fail(int32_t code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                                      \
+  do {                                                                                                     \
+    hipError_t _e = (expr);                                                                                \
+    if (_e != hipSuccess) return fail(KZG_FAIL_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));  \
+  } while (0)
+
+// ---------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------
+struct kzg_ctx {
+  int device = 0;
+  MsmGeom geom{};
+  uint4* d_table = nullptr;      // fixed-base table, table_entries(geom) * 96 B
+  uint4* d_bases_brp = nullptr;  // 4096 affine Lagrange points, BRP order
+  fr_t* d_roots_brp = nullptr;   // 4096 roots of unity, Montgomery, BRP order
+  uint64_t table_bytes = 0;
+  uint32_t num_cus = 256;
+  // workspace (grown on demand, guarded by lock)
+  mutable std::mutex lock;
+  mutable void* ws = nullptr;
+  mutable size_t ws_bytes = 0;
+  // profiling (kzg_profile_begin/end): event pairs around k_msm_fixed launches
+  mutable bool profiling = false;
+  mutable std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+  mutable size_t prof_used = 0;
+  // host copy of what the pairing needs
+  uint8_t g2_tau[96];  // g2_monomial[1] compressed (validated at create)
+};
+
+static int32_t ws_reserve(const kzg_ctx* ctx, size_t bytes) {
+  if (ctx->ws_bytes >= bytes) return 0;
+  if (ctx->ws) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipFree(ctx->ws));
+    ctx->ws = nullptr;
+    ctx->ws_bytes = 0;
+  }
+  size_t want = bytes + bytes / 8;
+  HIP_TRY(hipMalloc(&ctx->ws, want));
+  ctx->ws_bytes = want;
+  return 0;
+}
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static MsmGeom make_geom(uint32_t c) {
+  MsmGeom g;
+  g.c = c;
+  g.W = (256 + c - 1) / c;
+  g.half = 1u << (c - 1);
+  // largest raw top digit of a scalar < 2^255, plus a possible carry
+  uint32_t top_bits_lo = c * (g.W - 1);
+  uint32_t top_raw_max = (top_bits_lo >= 255) ? 0u : ((1u << (255 - top_bits_lo)) - 1u);
+  uint32_t top = top_raw_max + 1u;
+  g.top_entries = top < g.half ? top : g.half;
+  return g;
+}
+
+static uint32_t choose_splits(const kzg_ctx* ctx, uint64_t n) {
+  // aim for >= 4 waves per SIMD-slot-pair across the chip; splits is a power of two <= 64
+  const uint64_t target = (uint64_t)ctx->num_cus * 8;
+  uint32_t s = 1;
+  while (s < 64 && n * s < target) s <<= 1;
+  return s;
+}
+
+extern "C" uint64_t kzg_ctx_adds_per_blob(const kzg_ctx* ctx) { return ctx ? (uint64_t)ctx->geom.W * 4096u : 0; }
+
+extern "C" int32_t kzg_profile_begin(const kzg_ctx* ctx) {
+  if (!ctx) return fail(KZG_FAIL_ARGUMENT, "null argument");
+  std::lock_guard<std::mutex> guard(ctx->lock);
+  ctx->profiling = true;
+  ctx->prof_used = 0;
+  return 0;
+}
+
+extern "C" int32_t kzg_profile_end(const kzg_ctx* ctx, double* msm_ms_total, uint64_t* msm_launches) {
+  if (!ctx || !msm_ms_total || !msm_launches) return fail(KZG_FAIL_ARGUMENT, "null argument");
+  std::lock_guard<std::mutex> guard(ctx->lock);
+  HIP_TRY(hipSetDevice(ctx->device));
+  double total = 0;
+  for (size_t i = 0; i < ctx->prof_used; i++) {
+    float ms = 0;
+    HIP_TRY(hipEventSynchronize(ctx->prof_events[i].second));
+    HIP_TRY(hipEventElapsedTime(&ms, ctx->prof_events[i].first, ctx->prof_events[i].second));
+    total += ms;
+  }
+  *msm_ms_total = total;
+  *msm_launches = ctx->prof_used;
+  ctx->profiling = false;
+  ctx->prof_used = 0;
+  return 0;
+}
+
+// returns the event pair to record around the next dominant-kernel launch (or nullptrs)
+static int32_t prof_next(const kzg_ctx* ctx, hipEvent_t* e0, hipEvent_t* e1) {
+  *e0 = *e1 = nullptr;
+  if (!ctx->profiling) return 0;
+  if (ctx->prof_used == ctx->prof_events.size()) {
+    hipEvent_t a, b;
+    HIP_TRY(hipEventCreate(&a));
+    HIP_TRY(hipEventCreate(&b));
+    ctx->prof_events.emplace_back(a, b);
+  }
+  *e0 = ctx->prof_events[ctx->prof_used].first;
+  *e1 = ctx->prof_events[ctx->prof_used].second;
+  ctx->prof_used++;
+  return 0;
+}
+
+extern "C" int32_t kzg_ctx_window_bits(const kzg_ctx* ctx) { return ctx ? (int32_t)ctx->geom.c : 0; }
+extern "C" uint64_t kzg_ctx_table_bytes(const kzg_ctx* ctx) { return ctx ? ctx->table_bytes : 0; }
+
+extern "C" void kzg_ctx_destroy(kzg_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipDeviceSynchronize();
+  if (ctx->d_table) (void)hipFree(ctx->d_table);
+  if (ctx->d_bases_brp) (void)hipFree(ctx->d_bases_brp);
+  if (ctx->d_roots_brp) (void)hipFree(ctx->d_roots_brp);
+  if (ctx->ws) (void)hipFree(ctx->ws);
+  for (auto& pr : ctx->prof_events) {
+    (void)hipEventDestroy(pr.first);
+    (void)hipEventDestroy(pr.second);
+  }
+  delete ctx;
+}
+
+static int32_t ctx_build(kzg_ctx* ctx, const uint8_t* g1_lagrange, const uint8_t* g2_monomial) {
+  (void)g2_monomial;
+  const MsmGeom g = ctx->geom;
+  hipStream_t st = nullptr;
+  // ---- G1 Lagrange points: decompress, subgroup check, BRP -----------------
+  uint8_t* d_in = nullptr;
+  int32_t* d_status = nullptr;
+  HIP_TRY(hipMalloc(&d_in, 4096 * 48));
+  HIP_TRY(hipMalloc(&d_status, 4096 * sizeof(int32_t)));
+  HIP_TRY(hipMemcpy(d_in, g1_lagrange, 4096 * 48, hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc(&ctx->d_bases_brp, 4096 * 96));
+  hipLaunchKernelGGL(k_setup_g1, dim3(64), dim3(64), 0, st, d_in, ctx->d_bases_brp, d_status);
+  HIP_TRY(hipGetLastError());
+  std::vector<int32_t> h_status(4096);
+  HIP_TRY(hipMemcpy(h_status.data(), d_status, 4096 * sizeof(int32_t), hipMemcpyDeviceToHost));
+  HIP_TRY(hipFree(d_in));
+  HIP_TRY(hipFree(d_status));
+  for (int i = 0; i < 4096; i++)
+    if (h_status[i] != 0)
+      return fail(KZG_FAIL_SETUP_G1, "g1_lagrange[" + std::to_string(i) + "] rejected, code " + std::to_string(h_status[i]) +
+                                         (h_status[i] == 100 ? " (point at infinity is not supported as a setup base)" : ""));
+  // ---- roots of unity -------------------------------------------------------
+  HIP_TRY(hipMalloc(&ctx->d_roots_brp, 4096 * sizeof(fr_t)));
+  hipLaunchKernelGGL(k_setup_roots, dim3(64), dim3(64), 0, st, ctx->d_roots_brp);
+  HIP_TRY(hipGetLastError());
+  // ---- fixed-base table -----------------------------------------------------
+  const uint64_t entries = table_entries(g);
+  ctx->table_bytes = entries * 96;
+  HIP_TRY(hipMalloc(&ctx->d_table, ctx->table_bytes));
+  uint4* d_win_bases = nullptr;
+  HIP_TRY(hipMalloc(&d_win_bases, (size_t)g.W * 4096 * 96));
+  hipLaunchKernelGGL(k_table_window_bases, dim3(64), dim3(64), 0, st, ctx->d_bases_brp, d_win_bases, g);
+  HIP_TRY(hipGetLastError());
+  g1_xyzz* d_tmp = nullptr;
+  HIP_TRY(hipMalloc(&d_tmp, (size_t)4096 * g.half * sizeof(g1_xyzz)));
+  for (uint32_t j = 0; j < g.W; j++) {
+    const uint32_t e = (j + 1 < g.W) ? g.half : g.top_entries;
+    const uint64_t count = (uint64_t)4096 * e;
+    hipLaunchKernelGGL(k_table_chain, dim3(64), dim3(64), 0, st, d_win_bases, j, e, d_tmp);
+    constexpr int KN = 8;
+    const uint64_t threads = (count + KN - 1) / KN;
+    hipLaunchKernelGGL(k_table_normalize<KN>, dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, st, d_tmp, count, ctx->d_table,
+                       table_index(g, j, 0, 1));
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipFree(d_tmp));
+  HIP_TRY(hipFree(d_win_bases));
+  return 0;
+}
+
+extern "C" int32_t kzg_ctx_create(const uint8_t* g1_lagrange, const uint8_t* g2_monomial, const kzg_config* cfg, kzg_ctx** out) {
+  if (!g1_lagrange || !g2_monomial || !out) return fail(KZG_FAIL_ARGUMENT, "null argument");
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(KZG_FAIL_NO_DEVICE, "no HIP device visible: the kateth_amd engine has no CPU fallback");
+  int device = cfg ? cfg->device : 0;
+  if (device < 0 || device >= ndev) return fail(KZG_FAIL_ARGUMENT, "device ordinal out of range");
+  uint32_t c = (cfg && cfg->window_bits) ? (uint32_t)cfg->window_bits : 12u;
+  if (c < 4 || c > 16) return fail(KZG_FAIL_ARGUMENT, "window_bits must be in [4,16]");
+  HIP_TRY(hipSetDevice(device));
+  kzg_ctx* ctx = new (std::nothrow) kzg_ctx();
+  if (!ctx) return fail(KZG_FAIL_ARGUMENT, "out of host memory");
+  ctx->device = device;
+  ctx->geom = make_geom(c);
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cus = (uint32_t)prop.multiProcessorCount;
+  memcpy(ctx->g2_tau, g2_monomial + 96, 96);
+  int32_t rc = ctx_build(ctx, g1_lagrange, g2_monomial);
+  if (rc != 0) {
+    std::string keep = g_last_error;
+    kzg_ctx_destroy(ctx);
+    g_last_error = keep;
+    return rc;
+  }
+  *out = ctx;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// blob_to_kzg_commitment
+// ---------------------------------------------------------------------------
+static int32_t commit_dev_locked(const kzg_ctx* ctx, const void* d_blobs, uint64_t n, void* d_out48, int32_t* d_status, hipStream_t st) {
+  if (n == 0) return 0;
+  const uint32_t splits = choose_splits(ctx, n);
+  const size_t need = (size_t)n * splits * sizeof(g1_xyzz);
+  int32_t rc = ws_reserve(ctx, need);
+  if (rc) return rc;
+  g1_xyzz* partials = reinterpret_cast<g1_xyzz*>(ctx->ws);
+  HIP_TRY(hipMemsetAsync(d_status, 0, n * sizeof(int32_t), st));
+  if (n * splits > 0x7fffffffull) return fail(KZG_FAIL_ARGUMENT, "batch too large for one launch");
+  hipEvent_t pe0, pe1;
+  rc = prof_next(ctx, &pe0, &pe1);
+  if (rc) return rc;
+  if (pe0) HIP_TRY(hipEventRecord(pe0, st));
+  hipLaunchKernelGGL(k_msm_fixed<true>, dim3((unsigned)(n * splits)), dim3(64), 0, st, reinterpret_cast<const uint8_t*>(d_blobs), splits,
+                     ctx->d_table, ctx->geom, partials, d_status);
+  HIP_TRY(hipGetLastError());
+  if (pe1) HIP_TRY(hipEventRecord(pe1, st));
+  hipLaunchKernelGGL(k_msm_finalize, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, partials, splits, n, d_status,
+                     reinterpret_cast<uint8_t*>(d_out48));
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int32_t kzg_blob_to_commitment_batch_dev(const kzg_ctx* ctx, const void* d_blobs, uint64_t n, void* d_out48, void* d_status,
+                                                    void* hip_stream) {
+  if (!ctx || (n && (!d_blobs || !d_out48 || !d_status))) return fail(KZG_FAIL_ARGUMENT, "null argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  std::lock_guard<std::mutex> guard(ctx->lock);
+  return commit_dev_locked(ctx, d_blobs, n, d_out48, reinterpret_cast<int32_t*>(d_status), reinterpret_cast<hipStream_t>(hip_stream));
+}
+
+extern "C" int32_t kzg_blob_to_commitment_batch(const kzg_ctx* ctx, const uint8_t* blobs, uint64_t n, uint8_t* out48, int32_t* status) {
+  if (!ctx || (n && (!blobs || !out48 || !status))) return fail(KZG_FAIL_ARGUMENT, "null argument");
+  if (n == 0) return 0;
+  HIP_TRY(hipSetDevice(ctx->device));
+  uint8_t* d_blobs = nullptr;
+  uint8_t* d_out = nullptr;
+  int32_t* d_status = nullptr;
+  HIP_TRY(hipMalloc(&d_blobs, n * (size_t)KZG_BYTES_PER_BLOB));
+  HIP_TRY(hipMalloc(&d_out, n * 48));
+  HIP_TRY(hipMalloc(&d_status, n * sizeof(int32_t)));
+  HIP_TRY(hipMemcpy(d_blobs, blobs, n * (size_t)KZG_BYTES_PER_BLOB, hipMemcpyHostToDevice));
+  int32_t rc;
+  {
+    std::lock_guard<std::mutex> guard(ctx->lock);
+    rc = commit_dev_locked(ctx, d_blobs, n, d_out, d_status, nullptr);
+    if (rc == 0 && hipStreamSynchronize(nullptr) != hipSuccess) rc = fail(KZG_FAIL_HIP, "stream synchronize failed");
+  }
+  if (rc == 0) {
+    HIP_TRY(hipMemcpy(out48, d_out, n * 48, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(status, d_status, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+  }
+  (void)hipFree(d_blobs);
+  (void)hipFree(d_out);
+  (void)hipFree(d_status);
+  return rc;
+}
+
+// ---------------------------------------------------------------------------
+// synthetic blobs + micro-benchmarks
+// ---------------------------------------------------------------------------
+extern "C" int32_t kzg_synth_blobs_dev(const kzg_ctx* ctx, uint64_t seed, uint64_t first_index, uint64_t n, void* d_blobs, void* hip_stream) {
+  if (!ctx || (n && !d_blobs)) return fail(KZG_FAIL_ARGUMENT, "null argument");
+  if (n == 0) return 0;
+  HIP_TRY(hipSetDevice(ctx->device));
+  const uint64_t elems = n * 4096;
+  hipLaunchKernelGGL(k_synth_blobs, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(hip_stream), seed,
+                     first_index, elems, reinterpret_cast<uint8_t*>(d_blobs));
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void k_microbench_fp_mul(uint32_t* out, uint64_t iters) {
+  fp_t a, b;
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll
+  for (int q = 0; q < 12; q++) {
+    a.v[q] = FpParams::one(q) ^ (t & 0xffu);
+    b.v[q] = FpParams::r2(q) >> 1;
+  }
+  a.v[11] &= 0x0fffffffu;
+#pragma unroll 1
+  for (uint64_t it = 0; it < iters; it++) {
+    fp_t r;
+    fp_mul(r, a, b);
+    a = b;
+    b = r;
+  }
+  uint32_t x = 0;
+#pragma unroll
+  for (int q = 0; q < 12; q++) x ^= b.v[q];
+  out[t] = x;
+}
+
+extern "C" int32_t kzg_microbench_fp_mul(const kzg_ctx* ctx, uint64_t lanes, uint64_t iters, float* ms) {
+  if (!ctx || !ms || lanes == 0) return fail(KZG_FAIL_ARGUMENT, "null argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  lanes = align_up(lanes, 256);
+  uint32_t* d_out = nullptr;
+  HIP_TRY(hipMalloc(&d_out, lanes * sizeof(uint32_t)));
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  hipLaunchKernelGGL(k_microbench_fp_mul, dim3((unsigned)(lanes / 256)), dim3(256), 0, nullptr, d_out, (uint64_t)16);
+  HIP_TRY(hipEventRecord(e0, nullptr));
+  hipLaunchKernelGGL(k_microbench_fp_mul, dim3((unsigned)(lanes / 256)), dim3(256), 0, nullptr, d_out, iters);
+  HIP_TRY(hipEventRecord(e1, nullptr));
+  HIP_TRY(hipEventSynchronize(e1));
+  HIP_TRY(hipEventElapsedTime(ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(d_out);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// entry points still to come in this round
+// ---------------------------------------------------------------------------
+#include "engine_proof_verify.inc"

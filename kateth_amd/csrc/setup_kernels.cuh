@@ -1,0 +1,127 @@
+// Context-creation kernels: what Setup::load_json does after parsing
+// (src/kzg/setup.rs:52-81) plus the fixed-base table build of msm_fixed.cuh.
+#pragma once
+#include "msm_fixed.cuh"
+
+namespace kzg {
+#if defined(__HIPCC__)
+
+__device__ __forceinline__ uint32_t bitrev12(uint32_t i) { return __builtin_bitreverse32(i) >> 20; }
+
+// thread t: decompress + subgroup-check g1_lagrange[t] (file order), store the
+// affine Montgomery point at the bit-reversed index (src/kzg/setup.rs:59-65,
+// src/math.rs:72-74).  status[t] = KZG_ERR_* or 0; infinity -> flagged as 100.
+__global__ __launch_bounds__(64) void k_setup_g1(const uint8_t* __restrict__ in48, uint4* __restrict__ bases_brp, int32_t* __restrict__ status) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 4096) return;
+  fp_t x, y;
+  bool inf;
+  int32_t st = g1_decompress(x, y, inf, in48 + 48 * t);
+  if (st == 0 && inf) st = 100;
+  status[t] = st;
+  if (st == 0) store_affine96(bases_brp, bitrev12(t), x, y);
+}
+
+// thread i: window bases Q[j][i] = 2^(c*j) * L_i for j = 0..W-1 (affine).
+__global__ __launch_bounds__(64) void k_table_window_bases(const uint4* __restrict__ bases_brp, uint4* __restrict__ win_bases, MsmGeom g) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 4096) return;
+  fp_t x, y;
+  load_affine96(x, y, bases_brp, i);
+  store_affine96(win_bases, i, x, y);
+  g1_xyzz acc;
+  xyzz_from_affine(acc, x, y);
+  for (uint32_t j = 1; j < g.W; j++) {
+    for (uint32_t q = 0; q < g.c; q++) xyzz_dbl(acc);
+    xyzz_to_affine(x, y, acc);
+    store_affine96(win_bases, (uint64_t)j * 4096u + i, x, y);
+    xyzz_from_affine(acc, x, y);
+  }
+}
+
+// thread (i) of window j: chain d*Q for d = 1..entries, XYZZ results to tmp
+// (tmp index = i*entries + d-1).
+__global__ __launch_bounds__(64) void k_table_chain(const uint4* __restrict__ win_bases, uint32_t j, uint32_t entries, g1_xyzz* __restrict__ tmp) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 4096) return;
+  fp_t x, y;
+  load_affine96(x, y, win_bases, (uint64_t)j * 4096u + i);
+  g1_xyzz acc;
+  xyzz_from_affine(acc, x, y);
+  g1_xyzz* o = tmp + (uint64_t)i * entries;
+  o[0] = acc;
+#pragma unroll 1
+  for (uint32_t d = 1; d < entries; d++) {
+    xyzz_madd(acc, x, y);
+    o[d] = acc;
+  }
+}
+
+// thread: normalises KN consecutive XYZZ entries with one shared inversion
+// (Montgomery's trick on zz*zzz) and writes affine table entries.
+template <int KN>
+__global__ __launch_bounds__(64) void k_table_normalize(const g1_xyzz* __restrict__ tmp, uint64_t count, uint4* __restrict__ table, uint64_t table_off) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t first = t * KN;
+  if (first >= count) return;
+  fp_t w[KN];   // w[k] = zz_k * zzz_k
+  fp_t pre[KN]; // prefix products
+  fp_t total = fp_one();
+  int m = 0;
+#pragma unroll
+  for (int k = 0; k < KN; k++) {
+    if (first + k < count) {
+      const g1_xyzz& e = tmp[first + k];
+      fp_mul(w[k], e.zz, e.zzz);
+      if (k == 0)
+        pre[k] = w[k];
+      else
+        fp_mul(pre[k], pre[k - 1], w[k]);
+      total = pre[k];
+      m = k + 1;
+    }
+  }
+  fp_t inv;
+  fp_inv(inv, total);
+#pragma unroll
+  for (int k = KN - 1; k >= 0; k--) {
+    if (k < m) {
+      fp_t wi;  // 1 / w[k]
+      if (k == 0)
+        wi = inv;
+      else {
+        fp_mul(wi, inv, pre[k - 1]);
+        fp_mul(inv, inv, w[k]);
+      }
+      const g1_xyzz& e = tmp[first + k];
+      fp_t a, x, y;
+      fp_mul(a, wi, e.zzz);  // 1/zz
+      fp_mul(x, e.x, a);
+      fp_mul(a, wi, e.zz);  // 1/zzz
+      fp_mul(y, e.y, a);
+      store_affine96(table, table_off + first + k, x, y);
+    }
+  }
+}
+
+// roots_of_unity_brp (src/math.rs:16-29 + BRP, src/kzg/setup.rs:74-75), Montgomery form.
+// thread t computes omega^t by square-and-multiply and stores at bitrev12(t).
+__global__ __launch_bounds__(64) void k_setup_roots(fr_t* __restrict__ roots_brp) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 4096) return;
+  fr_t w;
+  {
+    const uint32_t om[8] = KZG_FR_OMEGA4096_MONT;
+#pragma unroll
+    for (int q = 0; q < 8; q++) w.v[q] = om[q];
+  }
+  fr_t acc = fr_one();
+  for (int bit = 11; bit >= 0; bit--) {
+    fr_sqr(acc, acc);
+    if ((t >> bit) & 1u) fr_mul(acc, acc, w);
+  }
+  roots_brp[bitrev12(t)] = acc;
+}
+
+#endif
+}  // namespace kzg

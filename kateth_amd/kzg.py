@@ -1,0 +1,441 @@
+"""Host-side mirror of kateth's `kzg::Setup` over the C ABI (ctypes).
+
+Method names, argument meaning and error behaviour follow the reference:
+
+    Setup.load_json(path)                        src/kzg/setup.rs:46-82
+    Setup.blob_to_commitment(blob)               src/kzg/setup.rs:167-171   (+ compress, src/bls.rs:491-503)
+    Setup.blob_proof(blob, commitment48)         src/kzg/setup.rs:177-183
+    Setup.proof(blob, z32)                       src/kzg/setup.rs:185-194
+    Setup.verify_proof(proof, commitment, z, y)  src/kzg/setup.rs:96-113
+    Setup.verify_blob_proof(blob, c, p)          src/kzg/setup.rs:208-221
+    Setup.verify_blob_proof_batch(blobs, cs, ps) src/kzg/setup.rs:247-275
+
+Points cross this boundary in their 48-byte compressed form (what every caller
+of the reference does next: benches/kzg.rs:25-32, src/kzg/setup.rs:341-343).
+The `*_batch` / `*_dev` methods expose the batch-level C entry points directly;
+the single-item methods are batches of one.
+"""
+from __future__ import annotations
+
+import ctypes
+import json
+import os
+from typing import Optional, Sequence
+
+BYTES_PER_BLOB = 131072
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+# ---------------------------------------------------------------------------
+# error types (src/blob.rs:6-10, src/bls.rs:21-50, src/kzg/mod.rs:15-31)
+# ---------------------------------------------------------------------------
+class BlobError(Exception):
+    def __init__(self, kind: str):
+        super().__init__("blob::Error::" + kind)
+        self.kind = kind
+
+
+class FiniteFieldError(Exception):
+    def __init__(self, kind: str):
+        super().__init__("bls::FiniteFieldError::" + kind)
+        self.kind = kind
+
+
+class ECGroupError(Exception):
+    def __init__(self, kind: str):
+        super().__init__("bls::ECGroupError::" + kind)
+        self.kind = kind
+
+
+class BlsError(Exception):
+    """`bls::Error` -- wraps FiniteField / ECGroup."""
+
+    def __init__(self, inner: Exception):
+        super().__init__(str(inner))
+        self.inner = inner
+
+
+class KzgError(Exception):
+    """`kzg::Error` -- `Blob(blob::Error)` or `Bls(bls::Error)`."""
+
+    def __init__(self, inner: Exception):
+        super().__init__(str(inner))
+        self.inner = inner
+
+
+class LoadSetupError(Exception):
+    pass
+
+
+class EngineError(RuntimeError):
+    """negative return from the C ABI: HIP / argument / device failure."""
+
+
+_STATUS = {
+    1: lambda: BlobError("InvalidLen"),
+    2: lambda: BlobError("InvalidFieldElement"),
+    3: lambda: ECGroupError("InvalidEncoding"),
+    4: lambda: ECGroupError("NotOnCurve"),
+    5: lambda: ECGroupError("NotInGroup"),
+    6: lambda: FiniteFieldError("InvalidEncoding"),
+    7: lambda: FiniteFieldError("NotInFiniteField"),
+}
+
+
+def error_from_status(code: int) -> Exception:
+    return _STATUS[code]()
+
+
+def _kzg_error(code: int) -> KzgError:
+    inner = error_from_status(code)
+    return KzgError(inner if isinstance(inner, BlobError) else BlsError(inner))
+
+
+# ---------------------------------------------------------------------------
+# library loading -- fails loudly, no fallback
+# ---------------------------------------------------------------------------
+class _Config(ctypes.Structure):
+    _fields_ = [("device", ctypes.c_int32), ("window_bits", ctypes.c_int32), ("flags", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+def library_path() -> str:
+    return os.environ.get("KATETH_AMD_LIB", os.path.join(_HERE, "libkateth_amd.so"))
+
+
+_LIB = None
+
+_u8p = ctypes.c_void_p
+_i32p = ctypes.POINTER(ctypes.c_int32)
+
+_SIGNATURES = {
+    "kzg_last_error": (ctypes.c_char_p, []),
+    "kzg_ctx_create": (ctypes.c_int32, [_u8p, _u8p, ctypes.POINTER(_Config), ctypes.POINTER(ctypes.c_void_p)]),
+    "kzg_ctx_destroy": (None, [ctypes.c_void_p]),
+    "kzg_ctx_window_bits": (ctypes.c_int32, [ctypes.c_void_p]),
+    "kzg_ctx_table_bytes": (ctypes.c_uint64, [ctypes.c_void_p]),
+    "kzg_blob_to_commitment_batch": (ctypes.c_int32, [ctypes.c_void_p, _u8p, ctypes.c_uint64, _u8p, _i32p]),
+    "kzg_blob_to_commitment_batch_dev": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "kzg_compute_blob_proof_batch": (ctypes.c_int32, [ctypes.c_void_p, _u8p, _u8p, ctypes.c_uint64, _u8p, _i32p]),
+    "kzg_compute_blob_proof_batch_dev": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "kzg_compute_proof_batch": (ctypes.c_int32, [ctypes.c_void_p, _u8p, _u8p, ctypes.c_uint64, _u8p, _u8p, _i32p]),
+    "kzg_verify_blob_proof_batch": (ctypes.c_int32, [ctypes.c_void_p, _u8p, _u8p, _u8p, ctypes.c_uint64, _i32p]),
+    "kzg_verify_blob_proof_batch_dev": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, _i32p, ctypes.c_void_p]),
+    "kzg_verify_blob_proof": (ctypes.c_int32, [ctypes.c_void_p, _u8p, _u8p, _u8p, _i32p]),
+    "kzg_verify_proof": (ctypes.c_int32, [ctypes.c_void_p, _u8p, _u8p, _u8p, _u8p, _i32p]),
+    "kzg_verify_blob_proof_batch_partial_dev": (
+        ctypes.c_int32,
+        [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, _u8p, _u8p, _i32p, ctypes.c_void_p],
+    ),
+    "kzg_verify_batch_finish": (ctypes.c_int32, [ctypes.c_void_p, _u8p, ctypes.c_uint64, _i32p]),
+    "kzg_synth_blobs_dev": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p]),
+    "kzg_profile_begin": (ctypes.c_int32, [ctypes.c_void_p]),
+    "kzg_profile_end": (ctypes.c_int32, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]),
+    "kzg_ctx_adds_per_blob": (ctypes.c_uint64, [ctypes.c_void_p]),
+    "kzg_microbench_fp_mul": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(ctypes.c_float)]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def _ensure_hip_runtime():
+    """libkateth_amd.so carries no DT_NEEDED for the HIP runtime: it binds to the
+    libamdhip64 already in the process.  PyTorch-ROCm wheels bundle their own copy
+    and a second runtime in the same process breaks both, so when torch is
+    installed its runtime is the one that gets loaded (and promoted to the global
+    symbol scope); otherwise the system ROCm runtime is."""
+    mode = getattr(ctypes, "RTLD_GLOBAL", 0)
+    try:
+        import torch  # noqa: F401  (plumbing only: loads torch's HIP runtime)
+
+        cand = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            ctypes.CDLL(cand, mode=mode)
+            return
+    except ImportError:
+        pass
+    for cand in (os.environ.get("KATETH_AMD_HIP_RUNTIME", ""), "/opt/rocm/lib/libamdhip64.so", "libamdhip64.so"):
+        if cand:
+            try:
+                ctypes.CDLL(cand, mode=mode)
+                return
+            except OSError:
+                continue
+    raise ImportError("kateth_amd: no HIP runtime (libamdhip64.so) could be loaded")
+
+
+def load_library():
+    """dlopen the HIP engine.  Raises if it has not been built -- by design there
+    is nothing to fall back to."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise ImportError(
+            "kateth_amd: HIP engine %s not found -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % path
+        )
+    _ensure_hip_runtime()
+    lib = ctypes.CDLL(path)
+    for name, (restype, argtypes) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export what include/kateth_amd.h declares
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _LIB = lib
+    return lib
+
+
+def _buf(data) -> bytes:
+    if isinstance(data, (bytes, bytearray, memoryview)):
+        return bytes(data)
+    return bytes(bytearray(data))
+
+
+def _unhex(s: str) -> bytes:
+    """`Bytes` deserialiser (src/bytes.rs:30-37): optional 0x prefix."""
+    return bytes.fromhex(s[2:] if s.startswith("0x") else s)
+
+
+class Setup:
+    """`Setup<4096, 65>` (src/kzg/setup.rs:37-42) resident on one MI355X."""
+
+    G1 = 4096
+    G2 = 65
+
+    def __init__(self, handle: int, lib):
+        self._h = ctypes.c_void_p(handle)
+        self._lib = lib
+
+    # -- construction --------------------------------------------------------
+    @classmethod
+    def load_json(cls, path, device: int = 0, window_bits: int = 0) -> "Setup":
+        """`Setup::load_json` (src/kzg/setup.rs:46-82)."""
+        try:
+            with open(path) as fh:
+                raw = json.load(fh)
+        except OSError as err:
+            raise LoadSetupError("Io(%s)" % err)
+        except ValueError as err:
+            raise LoadSetupError("Serde(%s)" % err)
+        try:
+            g1 = [_unhex(s) for s in raw["g1_lagrange"]]
+            g2 = [_unhex(s) for s in raw["g2_monomial"]]
+        except (KeyError, ValueError, AttributeError) as err:
+            raise LoadSetupError("Serde(%s)" % err)
+        return cls.from_bytes(g1, g2, device=device, window_bits=window_bits)
+
+    @classmethod
+    def from_bytes(cls, g1_lagrange: Sequence[bytes], g2_monomial: Sequence[bytes], device: int = 0, window_bits: int = 0) -> "Setup":
+        if len(g1_lagrange) != cls.G1:
+            raise LoadSetupError("InvalidLenG1Lagrange")  # src/kzg/setup.rs:52-54
+        if len(g2_monomial) != cls.G2:
+            raise LoadSetupError("InvalidLenG2Monomial")  # src/kzg/setup.rs:55-57
+        if any(len(p) != 48 for p in g1_lagrange) or any(len(p) != 96 for p in g2_monomial):
+            raise LoadSetupError("Bls(ECGroup(InvalidEncoding))")
+        lib = load_library()
+        window_bits = window_bits or int(os.environ.get("KATETH_AMD_WINDOW_BITS", "0"))
+        cfg = _Config(device, window_bits, 0, 0)
+        out = ctypes.c_void_p()
+        rc = lib.kzg_ctx_create(b"".join(g1_lagrange), b"".join(g2_monomial), ctypes.byref(cfg), ctypes.byref(out))
+        if rc in (-4, -5):
+            raise LoadSetupError("Bls: " + lib.kzg_last_error().decode())
+        if rc != 0:
+            raise EngineError("kzg_ctx_create failed (%d): %s" % (rc, lib.kzg_last_error().decode()))
+        return cls(out.value, lib)
+
+    def close(self):
+        if self._h:
+            self._lib.kzg_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self) -> int:
+        return self._h.value
+
+    @property
+    def window_bits(self) -> int:
+        return self._lib.kzg_ctx_window_bits(self._h)
+
+    @property
+    def table_bytes(self) -> int:
+        return self._lib.kzg_ctx_table_bytes(self._h)
+
+    def _check(self, rc: int, what: str):
+        if rc < 0:
+            raise EngineError("%s failed (%d): %s" % (what, rc, self._lib.kzg_last_error().decode()))
+
+    # -- batch entry points (host buffers) --------------------------------------
+    def blob_to_commitment_batch(self, blobs: bytes, n: Optional[int] = None):
+        """n concatenated blobs -> (n*48 bytes, [status])."""
+        blobs = _buf(blobs)
+        n = len(blobs) // BYTES_PER_BLOB if n is None else n
+        if len(blobs) != n * BYTES_PER_BLOB:
+            raise BlobError("InvalidLen")
+        out = ctypes.create_string_buffer(48 * n)
+        status = (ctypes.c_int32 * n)()
+        rc = self._lib.kzg_blob_to_commitment_batch(self._h, blobs, n, ctypes.cast(out, ctypes.c_void_p), status)
+        self._check(rc, "kzg_blob_to_commitment_batch")
+        return out.raw, list(status)
+
+    def compute_blob_proof_batch(self, blobs: bytes, commitments: bytes):
+        blobs, commitments = _buf(blobs), _buf(commitments)
+        n = len(commitments) // 48
+        if len(blobs) != n * BYTES_PER_BLOB or len(commitments) != 48 * n:
+            raise BlobError("InvalidLen")
+        out = ctypes.create_string_buffer(48 * n)
+        status = (ctypes.c_int32 * n)()
+        rc = self._lib.kzg_compute_blob_proof_batch(self._h, blobs, commitments, n, ctypes.cast(out, ctypes.c_void_p), status)
+        self._check(rc, "kzg_compute_blob_proof_batch")
+        return out.raw, list(status)
+
+    def compute_proof_batch(self, blobs: bytes, zs: bytes):
+        blobs, zs = _buf(blobs), _buf(zs)
+        n = len(zs) // 32
+        if len(blobs) != n * BYTES_PER_BLOB:
+            raise BlobError("InvalidLen")
+        proofs = ctypes.create_string_buffer(48 * n)
+        ys = ctypes.create_string_buffer(32 * n)
+        status = (ctypes.c_int32 * n)()
+        rc = self._lib.kzg_compute_proof_batch(self._h, blobs, zs, n, ctypes.cast(proofs, ctypes.c_void_p), ctypes.cast(ys, ctypes.c_void_p), status)
+        self._check(rc, "kzg_compute_proof_batch")
+        return proofs.raw, ys.raw, list(status)
+
+    # -- reference-shaped API ----------------------------------------------------
+    def blob_to_commitment(self, blob: bytes) -> bytes:
+        """`Setup::blob_to_commitment` + `compress`: 48-byte commitment or BlobError."""
+        blob = _buf(blob)
+        if len(blob) != BYTES_PER_BLOB:
+            raise BlobError("InvalidLen")  # src/blob.rs:27-29
+        out, status = self.blob_to_commitment_batch(blob, 1)
+        if status[0]:
+            raise error_from_status(status[0])
+        return out
+
+    def blob_proof(self, blob: bytes, commitment: bytes) -> bytes:
+        """`Setup::blob_proof` + `compress` (kzg::Error on bad input)."""
+        blob, commitment = _buf(blob), _buf(commitment)
+        if len(blob) != BYTES_PER_BLOB:
+            raise KzgError(BlobError("InvalidLen"))
+        if len(commitment) != 48:
+            raise KzgError(BlsError(ECGroupError("InvalidEncoding")))
+        out, status = self.compute_blob_proof_batch(blob, commitment)
+        if status[0]:
+            raise _kzg_error(status[0])
+        return out
+
+    def proof(self, blob: bytes, point: bytes):
+        """`Setup::proof`: (proof48, y32)."""
+        blob, point = _buf(blob), _buf(point)
+        if len(blob) != BYTES_PER_BLOB:
+            raise KzgError(BlobError("InvalidLen"))
+        if len(point) != 32:
+            raise KzgError(BlsError(FiniteFieldError("InvalidEncoding")))  # src/bls.rs:131-133
+        proofs, ys, status = self.compute_proof_batch(blob, point)
+        if status[0]:
+            raise _kzg_error(status[0])
+        return proofs, ys
+
+    def verify_proof(self, proof: bytes, commitment: bytes, point: bytes, evaluation: bytes) -> bool:
+        proof, commitment, point, evaluation = _buf(proof), _buf(commitment), _buf(point), _buf(evaluation)
+        if len(proof) != 48 or len(commitment) != 48:
+            raise KzgError(BlsError(ECGroupError("InvalidEncoding")))
+        if len(point) != 32 or len(evaluation) != 32:
+            raise KzgError(BlsError(FiniteFieldError("InvalidEncoding")))
+        ok = ctypes.c_int32(0)
+        rc = self._lib.kzg_verify_proof(self._h, proof, commitment, point, evaluation, ctypes.byref(ok))
+        self._check(rc, "kzg_verify_proof")
+        if rc > 0:
+            raise _kzg_error(rc)
+        return bool(ok.value)
+
+    def verify_blob_proof(self, blob: bytes, commitment: bytes, proof: bytes) -> bool:
+        blob, commitment, proof = _buf(blob), _buf(commitment), _buf(proof)
+        if len(blob) != BYTES_PER_BLOB:
+            raise KzgError(BlobError("InvalidLen"))
+        if len(commitment) != 48 or len(proof) != 48:
+            raise KzgError(BlsError(ECGroupError("InvalidEncoding")))
+        ok = ctypes.c_int32(0)
+        rc = self._lib.kzg_verify_blob_proof(self._h, blob, commitment, proof, ctypes.byref(ok))
+        self._check(rc, "kzg_verify_blob_proof")
+        if rc > 0:
+            raise _kzg_error(rc)
+        return bool(ok.value)
+
+    def verify_blob_proof_batch(self, blobs: Sequence[bytes], commitments: Sequence[bytes], proofs: Sequence[bytes]) -> bool:
+        """`Setup::verify_blob_proof_batch`.  Length mismatch panics in the
+        reference (src/kzg/setup.rs:256-257) -> AssertionError here."""
+        assert len(blobs) == len(commitments), "assertion `left == right` failed"
+        assert len(commitments) == len(proofs), "assertion `left == right` failed"
+        n = len(blobs)
+        # first-error-wins order of the reference: blobs, then commitments, then proofs
+        for b in blobs:
+            if len(b) != BYTES_PER_BLOB:
+                raise KzgError(BlobError("InvalidLen"))
+        for c in list(commitments) + list(proofs):
+            if len(c) != 48:
+                raise KzgError(BlsError(ECGroupError("InvalidEncoding")))
+        ok = ctypes.c_int32(0)
+        rc = self._lib.kzg_verify_blob_proof_batch(
+            self._h, b"".join(_buf(b) for b in blobs), b"".join(_buf(c) for c in commitments), b"".join(_buf(p) for p in proofs), n, ctypes.byref(ok)
+        )
+        self._check(rc, "kzg_verify_blob_proof_batch")
+        if rc > 0:
+            raise _kzg_error(rc)
+        return bool(ok.value)
+
+    # -- device-resident entry points (raw HIP pointers, e.g. torch.Tensor.data_ptr()) ---
+    def blob_to_commitment_batch_dev(self, d_blobs: int, n: int, d_out48: int, d_status: int, stream: int = 0):
+        rc = self._lib.kzg_blob_to_commitment_batch_dev(self._h, d_blobs, n, d_out48, d_status, stream)
+        self._check(rc, "kzg_blob_to_commitment_batch_dev")
+
+    def compute_blob_proof_batch_dev(self, d_blobs: int, d_commitments: int, n: int, d_out48: int, d_status: int, stream: int = 0):
+        rc = self._lib.kzg_compute_blob_proof_batch_dev(self._h, d_blobs, d_commitments, n, d_out48, d_status, stream)
+        self._check(rc, "kzg_compute_blob_proof_batch_dev")
+
+    def verify_blob_proof_batch_dev(self, d_blobs: int, d_commitments: int, d_proofs: int, n: int, stream: int = 0) -> bool:
+        ok = ctypes.c_int32(0)
+        rc = self._lib.kzg_verify_blob_proof_batch_dev(self._h, d_blobs, d_commitments, d_proofs, n, ctypes.byref(ok), stream)
+        self._check(rc, "kzg_verify_blob_proof_batch_dev")
+        if rc > 0:
+            raise _kzg_error(rc)
+        return bool(ok.value)
+
+    def verify_partial_dev(self, d_blobs: int, d_commitments: int, d_proofs: int, n_local: int, first_index: int, n_total: int, seed32: bytes, stream: int = 0):
+        out = ctypes.create_string_buffer(192)
+        err = (ctypes.c_int32 * 2)()
+        rc = self._lib.kzg_verify_blob_proof_batch_partial_dev(
+            self._h, d_blobs, d_commitments, d_proofs, n_local, first_index, n_total, _buf(seed32), ctypes.cast(out, ctypes.c_void_p), err, stream
+        )
+        self._check(rc, "kzg_verify_blob_proof_batch_partial_dev")
+        return out.raw, (err[0], err[1])
+
+    def verify_batch_finish(self, partials: bytes) -> bool:
+        ok = ctypes.c_int32(0)
+        rc = self._lib.kzg_verify_batch_finish(self._h, _buf(partials), len(partials) // 192, ctypes.byref(ok))
+        self._check(rc, "kzg_verify_batch_finish")
+        return bool(ok.value)
+
+    def synth_blobs_dev(self, seed: int, first_index: int, n: int, d_blobs: int, stream: int = 0):
+        rc = self._lib.kzg_synth_blobs_dev(self._h, seed, first_index, n, d_blobs, stream)
+        self._check(rc, "kzg_synth_blobs_dev")
+
+    def profile_begin(self):
+        self._check(self._lib.kzg_profile_begin(self._h), "kzg_profile_begin")
+
+    def profile_end(self) -> dict:
+        ms = ctypes.c_double(0)
+        cnt = ctypes.c_uint64(0)
+        self._check(self._lib.kzg_profile_end(self._h, ctypes.byref(ms), ctypes.byref(cnt)), "kzg_profile_end")
+        return {"msm_ms": ms.value, "msm_launches": cnt.value, "adds_per_blob": self._lib.kzg_ctx_adds_per_blob(self._h)}
+
+    def microbench_fp_mul(self, lanes: int, iters: int) -> float:
+        ms = ctypes.c_float(0)
+        rc = self._lib.kzg_microbench_fp_mul(self._h, lanes, iters, ctypes.byref(ms))
+        self._check(rc, "kzg_microbench_fp_mul")
+        return ms.value

@@ -1,0 +1,136 @@
+"""CPU unit tests of the product's single-source field / curve / hash headers
+(kateth_amd/csrc/{field,g1,sha256}.cuh compiled for the host by g++), checked
+against the Python oracle.  The same source is what the HIP kernels inline."""
+import ctypes
+import hashlib
+import os
+import random
+import subprocess
+
+import pytest
+
+from oracle.pyref import bls
+
+HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostmath")
+P, R = bls.P, bls.R
+
+
+@pytest.fixture(scope="module")
+def hm():
+    so = os.path.join(HERE, "libhostmath.so")
+    src = os.path.join(HERE, "shim.cpp")
+    hdr_dir = os.path.join(os.path.dirname(HERE), "..", "kateth_amd", "csrc")
+    newest = max(os.path.getmtime(os.path.join(hdr_dir, f)) for f in os.listdir(hdr_dir) if f.endswith(".cuh"))
+    if not os.path.exists(so) or os.path.getmtime(so) < max(newest, os.path.getmtime(src)):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", src, "-o", so])
+    return ctypes.CDLL(so)
+
+
+def _op(lib, fn, op, a, b, nbytes):
+    out = ctypes.create_string_buffer(nbytes)
+    getattr(lib, fn)(op, out, int(a).to_bytes(nbytes, "little"), int(b).to_bytes(nbytes, "little"))
+    return int.from_bytes(out.raw, "little")
+
+
+@pytest.mark.parametrize("fn,mod,nb", [("hm_fp_op", P, 48), ("hm_fr_op", R, 32)])
+def test_field_ops(hm, fn, mod, nb):
+    rnd = random.Random(11)
+    edge = [0, 1, 2, mod - 1, mod - 2, (mod - 1) // 2, (mod + 1) // 2, (1 << (8 * nb - 8)) % mod]
+    vals = edge + [rnd.randrange(mod) for _ in range(40)]
+    for a in vals:
+        for b in (vals[rnd.randrange(len(vals))], vals[rnd.randrange(len(vals))], a):
+            assert _op(hm, fn, 0, a, b, nb) == a * b % mod
+            assert _op(hm, fn, 1, a, b, nb) == (a + b) % mod
+            assert _op(hm, fn, 2, a, b, nb) == (a - b) % mod
+        assert _op(hm, fn, 3, a, 0, nb) == (-a) % mod
+        assert _op(hm, fn, 4, a, 0, nb) == a * a % mod
+    for a in vals[:12]:
+        inv = _op(hm, fn, 5, a, 0, nb)
+        assert inv == (pow(a, -1, mod) if a else 0)
+
+
+def test_fp_sqrt(hm):
+    rnd = random.Random(5)
+    for _ in range(10):
+        a = rnd.randrange(P)
+        sq = a * a % P
+        s = _op(hm, "hm_fp_op", 6, sq, 0, 48)
+        assert s in (a, P - a)
+
+
+def test_sha256_and_hash_to_fr(hm):
+    rnd = random.Random(3)
+    for ln in (0, 1, 20, 55, 56, 63, 64, 65, 119, 120, 128, 1000, 131152):
+        msg = bytes(rnd.randrange(256) for _ in range(ln))
+        out = ctypes.create_string_buffer(32)
+        hm.hm_sha256(out, msg, ctypes.c_uint64(ln))
+        assert out.raw == hashlib.sha256(msg).digest()
+        hm.hm_hash_to_fr(out, msg, ctypes.c_uint64(ln))
+        assert int.from_bytes(out.raw, "big") == bls.fr_hash_to(msg)
+
+
+def _sum(hm, pts, check=0):
+    out = ctypes.create_string_buffer(48)
+    st = hm.hm_g1_sum(out, b"".join(pts), len(pts), check)
+    return st, out.raw
+
+
+def test_g1_madd_complete(hm):
+    g = bls.G1_GEN
+    pts = [bls.g1_mul(g, k) for k in (1, 2, 3, 5, 0xABCDEF123456789)]
+    enc = [bls.g1_compress(p) for p in pts]
+    st, out = _sum(hm, enc)
+    want = None
+    for p in pts:
+        want = bls.g1_add(want, p)
+    assert st == 0 and out == bls.g1_compress(want)
+    # P + P (doubling branch), P + (-P) (cancellation), infinity operands
+    st, out = _sum(hm, [enc[0], enc[0]])
+    assert out == bls.g1_compress(bls.g1_mul(g, 2))
+    st, out = _sum(hm, [enc[1], enc[2], bls.g1_compress(bls.g1_mul(g, 5))])  # (2G+3G) + 5G
+    assert out == bls.g1_compress(bls.g1_mul(g, 10))
+    st, out = _sum(hm, [enc[3], bls.g1_compress(bls.g1_neg(pts[3]))])
+    assert out == bls.g1_compress(None)
+    st, out = _sum(hm, [bls.g1_compress(None), enc[4], bls.g1_compress(None)])
+    assert out == enc[4]
+    st, out = _sum(hm, [])
+    assert out == bls.g1_compress(None)
+
+
+def test_g1_full_add_and_mul(hm):
+    g = bls.G1_GEN
+    a, b = bls.g1_mul(g, 77), bls.g1_mul(g, 1234567)
+    out = ctypes.create_string_buffer(48)
+    for x, y in ((a, b), (a, a), (a, bls.g1_neg(a)), (None, b), (a, None), (None, None)):
+        assert hm.hm_g1_add_full(out, bls.g1_compress(x), bls.g1_compress(y)) == 0
+        assert out.raw == bls.g1_compress(bls.g1_add(x, y))
+    rnd = random.Random(9)
+    for k in (0, 1, 2, R - 1, rnd.randrange(R), rnd.randrange(R)):
+        assert hm.hm_g1_mul(out, bls.g1_compress(a), k.to_bytes(32, "big")) == 0
+        assert out.raw == bls.g1_compress(bls.g1_mul(a, k))
+
+
+def test_g1_decompress_status_codes(hm):
+    gen = bls.g1_compress(bls.G1_GEN)
+    assert hm.hm_g1_decompress_status(gen) == 0
+    assert hm.hm_g1_decompress_status(bls.g1_compress(None)) == 0
+    assert hm.hm_g1_decompress_status(bytes([gen[0] & 0x7F]) + gen[1:]) == 3
+    assert hm.hm_g1_decompress_status(bytes([0x9A]) + bytes([0xFF] * 47)) == 3
+    assert hm.hm_g1_decompress_status(bytes([0xE0]) + bytes(47)) == 3
+    assert hm.hm_g1_decompress_status(bytes([0xC0]) + bytes(46) + b"\x01") == 3
+    x = 1
+    while bls._fp_sqrt(x**3 + 4) is not None:
+        x += 1
+    assert hm.hm_g1_decompress_status(bytes([0x80]) + x.to_bytes(48, "big")[1:]) == 4
+    x = 1
+    while True:
+        y = bls._fp_sqrt(x**3 + 4)
+        if y is not None and not bls.g1_in_subgroup((x, y)):
+            break
+        x += 1
+    assert hm.hm_g1_decompress_status(bls.g1_compress((x, y))) == 5
+    # both sign choices decode to the right y
+    q = bls.g1_mul(bls.G1_GEN, 424242)
+    for pt in (q, bls.g1_neg(q)):
+        st, out = _sum(hm, [bls.g1_compress(pt)])
+        assert st == 0 and out == bls.g1_compress(pt)
