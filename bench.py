@@ -43,17 +43,19 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(sample_blobs, setup_path):
+def cpu_baseline(sample_blobs, setup_path, gpu_out48):
     """oracle/cport (C port of kateth's CPU path: Pippenger c=10 signed digits as
-    blst uses) timed on the host cores, rank 0 only.  Checker code: never the
-    thing measured as `value`."""
-    so = os.path.join(ROOT, "oracle", "cport", "libkzg_cport.so")
-    if not os.path.exists(so):
-        return None
-    lib = ctypes.CDLL(so)
+    blst uses, bases re-normalised on every call, one thread and all host cores)
+    timed on a bounded sample of the same synthetic blobs, rank 0 only.  Checker
+    code: never the thing measured as `value`.  Its outputs are compared byte for
+    byte with the GPU's for the same blobs."""
     from oracle.cport import binding
 
-    return binding.time_commitment(lib, setup_path, sample_blobs, SEED)
+    res = binding.time_commitment(None, setup_path, sample_blobs, SEED)
+    raw = res.pop("_raw_outputs")
+    res.pop("outputs", None)
+    res["matches_gpu_bytes"] = bool(raw == gpu_out48[: len(raw)])
+    return res
 
 
 def main():
@@ -115,9 +117,10 @@ def main():
     assert int(d_status.abs().sum()) == 0, "synthetic blobs must all be valid"
 
     # ---- correctness spot check of the timed output against the oracle golden vectors
+    gpu_out = d_out.cpu().numpy().tobytes() if rank == 0 else b""
     if rank == 0:
         golden = json.load(open(os.path.join(ROOT, "tests", "golden", "kzg_vectors.json")))
-        out = d_out[: 48 * len(golden["blobs"])].cpu().numpy().tobytes()
+        out = gpu_out
         for rec in golden["blobs"]:
             b = rec["index"]
             if b < n:
@@ -147,6 +150,10 @@ def main():
         },
     }
     if rank == 0:
+        # measured integer-ALU ceiling: dependent Fp Montgomery multiplies, 8 waves/SIMD, whole chip
+        lanes = 256 * 4 * 64 * 8
+        setup.microbench_fp_mul(lanes, 200)
+        prof["fp_mul_peak_per_s"] = lanes * 2000 / (setup.microbench_fp_mul(lanes, 2000) * 1e-3)
         k_ms = prof["msm_ms"] / max(1, prof["msm_launches"])
         alg_bytes = ALG_BYTES_COMMIT * n  # per launch: one launch processes the rank's whole batch
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else None
@@ -171,7 +178,7 @@ def main():
             result["roofline"]["valu_frac"] = result["roofline"]["valu_fp_mul_per_s"] / result["roofline"]["valu_fp_mul_peak_per_s"]
         if not args.no_cpu_baseline and world == 1:
             try:
-                result["cpu_baseline"] = cpu_baseline(args.cpu_sample, setup_path)
+                result["cpu_baseline"] = cpu_baseline(args.cpu_sample, setup_path, gpu_out)
             except Exception as err:  # the baseline is reporting only; never hide the GPU number
                 result["cpu_baseline"] = {"value": None, "error": repr(err)}
         print(json.dumps(result), flush=True)

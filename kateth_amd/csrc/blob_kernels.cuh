@@ -8,6 +8,30 @@
 namespace kzg {
 #if defined(__HIPCC__)
 
+__device__ __forceinline__ void store_affine96_(uint4* tbl, uint64_t idx, const fp_t& x, const fp_t& y) {
+  uint4* p = tbl + idx * 6;
+  p[0] = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
+  p[1] = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
+  p[2] = make_uint4(x.v[8], x.v[9], x.v[10], x.v[11]);
+  p[3] = make_uint4(y.v[0], y.v[1], y.v[2], y.v[3]);
+  p[4] = make_uint4(y.v[4], y.v[5], y.v[6], y.v[7]);
+  p[5] = make_uint4(y.v[8], y.v[9], y.v[10], y.v[11]);
+}
+
+// 32 big-endian bytes (16-B aligned) -> 8 plain little-endian limbs
+__device__ __forceinline__ void load_scalar_be_(uint32_t* sc, const uint8_t* __restrict__ p) {
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  uint4 w0 = q[0], w1 = q[1];
+  sc[7] = __builtin_bswap32(w0.x);
+  sc[6] = __builtin_bswap32(w0.y);
+  sc[5] = __builtin_bswap32(w0.z);
+  sc[4] = __builtin_bswap32(w0.w);
+  sc[3] = __builtin_bswap32(w1.x);
+  sc[2] = __builtin_bswap32(w1.y);
+  sc[1] = __builtin_bswap32(w1.z);
+  sc[0] = __builtin_bswap32(w1.w);
+}
+
 // element(b, i) = SHA-256(seed_le64 || b_le64 || i_le32) mod r, 32 B big-endian
 // (seeded counterpart of Blob::random, src/blob.rs:66-76).  One thread per element.
 __global__ __launch_bounds__(256) void k_synth_blobs(uint64_t seed, uint64_t first_index, uint64_t elems, uint8_t* __restrict__ out) {
@@ -35,6 +59,322 @@ __global__ __launch_bounds__(256) void k_synth_blobs(uint64_t seed, uint64_t fir
   uint4* o = reinterpret_cast<uint4*>(out + e * 32);
   o[0] = make_uint4(__builtin_bswap32(v.v[7]), __builtin_bswap32(v.v[6]), __builtin_bswap32(v.v[5]), __builtin_bswap32(v.v[4]));
   o[1] = make_uint4(__builtin_bswap32(v.v[3]), __builtin_bswap32(v.v[2]), __builtin_bswap32(v.v[1]), __builtin_bswap32(v.v[0]));
+}
+
+// ---------------------------------------------------------------------------
+// K7: P1::decompress (src/bls.rs:505-531) for n points, one thread per point.
+// status[i] = 0 / KZG_ERR_EC_*.  If `affine` != null the decoded point is stored
+// (Montgomery x,y; infinity -> all-zero entry and inf[i] = 1).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_g1_decompress(const uint8_t* __restrict__ in48, uint64_t n, int32_t* __restrict__ status,
+                                                      uint4* __restrict__ affine, uint8_t* __restrict__ inf) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint8_t buf[48];
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(in48 + i * 48);
+#pragma unroll
+  for (int q = 0; q < 12; q++) {
+    uint32_t w = src[q];
+    buf[4 * q] = (uint8_t)w;
+    buf[4 * q + 1] = (uint8_t)(w >> 8);
+    buf[4 * q + 2] = (uint8_t)(w >> 16);
+    buf[4 * q + 3] = (uint8_t)(w >> 24);
+  }
+  fp_t x, y;
+  bool is_inf = false;
+  int32_t st = g1_decompress(x, y, is_inf, buf);
+  status[i] = st;
+  if (affine != nullptr) {
+    if (st != 0 || is_inf) {
+      bn_zero(x);
+      bn_zero(y);
+    }
+    store_affine96_(affine, i, x, y);
+    inf[i] = (st == 0 && is_inf) ? 1 : 0;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K4: Blob::challenge (src/blob.rs:78-97) -- z = SHA-256("FSBLOBVERIFY_V1_" ||
+// u128_be(4096) || blob || commitment48) mod r, one thread per blob, 2050
+// sequential blocks.  The commitment BYTES are hashed as given (for a valid
+// encoding compress(decompress(c)) == c).  Output: plain (non-Montgomery) limbs.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void load_be_words16(uint32_t* w, const uint8_t* __restrict__ p) {  // 16 B aligned source
+  uint4 v = *reinterpret_cast<const uint4*>(p);
+  w[0] = __builtin_bswap32(v.x);
+  w[1] = __builtin_bswap32(v.y);
+  w[2] = __builtin_bswap32(v.z);
+  w[3] = __builtin_bswap32(v.w);
+}
+
+__global__ __launch_bounds__(64) void k_challenge(const uint8_t* __restrict__ blobs, const uint8_t* __restrict__ commitments48, uint64_t n,
+                                                  fr_t* __restrict__ z_plain) {
+  const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n) return;
+  const uint8_t* blob = blobs + b * 131072ull;
+  const uint8_t* com = commitments48 + b * 48;
+  sha256_state s;
+  sha256_init(s);
+  uint32_t w[16];
+  // block 0: domain separator, degree, first 32 blob bytes
+  w[0] = 0x4653424cu;  // "FSBL"
+  w[1] = 0x4f425645u;  // "OBVE"
+  w[2] = 0x52494659u;  // "RIFY"
+  w[3] = 0x5f56315fu;  // "_V1_"
+  w[4] = 0;
+  w[5] = 0;
+  w[6] = 0;
+  w[7] = 4096;
+  load_be_words16(w + 8, blob);
+  load_be_words16(w + 12, blob + 16);
+  sha256_block(s, w);
+  // blocks 1..2047: blob bytes [64k-32, 64k+32)
+  uint32_t nw[16];
+  load_be_words16(nw, blob + 32);
+  load_be_words16(nw + 4, blob + 48);
+  load_be_words16(nw + 8, blob + 64);
+  load_be_words16(nw + 12, blob + 80);
+#pragma unroll 1
+  for (uint32_t k = 1; k < 2048; k++) {
+#pragma unroll
+    for (int q = 0; q < 16; q++) w[q] = nw[q];
+    if (k < 2047) {  // prefetch the next block while this one is hashed
+      const uint8_t* nx = blob + 64u * (k + 1) - 32u;
+      load_be_words16(nw, nx);
+      load_be_words16(nw + 4, nx + 16);
+      load_be_words16(nw + 8, nx + 32);
+      load_be_words16(nw + 12, nx + 48);
+    }
+    sha256_block(s, w);
+  }
+  // block 2048: last 32 blob bytes + first 32 commitment bytes
+  load_be_words16(w, blob + 131040);
+  load_be_words16(w + 4, blob + 131056);
+  load_be_words16(w + 8, com);
+  load_be_words16(w + 12, com + 16);
+  sha256_block(s, w);
+  // block 2049: last 16 commitment bytes, padding, bit length of 131152 bytes
+  load_be_words16(w, com + 32);
+  w[4] = 0x80000000u;
+#pragma unroll
+  for (int q = 5; q < 15; q++) w[q] = 0;
+  w[15] = 131152u * 8u;
+  sha256_block(s, w);
+  fr_t v;
+#pragma unroll
+  for (int q = 0; q < 8; q++) v.v[7 - q] = s.h[q];
+  fr_reduce_256(v);
+  z_plain[b] = v;
+}
+
+// z given by the caller (Setup::proof, src/kzg/setup.rs:185-194): parse + range check
+__global__ __launch_bounds__(64) void k_fr_parse(const uint8_t* __restrict__ in32, uint64_t n, fr_t* __restrict__ out_plain, int32_t* __restrict__ status) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t sc[8];
+  load_scalar_be_(sc, in32 + i * 32);
+  fr_t v;
+#pragma unroll
+  for (int q = 0; q < 8; q++) v.v[q] = sc[q];
+  if (!fr_is_canonical(v)) {
+    if (status[i] == 0) status[i] = KZG_ERR_FF_NOT_IN_FIELD;
+    bn_zero(v);
+  }
+  out_plain[i] = v;
+}
+
+// ---------------------------------------------------------------------------
+// K1 + K5 + K6: Blob::from_slice validation (src/blob.rs:26-37),
+// Polynomial::evaluate (src/kzg/poly.rs:10-33) and the quotient of
+// Polynomial::prove (src/kzg/poly.rs:44-66), one 512-thread workgroup per blob,
+// 8 elements per thread held in registers.
+//
+// The reference performs one field inversion per element (4096 + 4096 per
+// proof); here all 4096 denominators (z - w_i) are inverted with ONE inversion
+// per blob: per-thread prefix products, a 512-leaf product tree in LDS, a single
+// Fermat inversion of the root, and the inverse pushed back down the tree.
+//   y   = (z^4096 - 1)/4096 * sum_i e_i w_i / (z - w_i)          (z outside the domain)
+//   q_i = (e_i - y) / (w_i - z) = (y - e_i) * inv(z - w_i)
+// In-domain z == w_m (poly.rs:14-18, :50-64): y = e_m and
+//   q_m = w_m^-1 * sum_{j != m} (e_j - y) w_j / (w_m - w_j) = -w_m^-1 * sum_{j != m} q_j w_j .
+// status[b] |= KZG_ERR_BLOB_INVALID_FIELD_ELEMENT when an element is >= r.
+// Outputs are plain (non-Montgomery) little-endian limbs.
+// ---------------------------------------------------------------------------
+template <bool QUOTIENT>
+__global__ __launch_bounds__(512) void k_poly(const uint8_t* __restrict__ blobs, const fr_t* __restrict__ z_plain,
+                                              const fr_t* __restrict__ roots_brp, fr_t* __restrict__ y_plain, fr_t* __restrict__ q_plain,
+                                              int32_t* __restrict__ status) {
+  __shared__ fr_t tree[1024];
+  __shared__ int sh_domain;
+  __shared__ int sh_bad;
+  __shared__ fr_t sh_y;
+  const int t = threadIdx.x;
+  const uint64_t b = blockIdx.x;
+  const uint8_t* blob = blobs + b * 131072ull;
+  if (t == 0) {
+    sh_domain = -1;
+    sh_bad = 0;
+  }
+  __syncthreads();
+  fr_t z;
+  to_mont<FrParams>(z, z_plain[b]);
+  fr_t e[8], pre[8];
+  fr_t run = fr_one();
+  bool bad = false;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const int i = k * 512 + t;
+    uint32_t sc[8];
+    load_scalar_be_(sc, blob + (uint64_t)i * 32u);
+    fr_t v;
+#pragma unroll
+    for (int q = 0; q < 8; q++) v.v[q] = sc[q];
+    if (!fr_is_canonical(v)) {
+      bad = true;
+      bn_zero(v);
+    }
+    to_mont<FrParams>(e[k], v);
+    fr_t d;
+    fr_sub(d, z, roots_brp[i]);
+    if (bn_is_zero(d)) {
+      sh_domain = i;  // at most one index can match
+      d = fr_one();
+    }
+    fr_mul(run, run, d);
+    pre[k] = run;
+  }
+  if (bad) sh_bad = 1;
+  tree[512 + t] = run;
+  __syncthreads();
+  // product tree: node j = node 2j * node 2j+1
+  for (int width = 256; width >= 1; width >>= 1) {
+    if (t < width) {
+      fr_t a = tree[2 * (width + t)], c = tree[2 * (width + t) + 1], r;
+      fr_mul(r, a, c);
+      tree[width + t] = r;
+    }
+    __syncthreads();
+  }
+  if (t == 0) {
+    fr_t r = tree[1], ri;
+    fr_inv(ri, r);
+    tree[1] = ri;
+  }
+  __syncthreads();
+  // push inverses down: children of j get inv(j) * sibling product
+  for (int width = 1; width <= 256; width <<= 1) {
+    if (t < width) {
+      const int j = width + t;
+      fr_t ip = tree[j], a = tree[2 * j], c = tree[2 * j + 1], ra, rc;
+      fr_mul(ra, ip, c);
+      fr_mul(rc, ip, a);
+      tree[2 * j] = ra;
+      tree[2 * j + 1] = rc;
+    }
+    __syncthreads();
+  }
+  const int domain = sh_domain;
+  fr_t inv_run = tree[512 + t];  // inverse of this thread's total product
+  __syncthreads();
+  fr_t ysum;
+  bn_zero(ysum);
+#pragma unroll
+  for (int k = 7; k >= 0; k--) {
+    const int i = k * 512 + t;
+    const fr_t w = roots_brp[i];
+    fr_t d, inv_d, term;
+    fr_sub(d, z, w);
+    if (i == domain) d = fr_one();
+    if (k == 0)
+      inv_d = inv_run;
+    else
+      fr_mul(inv_d, inv_run, pre[k - 1]);
+    fr_mul(inv_run, inv_run, d);
+    pre[k] = inv_d;  // slot k now holds 1/(z - w_i)
+    fr_mul(term, e[k], w);
+    fr_mul(term, term, inv_d);
+    if (i != domain) fr_add(ysum, ysum, term);
+  }
+  // block sum of ysum
+  tree[t] = ysum;
+  __syncthreads();
+  for (int width = 256; width >= 1; width >>= 1) {
+    if (t < width) {
+      fr_t a = tree[t], c = tree[t + width], r;
+      fr_add(r, a, c);
+      tree[t] = r;
+    }
+    __syncthreads();
+  }
+  if (t == 0) {
+    fr_t total = tree[0], zn = z, f;
+    for (int q = 0; q < 12; q++) fr_sqr(zn, zn);  // z^4096
+    fr_sub(zn, zn, fr_one());
+    {
+      const uint32_t c4096[8] = KZG_FR_INV4096_MONT;
+#pragma unroll
+      for (int q = 0; q < 8; q++) f.v[q] = c4096[q];
+    }
+    fr_mul(f, f, zn);
+    fr_mul(total, total, f);
+    sh_y = total;
+  }
+  __syncthreads();
+  if (domain >= 0 && (domain & 511) == t) {
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+      if (k == (domain >> 9)) sh_y = e[k];  // y = e_m (poly.rs:14-18)
+  }
+  __syncthreads();
+  const fr_t y = sh_y;
+  if (t == 0) {
+    fr_t yp;
+    from_mont<FrParams>(yp, y);
+    y_plain[b] = yp;
+    if (sh_bad) atomicOr(&status[b], KZG_ERR_BLOB_INVALID_FIELD_ELEMENT);
+  }
+  if (QUOTIENT) {
+    fr_t* qout = q_plain + b * 4096ull;
+    fr_t ssum;
+    bn_zero(ssum);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int i = k * 512 + t;
+      fr_t q, qp;
+      fr_sub(q, y, e[k]);
+      fr_mul(q, q, pre[k]);
+      if (i == domain) bn_zero(q);
+      if (domain >= 0) {  // block-uniform
+        fr_t qw;
+        fr_mul(qw, q, roots_brp[i]);
+        fr_add(ssum, ssum, qw);
+      }
+      from_mont<FrParams>(qp, q);
+      qout[i] = qp;
+    }
+    if (domain >= 0) {  // rare in-domain branch (poly.rs:50-64)
+      __syncthreads();
+      tree[t] = ssum;
+      __syncthreads();
+      for (int width = 256; width >= 1; width >>= 1) {
+        if (t < width) {
+          fr_t a = tree[t], c = tree[t + width], r;
+          fr_add(r, a, c);
+          tree[t] = r;
+        }
+        __syncthreads();
+      }
+      if (t == 0) {
+        fr_t wm = roots_brp[domain], wi, qm, qp;
+        fr_inv(wi, wm);
+        fr_mul(qm, tree[0], wi);
+        fr_neg(qm, qm);
+        from_mont<FrParams>(qp, qm);
+        qout[domain] = qp;
+      }
+    }
+  }
 }
 
 #endif

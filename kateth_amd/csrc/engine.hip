@@ -6,6 +6,7 @@
 // fails with KZG_FAIL_NO_DEVICE / KZG_FAIL_HIP.
 #include <hip/hip_runtime.h>
 
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -49,6 +50,7 @@ struct kzg_ctx {
   fr_t* d_roots_brp = nullptr;   // 4096 roots of unity, Montgomery, BRP order
   uint64_t table_bytes = 0;
   uint32_t num_cus = 256;
+  int msm_occupancy = 2;  // waves per SIMD the MSM kernel is compiled for (KATETH_AMD_MSM_OCC=3: experiment)
   // workspace (grown on demand, guarded by lock)
   mutable std::mutex lock;
   mutable void* ws = nullptr;
@@ -229,6 +231,7 @@ extern "C" int32_t kzg_ctx_create(const uint8_t* g1_lagrange, const uint8_t* g2_
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cus = (uint32_t)prop.multiProcessorCount;
   memcpy(ctx->g2_tau, g2_monomial + 96, 96);
+  if (const char* e = getenv("KATETH_AMD_MSM_OCC")) ctx->msm_occupancy = (atoi(e) == 3) ? 3 : 2;
   int32_t rc = ctx_build(ctx, g1_lagrange, g2_monomial);
   if (rc != 0) {
     std::string keep = g_last_error;
@@ -243,26 +246,28 @@ extern "C" int32_t kzg_ctx_create(const uint8_t* g1_lagrange, const uint8_t* g2_
 // ---------------------------------------------------------------------------
 // blob_to_kzg_commitment
 // ---------------------------------------------------------------------------
+template <bool BE_BYTES>
+static int32_t msm_pipeline(const kzg_ctx* ctx, const uint8_t* d_scalars, uint64_t n, uint8_t* d_out48, int32_t* d_status, g1_xyzz* partials,
+                            g1_xyzz* sums, uint32_t splits, hipStream_t st);
+
 static int32_t commit_dev_locked(const kzg_ctx* ctx, const void* d_blobs, uint64_t n, void* d_out48, int32_t* d_status, hipStream_t st) {
   if (n == 0) return 0;
-  const uint32_t splits = choose_splits(ctx, n);
-  const size_t need = (size_t)n * splits * sizeof(g1_xyzz);
+  const uint64_t chunk_max = 16384;  // bounds the lane-partial scratch (12 KiB per blob)
+  const uint64_t cn = n < chunk_max ? n : chunk_max;
+  const uint32_t splits = choose_splits(ctx, cn);
+  const size_t partial_bytes = (size_t)cn * splits * 64 * sizeof(g1_xyzz);
+  const size_t need = partial_bytes + (size_t)cn * sizeof(g1_xyzz);
   int32_t rc = ws_reserve(ctx, need);
   if (rc) return rc;
   g1_xyzz* partials = reinterpret_cast<g1_xyzz*>(ctx->ws);
+  g1_xyzz* sums = reinterpret_cast<g1_xyzz*>(reinterpret_cast<uint8_t*>(ctx->ws) + partial_bytes);
   HIP_TRY(hipMemsetAsync(d_status, 0, n * sizeof(int32_t), st));
-  if (n * splits > 0x7fffffffull) return fail(KZG_FAIL_ARGUMENT, "batch too large for one launch");
-  hipEvent_t pe0, pe1;
-  rc = prof_next(ctx, &pe0, &pe1);
-  if (rc) return rc;
-  if (pe0) HIP_TRY(hipEventRecord(pe0, st));
-  hipLaunchKernelGGL(k_msm_fixed<true>, dim3((unsigned)(n * splits)), dim3(64), 0, st, reinterpret_cast<const uint8_t*>(d_blobs), splits,
-                     ctx->d_table, ctx->geom, partials, d_status);
-  HIP_TRY(hipGetLastError());
-  if (pe1) HIP_TRY(hipEventRecord(pe1, st));
-  hipLaunchKernelGGL(k_msm_finalize, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, partials, splits, n, d_status,
-                     reinterpret_cast<uint8_t*>(d_out48));
-  HIP_TRY(hipGetLastError());
+  for (uint64_t base = 0; base < n; base += cn) {
+    const uint64_t m = (n - base < cn) ? (n - base) : cn;
+    rc = msm_pipeline<true>(ctx, reinterpret_cast<const uint8_t*>(d_blobs) + base * (uint64_t)KZG_BYTES_PER_BLOB, m,
+                            reinterpret_cast<uint8_t*>(d_out48) + base * 48, d_status + base, partials, sums, splits, st);
+    if (rc) return rc;
+  }
   return 0;
 }
 

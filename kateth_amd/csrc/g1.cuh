@@ -36,7 +36,7 @@ KZG_HD void xyzz_from_affine(g1_xyzz& p, const fp_t& x, const fp_t& y) {
 
 // p = 2*(x, y)   (mdbl-2008-s-1, a = 0).  (x,y) must not be infinity; y == 0
 // cannot happen on this curve's prime-order subgroup but is handled (-> inf).
-KZG_HD_NOINLINE void xyzz_mdbl(g1_xyzz& p, const fp_t& x, const fp_t& y) {
+KZG_HD void xyzz_mdbl_inl(g1_xyzz& p, const fp_t& x, const fp_t& y) {
   if (bn_is_zero(y)) {
     xyzz_set_inf(p);
     return;
@@ -59,6 +59,7 @@ KZG_HD_NOINLINE void xyzz_mdbl(g1_xyzz& p, const fp_t& x, const fp_t& y) {
   p.zz = v;
   p.zzz = w;
 }
+KZG_HD_NOINLINE void xyzz_mdbl(g1_xyzz& p, const fp_t& x, const fp_t& y) { xyzz_mdbl_inl(p, x, y); }
 
 // p = 2*p  (dbl-2008-s-1)
 KZG_HD_NOINLINE void xyzz_dbl(g1_xyzz& p) {
@@ -89,14 +90,6 @@ KZG_HD_NOINLINE void xyzz_dbl(g1_xyzz& p) {
   p.y = y3;
 }
 
-// rare paths of the mixed add, kept out of line so the hot loop stays small
-KZG_HD_NOINLINE void xyzz_madd_special(g1_xyzz& p, const fp_t& x2, const fp_t& y2, bool same_y) {
-  if (same_y)
-    xyzz_mdbl(p, x2, y2);  // P + P
-  else
-    xyzz_set_inf(p);  // P + (-P)
-}
-
 // p += (x2, y2)  with (x2, y2) a finite affine point   (madd-2008-s)
 KZG_HD void xyzz_madd(g1_xyzz& p, const fp_t& x2, const fp_t& y2) {
   if (xyzz_is_inf(p)) {
@@ -108,11 +101,13 @@ KZG_HD void xyzz_madd(g1_xyzz& p, const fp_t& x2, const fp_t& y2) {
   fp_mul(s2, y2, p.zzz);
   fp_sub(u2, u2, p.x);  // P
   fp_sub(r, s2, p.y);   // R
-  if (bn_is_zero(u2)) {  // rare: work on a copy so `p` itself never has its address taken
-    g1_xyzz tmp = p;
-    fp_t tx = x2, ty = y2;
-    xyzz_madd_special(tmp, tx, ty, bn_is_zero(r));
-    p = tmp;
+  if (bn_is_zero(u2)) {
+    // rare (P == +-Q): handled inline -- an out-of-line call would take the address of the
+    // caller's accumulator and operands and force them into scratch memory in the hot loop
+    if (bn_is_zero(r))
+      xyzz_mdbl_inl(p, x2, y2);  // P + P
+    else
+      xyzz_set_inf(p);  // P + (-P)
     return;
   }
   fp_sqr(pp, u2);

@@ -103,11 +103,10 @@ __device__ __forceinline__ void wave_reduce_xyzz(g1_xyzz& acc, g1_xyzz* lds, int
 // One wave per (blob, split).  BE_BYTES: scalars are raw blob bytes (32-B
 // big-endian, validated here: Blob::from_slice, src/blob.rs:26-37); otherwise
 // canonical little-endian limbs produced on device (quotient polynomial).
-template <bool BE_BYTES>
-__global__ __launch_bounds__(64) void k_msm_fixed(const uint8_t* __restrict__ scalars, uint32_t splits,
+template <bool BE_BYTES, int OCC>
+__global__ __launch_bounds__(64, OCC) void k_msm_fixed(const uint8_t* __restrict__ scalars, uint32_t splits,
                                                   const uint4* __restrict__ table, MsmGeom g,
                                                   g1_xyzz* __restrict__ partials, int32_t* __restrict__ status) {
-  __shared__ g1_xyzz lds[32];
   const int lane = threadIdx.x;
   const uint64_t unit = blockIdx.x;
   const uint64_t blob = unit / splits;
@@ -174,33 +173,47 @@ __global__ __launch_bounds__(64) void k_msm_fixed(const uint8_t* __restrict__ sc
     }
   }
 
-  wave_reduce_xyzz(acc, lds, lane);
-  if (lane == 0) partials[unit] = acc;
+  // lane sums go to HBM (12 KB per wave); the cross-lane tree and the encoding run in
+  // k_msm_finalize so that this kernel has no calls and no LDS
+  partials[unit * 64 + lane] = acc;
   if (BE_BYTES) {
     if (__any(bad) && lane == 0) atomicOr(&status[blob], KZG_ERR_BLOB_INVALID_FIELD_ELEMENT);
   }
 }
 
-// Sum the `splits` partials of each item, convert to affine and emit the
-// 48-byte compressed encoding (K3: blst_p1_compress, src/bls.rs:499).
-// Items whose status is non-zero get 48 zero bytes.
-__global__ __launch_bounds__(64) void k_msm_finalize(const g1_xyzz* __restrict__ partials, uint32_t splits, uint64_t n,
-                                                     const int32_t* __restrict__ status, uint8_t* __restrict__ out48) {
-  const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// One wave per item: sums the 64 * splits lane partials of k_msm_fixed (6-level tree
+// through LDS) into one XYZZ point per item.
+__global__ __launch_bounds__(64) void k_msm_reduce(const g1_xyzz* __restrict__ partials, uint32_t splits, uint64_t n,
+                                                   g1_xyzz* __restrict__ sums) {
+  __shared__ g1_xyzz lds[32];
+  const int lane = threadIdx.x;
+  const uint64_t b = blockIdx.x;
   if (b >= n) return;
-  uint8_t* o = out48 + b * 48;
-  if (status != nullptr && status[b] != 0) {
-    for (int q = 0; q < 48; q++) o[q] = 0;
-    return;
-  }
-  g1_xyzz acc = partials[b * splits];
+  g1_xyzz acc = partials[(b * splits) * 64 + lane];
   for (uint32_t s = 1; s < splits; s++) {
-    g1_xyzz t = partials[b * splits + s];
+    g1_xyzz t = partials[(b * splits + s) * 64 + lane];
     xyzz_add(acc, t);
   }
+  wave_reduce_xyzz(acc, lds, lane);
+  if (lane == 0) sums[b] = acc;
+}
+
+// One thread per item: XYZZ -> affine -> 48-byte compressed encoding
+// (K3: blst_p1_compress, src/bls.rs:499).  Items whose status is non-zero get 48 zero bytes.
+__global__ __launch_bounds__(64) void k_g1_compress(const g1_xyzz* __restrict__ sums, uint64_t n, const int32_t* __restrict__ status,
+                                                    uint8_t* __restrict__ out48) {
+  const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n) return;
+  uint32_t* o = reinterpret_cast<uint32_t*>(out48 + b * 48);
   uint8_t tmp[48];
-  g1_compress_xyzz(tmp, acc);
-  for (int q = 0; q < 48; q++) o[q] = tmp[q];
+  if (status != nullptr && status[b] != 0) {
+    for (int q = 0; q < 48; q++) tmp[q] = 0;
+  } else {
+    g1_xyzz acc = sums[b];
+    g1_compress_xyzz(tmp, acc);
+  }
+  for (int q = 0; q < 12; q++)
+    o[q] = (uint32_t)tmp[4 * q] | ((uint32_t)tmp[4 * q + 1] << 8) | ((uint32_t)tmp[4 * q + 2] << 16) | ((uint32_t)tmp[4 * q + 3] << 24);
 }
 
 #endif  // __HIPCC__

@@ -178,3 +178,95 @@ def test_window_sizes_agree(golden):
             assert out[48:].hex() == golden["blobs"][1]["commitment"]
         finally:
             s.close()
+
+
+# ---------------------------------------------------------------------------
+# compute_blob_kzg_proof / compute_kzg_proof
+# ---------------------------------------------------------------------------
+def test_blob_proof_matches_golden(engine, golden):
+    recs = golden["blobs"]
+    blobs = b"".join(synth_blob(r["index"]) for r in recs)
+    commitments = b"".join(bytes.fromhex(r["commitment"]) for r in recs)
+    out, status = engine.compute_blob_proof_batch(blobs, commitments)
+    assert status == [0] * len(recs)
+    for k, r in enumerate(recs):
+        assert out[48 * k:48 * k + 48].hex() == r["proof"], k
+    # single-item API shape (Setup::blob_proof)
+    assert engine.blob_proof(blobs[:131072], commitments[:48]).hex() == recs[0]["proof"]
+
+
+def test_kzg_proof_at_point_matches_golden(engine, golden):
+    recs = golden["blobs"]
+    blobs = b"".join(synth_blob(r["index"]) for r in recs)
+    zs = b"".join(bytes.fromhex(r["kzg_proof_at"]["z"]) for r in recs)
+    proofs, ys, status = engine.compute_proof_batch(blobs, zs)
+    assert status == [0] * len(recs)
+    for k, r in enumerate(recs):
+        assert proofs[48 * k:48 * k + 48].hex() == r["kzg_proof_at"]["proof"], k
+        assert ys[32 * k:32 * k + 32].hex() == r["kzg_proof_at"]["y"], k
+    # in-domain evaluation point (src/kzg/poly.rs:14-18 and :50-64)
+    dom = recs[0]["kzg_proof_in_domain"]
+    proof, y = engine.proof(blobs[:131072], bytes.fromhex(dom["z"]))
+    assert y.hex() == dom["y"] and proof.hex() == dom["proof"]
+
+
+def test_proof_known_answers(engine):
+    """constant blob -> y = c, proof = infinity; p(x) = x -> y = z."""
+    from oracle.pyref import domain
+
+    c = 0x55AA
+    z = be32(0x1234567890ABCDEF)
+    proof, y = engine.proof(be32(c) * 4096, z)
+    assert y == be32(c) and proof == INF48
+    roots = domain.bit_reversal_permutation(domain.roots_of_unity(4096))
+    blob = b"".join(be32(w) for w in roots)
+    proof, y = engine.proof(blob, z)
+    assert y == z
+    # zero blob with the infinity commitment is a valid (blob, commitment) pair
+    assert engine.blob_proof(bytes(131072), INF48) == INF48
+
+
+def test_proof_rejections(engine, golden):
+    import kateth_amd
+
+    good_blob = synth_blob(0)
+    good_c = bytes.fromhex(golden["blobs"][0]["commitment"])
+    bad_blob = bytearray(good_blob)
+    bad_blob[64:96] = be32(R)
+    with pytest.raises(kateth_amd.KzgError) as e:
+        engine.blob_proof(bytes(bad_blob), good_c)
+    assert isinstance(e.value.inner, kateth_amd.BlobError) and e.value.inner.kind == "InvalidFieldElement"
+    cases = {
+        bytes([good_c[0] & 0x7F]) + good_c[1:]: "InvalidEncoding",
+        bytes([0x9A]) + bytes([0xFF] * 47): "InvalidEncoding",
+        bytes([0xE0]) + bytes(47): "InvalidEncoding",
+    }
+    from oracle.pyref import bls
+
+    x = 1
+    while bls._fp_sqrt(x**3 + 4) is not None:
+        x += 1
+    cases[bytes([0x80]) + x.to_bytes(48, "big")[1:]] = "NotOnCurve"
+    x = 1
+    while True:
+        y = bls._fp_sqrt(x**3 + 4)
+        if y is not None and not bls.g1_in_subgroup((x, y)):
+            break
+        x += 1
+    cases[bls.g1_compress((x, y))] = "NotInGroup"
+    for c48, kind in cases.items():
+        with pytest.raises(kateth_amd.KzgError) as e:
+            engine.blob_proof(good_blob, c48)
+        assert e.value.inner.inner.kind == kind, kind
+    # blob error wins over commitment error (src/kzg/setup.rs:177-181 order)
+    with pytest.raises(kateth_amd.KzgError) as e:
+        engine.blob_proof(bytes(bad_blob), bytes([0xE0]) + bytes(47))
+    assert isinstance(e.value.inner, kateth_amd.BlobError)
+    # z out of range for Setup::proof
+    with pytest.raises(kateth_amd.KzgError) as e:
+        engine.proof(good_blob, be32(R))
+    assert e.value.inner.inner.kind == "NotInFiniteField"
+    # per-item isolation in a batch
+    out, status = engine.compute_blob_proof_batch(good_blob + bytes(bad_blob) + good_blob, good_c * 3)
+    assert status == [0, 2, 0] and out[:48] == out[96:] and out[48:96] == bytes(48)
+    assert out[:48].hex() == golden["blobs"][0]["proof"]
