@@ -130,20 +130,29 @@ int32_t kzg_verify_blob_proof(const kzg_ctx* ctx, const uint8_t* blob, const uin
 int32_t kzg_verify_proof(const kzg_ctx* ctx, const uint8_t* proof48, const uint8_t* commitment48, const uint8_t* z32, const uint8_t* y32, int32_t* ok);
 
 /*
- * Multi-GPU batch verification: each rank reduces its
- * shard to two G1 partial sums; rank 0 adds the partials of all ranks and runs
- * the single pairing check.
- *   partial_dev : checks this rank's n_local items whose global indices start
- *                 at first_index within a batch of n_total; writes 2 * 96 bytes
- *                 (affine, big-endian x||y, all-zero = infinity) to out192 and
- *                 the first local error (code, local index) to err2.
- *   finish      : given world * 192 bytes of partials, returns *ok.
- * `batch_seed32` is the shared 32-byte transcript digest that seeds the random
- * linear combination; see DESIGN.md (batch challenge).
+ * Multi-GPU batch verification.  Blobs are sharded by
+ * contiguous global index ranges; each rank runs
+ *   phase 1 : per-item work on its n_local items (validation, challenge z_i,
+ *             evaluation y_i) and a 32-byte transcript root over them;
+ *             err6 = {blob_idx, blob_code, commitment_idx, commitment_code,
+ *             proof_idx, proof_code} with LOCAL index of the first rejected
+ *             input of each kind (-1 = none), so the caller can rebuild the
+ *             reference's first-error-wins order (src/kzg/setup.rs:259-271)
+ *             across ranks;
+ *   (the caller gathers the `world` roots -- RCCL all-gather of 32 B per rank)
+ *   phase 2 : the rank's share of the two random linear combinations, with the
+ *             challenge seeded by ALL roots; 2 x 96 bytes (affine big-endian
+ *             x||y, all-zero = infinity);
+ *   finish  : on one rank, sums the gathered partials (192 B per rank) and runs
+ *             the single two-pairing check.
+ * A session owns its device buffers and may not be used concurrently.
  */
-int32_t kzg_verify_blob_proof_batch_partial_dev(const kzg_ctx* ctx, const void* d_blobs, const void* d_commitments48, const void* d_proofs48,
-                                                uint64_t n_local, uint64_t first_index, uint64_t n_total, const uint8_t* batch_seed32,
-                                                uint8_t* out192, int32_t* err2, void* hip_stream);
+typedef struct kzg_verify_session kzg_verify_session;
+int32_t kzg_verify_phase1_dev(const kzg_ctx* ctx, const void* d_blobs, const void* d_commitments48, const void* d_proofs48, uint64_t n_local,
+                              uint8_t* out_root32, int32_t* err6, kzg_verify_session** session, void* hip_stream);
+int32_t kzg_verify_phase2_dev(kzg_verify_session* session, const uint8_t* roots32, uint64_t world, uint64_t first_index, uint64_t n_total,
+                              uint8_t* out192);
+void kzg_verify_session_destroy(kzg_verify_session* session);
 int32_t kzg_verify_batch_finish(const kzg_ctx* ctx, const uint8_t* partials192, uint64_t world, int32_t* ok);
 
 /*

@@ -18,7 +18,9 @@
 #include "../../include/kateth_amd.h"
 #include "blob_kernels.cuh"
 #include "msm_fixed.cuh"
+#include "pairing.hpp"
 #include "setup_kernels.cuh"
+#include "verify_kernels.cuh"
 
 using namespace kzg;
 
@@ -48,6 +50,9 @@ struct kzg_ctx {
   uint4* d_table = nullptr;      // fixed-base table, table_entries(geom) * 96 B
   uint4* d_bases_brp = nullptr;  // 4096 affine Lagrange points, BRP order
   fr_t* d_roots_brp = nullptr;   // 4096 roots of unity, Montgomery, BRP order
+  fr_t* d_roots_r2 = nullptr;    // the same roots times R^2 (see k_eval_frac)
+  uint4* d_gen_affine = nullptr; // G1 generator, affine Montgomery (96 B)
+  host::pairing_ctx* pairing = nullptr;  // host: Frobenius constants + Miller lines of G2 and [tau]_2
   uint64_t table_bytes = 0;
   uint32_t num_cus = 256;
   int msm_occupancy = 2;  // waves per SIMD the MSM kernel is compiled for (KATETH_AMD_MSM_OCC=3: experiment)
@@ -154,6 +159,9 @@ extern "C" void kzg_ctx_destroy(kzg_ctx* ctx) {
   if (ctx->d_table) (void)hipFree(ctx->d_table);
   if (ctx->d_bases_brp) (void)hipFree(ctx->d_bases_brp);
   if (ctx->d_roots_brp) (void)hipFree(ctx->d_roots_brp);
+  if (ctx->d_roots_r2) (void)hipFree(ctx->d_roots_r2);
+  if (ctx->d_gen_affine) (void)hipFree(ctx->d_gen_affine);
+  delete ctx->pairing;
   if (ctx->ws) (void)hipFree(ctx->ws);
   for (auto& pr : ctx->prof_events) {
     (void)hipEventDestroy(pr.first);
@@ -162,10 +170,53 @@ extern "C" void kzg_ctx_destroy(kzg_ctx* ctx) {
   delete ctx;
 }
 
+__global__ __launch_bounds__(64) void k_setup_roots_r2(const fr_t* __restrict__ roots, fr_t* __restrict__ out) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 4096) return;
+  fr_t r;
+  to_mont<FrParams>(r, roots[t]);
+  out[t] = r;
+}
+
 static int32_t ctx_build(kzg_ctx* ctx, const uint8_t* g1_lagrange, const uint8_t* g2_monomial) {
-  (void)g2_monomial;
   const MsmGeom g = ctx->geom;
   hipStream_t st = nullptr;
+  // ---- G2 monomial points (host): P2::decompress of all 65 (src/kzg/setup.rs:67-72) ----
+  {
+    host::g2_affine tau{};
+    for (int i = 0; i < KZG_SETUP_G2_POINTS; i++) {
+      host::g2_affine q;
+      int32_t stq = host::g2_decompress(q, g2_monomial + 96 * i);
+      if (stq != 0) return fail(KZG_FAIL_SETUP_G2, "g2_monomial[" + std::to_string(i) + "] rejected, code " + std::to_string(stq));
+      if (i == 1) tau = q;
+    }
+    ctx->pairing = new host::pairing_ctx();
+    ctx->pairing->fc = host::make_frob_consts();
+    host::g2_affine gen;
+    {
+      const uint32_t x0[12] = KZG_FP_G2X0_MONT, x1[12] = KZG_FP_G2X1_MONT, y0[12] = KZG_FP_G2Y0_MONT, y1[12] = KZG_FP_G2Y1_MONT;
+      for (int q = 0; q < 12; q++) {
+        gen.x.c0.v[q] = x0[q];
+        gen.x.c1.v[q] = x1[q];
+        gen.y.c0.v[q] = y0[q];
+        gen.y.c1.v[q] = y1[q];
+      }
+      gen.inf = false;
+    }
+    ctx->pairing->lines_g2 = host::precompute_lines(gen);
+    ctx->pairing->lines_tau = host::precompute_lines(tau);
+  }
+  // ---- G1 generator (BLS12_381_G1, src/bls.rs:391) ----
+  {
+    const uint32_t gx[12] = KZG_FP_G1X_MONT, gy[12] = KZG_FP_G1Y_MONT;
+    uint32_t h[24];
+    for (int q = 0; q < 12; q++) {
+      h[q] = gx[q];
+      h[12 + q] = gy[q];
+    }
+    HIP_TRY(hipMalloc(&ctx->d_gen_affine, 96));
+    HIP_TRY(hipMemcpy(ctx->d_gen_affine, h, 96, hipMemcpyHostToDevice));
+  }
   // ---- G1 Lagrange points: decompress, subgroup check, BRP -----------------
   uint8_t* d_in = nullptr;
   int32_t* d_status = nullptr;
@@ -186,6 +237,8 @@ static int32_t ctx_build(kzg_ctx* ctx, const uint8_t* g1_lagrange, const uint8_t
   // ---- roots of unity -------------------------------------------------------
   HIP_TRY(hipMalloc(&ctx->d_roots_brp, 4096 * sizeof(fr_t)));
   hipLaunchKernelGGL(k_setup_roots, dim3(64), dim3(64), 0, st, ctx->d_roots_brp);
+  HIP_TRY(hipMalloc(&ctx->d_roots_r2, 4096 * sizeof(fr_t)));
+  hipLaunchKernelGGL(k_setup_roots_r2, dim3(64), dim3(64), 0, st, ctx->d_roots_brp, ctx->d_roots_r2);
   HIP_TRY(hipGetLastError());
   // ---- fixed-base table -----------------------------------------------------
   const uint64_t entries = table_entries(g);

@@ -122,10 +122,12 @@ _SIGNATURES = {
     "kzg_verify_blob_proof_batch_dev": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, _i32p, ctypes.c_void_p]),
     "kzg_verify_blob_proof": (ctypes.c_int32, [ctypes.c_void_p, _u8p, _u8p, _u8p, _i32p]),
     "kzg_verify_proof": (ctypes.c_int32, [ctypes.c_void_p, _u8p, _u8p, _u8p, _u8p, _i32p]),
-    "kzg_verify_blob_proof_batch_partial_dev": (
+    "kzg_verify_phase1_dev": (
         ctypes.c_int32,
-        [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, _u8p, _u8p, _i32p, ctypes.c_void_p],
+        [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, _u8p, _i32p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p],
     ),
+    "kzg_verify_phase2_dev": (ctypes.c_int32, [ctypes.c_void_p, _u8p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, _u8p]),
+    "kzg_verify_session_destroy": (None, [ctypes.c_void_p]),
     "kzg_verify_batch_finish": (ctypes.c_int32, [ctypes.c_void_p, _u8p, ctypes.c_uint64, _i32p]),
     "kzg_synth_blobs_dev": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p]),
     "kzg_profile_begin": (ctypes.c_int32, [ctypes.c_void_p]),
@@ -406,14 +408,23 @@ class Setup:
             raise _kzg_error(rc)
         return bool(ok.value)
 
-    def verify_partial_dev(self, d_blobs: int, d_commitments: int, d_proofs: int, n_local: int, first_index: int, n_total: int, seed32: bytes, stream: int = 0):
+    def verify_phase1_dev(self, d_blobs: int, d_commitments: int, d_proofs: int, n_local: int, stream: int = 0):
+        """-> (session handle, 32-byte transcript root, err6)."""
+        root = ctypes.create_string_buffer(32)
+        err = (ctypes.c_int32 * 6)()
+        sess = ctypes.c_void_p()
+        rc = self._lib.kzg_verify_phase1_dev(self._h, d_blobs, d_commitments, d_proofs, n_local, ctypes.cast(root, ctypes.c_void_p), err, ctypes.byref(sess), stream)
+        self._check(rc, "kzg_verify_phase1_dev")
+        return sess, root.raw, list(err)
+
+    def verify_phase2_dev(self, session, roots: bytes, first_index: int, n_total: int) -> bytes:
         out = ctypes.create_string_buffer(192)
-        err = (ctypes.c_int32 * 2)()
-        rc = self._lib.kzg_verify_blob_proof_batch_partial_dev(
-            self._h, d_blobs, d_commitments, d_proofs, n_local, first_index, n_total, _buf(seed32), ctypes.cast(out, ctypes.c_void_p), err, stream
-        )
-        self._check(rc, "kzg_verify_blob_proof_batch_partial_dev")
-        return out.raw, (err[0], err[1])
+        rc = self._lib.kzg_verify_phase2_dev(session, _buf(roots), len(roots) // 32, first_index, n_total, ctypes.cast(out, ctypes.c_void_p))
+        self._check(rc, "kzg_verify_phase2_dev")
+        return out.raw
+
+    def verify_session_destroy(self, session):
+        self._lib.kzg_verify_session_destroy(session)
 
     def verify_batch_finish(self, partials: bytes) -> bool:
         ok = ctypes.c_int32(0)

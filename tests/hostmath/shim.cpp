@@ -132,3 +132,72 @@ void hm_hash_to_fr(uint8_t* out32be, const uint8_t* msg, uint64_t len) {
   fr_to_be_bytes_plain(out32be, v);
 }
 }
+
+// ---- host pairing (kateth_amd/csrc/pairing.hpp) test hooks ---------------------------------
+#include "../../kateth_amd/csrc/pairing.hpp"
+using namespace kzg::host;
+
+static bool load_g1(g1_host_affine& p, const uint8_t* in48) {
+  fp_t x, y;
+  bool inf;
+  if (g1_uncompress(x, y, inf, in48) != 0) return false;
+  p.x = x;
+  p.y = y;
+  p.inf = inf;
+  return true;
+}
+
+extern "C" {
+// e(-a1, q1) * e(b1, q2) == 1 with arbitrary G2 points (lines computed on the fly)
+int32_t hm_pairing_check(const uint8_t* a48, const uint8_t* q1_96, const uint8_t* b48, const uint8_t* q2_96) {
+  g1_host_affine a, b;
+  g2_affine q1, q2;
+  if (!load_g1(a, a48) || !load_g1(b, b48)) return -1;
+  if (g2_decompress(q1, q1_96) != 0 || g2_decompress(q2, q2_96) != 0) return -2;
+  static frob_consts fc = make_frob_consts();
+  miller_lines l1 = precompute_lines(q1), l2 = precompute_lines(q2);
+  g1_host_affine na = a;
+  if (!na.inf) fp_neg(na.y, na.y);
+  g1_host_affine ps[2] = {na, b};
+  const miller_lines* ls[2] = {&l1, &l2};
+  fp12 f = multi_miller(ps, ls, 2);
+  return final_exp_is_one(f, fc) ? 1 : 0;
+}
+int32_t hm_g2_decompress_status(const uint8_t* in96) {
+  g2_affine q;
+  return g2_decompress(q, in96);
+}
+// compares the addition-chain final exponentiation with the definition f^((p^12-1)/r)
+// on the Miller-loop value of (a, q); returns 1 if both agree on "== 1", plus 2 if that value is one
+int32_t hm_final_exp_crosscheck(const uint8_t* a48, const uint8_t* q96, const uint8_t* exp_le, int exp_limbs) {
+  g1_host_affine a;
+  g2_affine q;
+  if (!load_g1(a, a48) || g2_decompress(q, q96) != 0) return -1;
+  static frob_consts fc = make_frob_consts();
+  miller_lines l = precompute_lines(q);
+  const miller_lines* ls[1] = {&l};
+  fp12 f = multi_miller(&a, ls, 1);
+  std::vector<uint32_t> e(exp_limbs);
+  for (int i = 0; i < exp_limbs; i++) e[i] = (uint32_t)exp_le[4 * i] | ((uint32_t)exp_le[4 * i + 1] << 8) | ((uint32_t)exp_le[4 * i + 2] << 16) | ((uint32_t)exp_le[4 * i + 3] << 24);
+  bool slow = f12_is_one(f12_pow_big(f, e));
+  bool fast = final_exp_is_one(f, fc);
+  return (slow == fast ? 1 : 0) | (fast ? 2 : 0);
+}
+// frobenius sanity: frob^12 == identity and frob(f) == f^p is checked through frob^6 == conj
+int32_t hm_frobenius_check(const uint8_t* a48, const uint8_t* q96) {
+  g1_host_affine a;
+  g2_affine q;
+  if (!load_g1(a, a48) || g2_decompress(q, q96) != 0) return -1;
+  static frob_consts fc = make_frob_consts();
+  miller_lines l = precompute_lines(q);
+  const miller_lines* ls[1] = {&l};
+  fp12 f = multi_miller(&a, ls, 1);
+  fp12 g = f;
+  for (int i = 0; i < 6; i++) g = f12_frobenius(g, fc);
+  if (!f12_eq(g, f12_conj(f))) return 0;
+  fp12 inv = f12_inv(f);
+  if (!f12_is_one(f12_mul(inv, f))) return 0;
+  if (!f12_eq(f12_sqr(f), f12_mul(f, f))) return 0;
+  return 1;
+}
+}

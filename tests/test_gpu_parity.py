@@ -270,3 +270,125 @@ def test_proof_rejections(engine, golden):
     out, status = engine.compute_blob_proof_batch(good_blob + bytes(bad_blob) + good_blob, good_c * 3)
     assert status == [0, 2, 0] and out[:48] == out[96:] and out[48:96] == bytes(48)
     assert out[:48].hex() == golden["blobs"][0]["proof"]
+
+
+# ---------------------------------------------------------------------------
+# verify_blob_kzg_proof_batch / verify_blob_kzg_proof / verify_kzg_proof
+# ---------------------------------------------------------------------------
+def _golden_triplets(golden, k):
+    recs = golden["blobs"][:k]
+    return ([synth_blob(r["index"]) for r in recs], [bytes.fromhex(r["commitment"]) for r in recs], [bytes.fromhex(r["proof"]) for r in recs])
+
+
+def test_verify_batch_true_and_false(engine, golden):
+    blobs, cs, ps = _golden_triplets(golden, 6)
+    assert engine.verify_blob_proof_batch(blobs, cs, ps) is True
+    for k in (1, 2, 3):
+        assert engine.verify_blob_proof_batch(blobs[:k], cs[:k], ps[:k]) is True
+    assert engine.verify_blob_proof_batch([], [], []) is True  # n == 0
+    # swapped proofs, swapped commitments, a modified blob element
+    assert engine.verify_blob_proof_batch(blobs, cs, [ps[1], ps[0]] + ps[2:]) is False
+    assert engine.verify_blob_proof_batch(blobs, [cs[1], cs[0]] + cs[2:], ps) is False
+    bad = bytearray(blobs[3])
+    bad[31] ^= 1
+    assert engine.verify_blob_proof_batch(blobs[:3] + [bytes(bad)] + blobs[4:], cs, ps) is False
+    # a valid-but-wrong proof point (the generator) in the last slot
+    assert engine.verify_blob_proof_batch(blobs, cs, ps[:5] + [GEN48]) is False
+    # single-item API
+    assert engine.verify_blob_proof(blobs[0], cs[0], ps[0]) is True
+    assert engine.verify_blob_proof(blobs[0], cs[0], ps[1]) is False
+    # zero blob / infinity commitment / infinity proof is a valid triple
+    assert engine.verify_blob_proof(bytes(131072), INF48, INF48) is True
+
+
+def test_verify_matches_oracle_decisions(engine, golden, oracle_setup):
+    blobs, cs, ps = _golden_triplets(golden, 2)
+    assert oracle_setup.verify_blob_proof_batch(blobs, cs, ps) is True
+    assert engine.verify_blob_proof_batch(blobs, cs, ps) is True
+    assert oracle_setup.verify_blob_proof_batch(blobs, cs, ps[::-1]) is False
+    assert engine.verify_blob_proof_batch(blobs, cs, ps[::-1]) is False
+
+
+def test_verify_errors_first_error_wins(engine, golden):
+    import kateth_amd
+
+    blobs, cs, ps = _golden_triplets(golden, 3)
+    bad_blob = bytearray(blobs[1])
+    bad_blob[0:32] = be32(R)
+    not_compressed = bytes([cs[0][0] & 0x7F]) + cs[0][1:]
+    with pytest.raises(kateth_amd.KzgError) as e:  # blob error beats everything (src/kzg/setup.rs:259-262)
+        engine.verify_blob_proof_batch([blobs[0], bytes(bad_blob), blobs[2]], [not_compressed] + cs[1:], ps)
+    assert isinstance(e.value.inner, kateth_amd.BlobError) and e.value.inner.kind == "InvalidFieldElement"
+    with pytest.raises(kateth_amd.KzgError) as e:  # commitment error beats proof error
+        engine.verify_blob_proof_batch(blobs, [cs[0], not_compressed, cs[2]], [bytes([0xE0]) + bytes(47)] + ps[1:])
+    assert e.value.inner.inner.kind == "InvalidEncoding"
+    from oracle.pyref import bls
+
+    x = 1
+    while True:
+        y = bls._fp_sqrt(x**3 + 4)
+        if y is not None and not bls.g1_in_subgroup((x, y)):
+            break
+        x += 1
+    with pytest.raises(kateth_amd.KzgError) as e:
+        engine.verify_blob_proof_batch(blobs, cs, ps[:2] + [bls.g1_compress((x, y))])
+    assert e.value.inner.inner.kind == "NotInGroup"
+    with pytest.raises(AssertionError):  # length mismatch panics in the reference (src/kzg/setup.rs:256-257)
+        engine.verify_blob_proof_batch(blobs, cs[:2], ps)
+    with pytest.raises(kateth_amd.KzgError) as e:
+        engine.verify_blob_proof_batch([blobs[0][:-1]], cs[:1], ps[:1])
+    assert e.value.inner.kind == "InvalidLen"
+
+
+def test_verify_kzg_proof_single(engine, golden):
+    import kateth_amd
+
+    rec = golden["blobs"][0]
+    c = bytes.fromhex(rec["commitment"])
+    at = rec["kzg_proof_at"]
+    z, y, pi = bytes.fromhex(at["z"]), bytes.fromhex(at["y"]), bytes.fromhex(at["proof"])
+    assert engine.verify_proof(pi, c, z, y) is True
+    wrong_y = be32((int.from_bytes(y, "big") + 1) % R)
+    assert engine.verify_proof(pi, c, z, wrong_y) is False
+    assert engine.verify_proof(pi, c, be32(5), y) is False
+    dom = rec["kzg_proof_in_domain"]
+    assert engine.verify_proof(bytes.fromhex(dom["proof"]), c, bytes.fromhex(dom["z"]), bytes.fromhex(dom["y"])) is True
+    # blob challenge point: (z, y, proof) of the blob proof also verifies as a plain KZG proof
+    assert engine.verify_proof(bytes.fromhex(rec["proof"]), c, bytes.fromhex(rec["challenge_z"]), bytes.fromhex(rec["eval_y"])) is True
+    with pytest.raises(kateth_amd.KzgError) as e:
+        engine.verify_proof(pi, c, be32(R), y)
+    assert e.value.inner.inner.kind == "NotInFiniteField"
+    with pytest.raises(kateth_amd.KzgError) as e:
+        engine.verify_proof(bytes([pi[0] & 0x7F]) + pi[1:], bytes([0xE0]) + bytes(47), be32(R), y)
+    assert e.value.inner.inner.kind == "InvalidEncoding"
+
+
+def test_verify_roundtrip_at_batch_size(engine, torch_cuda):
+    """size-independent closure at a larger batch, all on device: commit -> prove
+    -> verify is true; corrupting one proof in the middle makes it false."""
+    torch = torch_cuda
+    n = 1024
+    d_blobs = torch.empty(n * 131072, dtype=torch.uint8, device="cuda")
+    d_c = torch.empty(n * 48, dtype=torch.uint8, device="cuda")
+    d_p = torch.empty(n * 48, dtype=torch.uint8, device="cuda")
+    d_status = torch.empty(n, dtype=torch.int32, device="cuda")
+    engine.synth_blobs_dev(0xC0DE, 0, n, d_blobs.data_ptr())
+    engine.blob_to_commitment_batch_dev(d_blobs.data_ptr(), n, d_c.data_ptr(), d_status.data_ptr())
+    engine.compute_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), n, d_p.data_ptr(), d_status.data_ptr())
+    torch.cuda.synchronize()
+    assert int(d_status.abs().sum()) == 0
+    assert engine.verify_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n) is True
+    # two-shard path (what two ranks would do) gives the same answer
+    half = n // 2
+    s0, r0, e0 = engine.verify_phase1_dev(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), half)
+    s1, r1, e1 = engine.verify_phase1_dev(d_blobs.data_ptr() + half * 131072, d_c.data_ptr() + half * 48, d_p.data_ptr() + half * 48, n - half)
+    assert e0[0] == e0[2] == e0[4] == -1 and e1[0] == e1[2] == e1[4] == -1
+    p0 = engine.verify_phase2_dev(s0, r0 + r1, 0, n)
+    p1 = engine.verify_phase2_dev(s1, r0 + r1, half, n)
+    engine.verify_session_destroy(s0)
+    engine.verify_session_destroy(s1)
+    assert engine.verify_batch_finish(p0 + p1) is True
+    # corrupt: copy proof 0 over proof 500
+    d_p[500 * 48:501 * 48] = d_p[0:48]
+    torch.cuda.synchronize()
+    assert engine.verify_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n) is False

@@ -134,3 +134,64 @@ def test_g1_decompress_status_codes(hm):
     for pt in (q, bls.g1_neg(q)):
         st, out = _sum(hm, [bls.g1_compress(pt)])
         assert st == 0 and out == bls.g1_compress(pt)
+
+
+# ---- host pairing (kateth_amd/csrc/pairing.hpp), the once-per-call check of verify ----------
+def test_host_pairing_against_oracle(hm, oracle_setup):
+    g1, g2 = bls.G1_GEN, bls.G2_GEN
+    a, b = 0x1234567, 0x89ABCDEF01
+    c = lambda p: bls.g1_compress(p)
+    c2 = lambda q: bls.g2_compress(q)
+    # e(-(ab)G, H) * e(aG, bH) == 1
+    assert hm.hm_pairing_check(c(bls.g1_mul(g1, a * b)), c2(g2), c(bls.g1_mul(g1, a)), c2(bls.g2_mul(g2, b))) == 1
+    assert hm.hm_pairing_check(c(bls.g1_mul(g1, a * b + 1)), c2(g2), c(bls.g1_mul(g1, a)), c2(bls.g2_mul(g2, b))) == 0
+    # infinity operands (reference Q4: two infinities verify as true)
+    assert hm.hm_pairing_check(c(None), c2(g2), c(None), c2(bls.g2_mul(g2, b))) == 1
+    assert hm.hm_pairing_check(c(None), c2(g2), c(g1), c2(g2)) == 0
+    # ceremony consistency: e([tau]_1, G2) == e(G1, [tau]_2)
+    from oracle.pyref import blob as oblob
+
+    tau1 = oblob.commitment(oracle_setup.roots_of_unity_brp, oracle_setup)
+    tau2 = c2(oracle_setup.g2_monomial[1])
+    assert hm.hm_pairing_check(c(tau1), c2(g2), c(g1), tau2) == 1
+    assert hm.hm_pairing_check(c(tau1), c2(g2), c(g1), c2(oracle_setup.g2_monomial[2])) == 0
+    # same decisions as the oracle's pairing on a few mixed cases
+    rnd = random.Random(4)
+    for _ in range(3):
+        x, y = rnd.randrange(R), rnd.randrange(R)
+        good = rnd.random() < 0.5
+        lhs = bls.g1_mul(g1, x * y % R if good else (x * y + 5) % R)
+        got = hm.hm_pairing_check(c(lhs), c2(g2), c(bls.g1_mul(g1, x)), c2(bls.g2_mul(g2, y)))
+        want = bls.verify_pairings((lhs, g2), (bls.g1_mul(g1, x), bls.g2_mul(g2, y)))
+        assert got == int(want) == int(good)
+
+
+def test_host_final_exp_chain_matches_definition(hm):
+    e = (P**12 - 1) // R
+    nl = (e.bit_length() + 31) // 32
+    eb = e.to_bytes(4 * nl, "little")
+    res = hm.hm_final_exp_crosscheck(bls.g1_compress(bls.g1_mul(bls.G1_GEN, 77)), bls.g2_compress(bls.g2_mul(bls.G2_GEN, 99)), eb, nl)
+    assert res == 1  # agree, and a non-degenerate pairing value is not one
+    res = hm.hm_final_exp_crosscheck(bls.g1_compress(None), bls.g2_compress(bls.G2_GEN), eb, nl)
+    assert res == 3  # agree, value is one
+    assert hm.hm_frobenius_check(bls.g1_compress(bls.g1_mul(bls.G1_GEN, 5)), bls.g2_compress(bls.g2_mul(bls.G2_GEN, 7))) == 1
+
+
+def test_host_g2_decompress(hm, oracle_setup):
+    raw = __import__("json").load(open(__import__("conftest").TRUSTED_SETUP))
+    for s in raw["g2_monomial"][:4] + raw["g2_monomial"][-2:]:
+        assert hm.hm_g2_decompress_status(bytes.fromhex(s[2:])) == 0
+    good = bytes.fromhex(raw["g2_monomial"][1][2:])
+    assert hm.hm_g2_decompress_status(bytes([good[0] & 0x7F]) + good[1:]) == 3
+    assert hm.hm_g2_decompress_status(bytes([0xC0]) + bytes(95)) == 0
+    assert hm.hm_g2_decompress_status(bytes([0xE0]) + bytes(95)) == 3
+    # flipped sign bit still decodes (the other root): status 0
+    assert hm.hm_g2_decompress_status(bytes([good[0] ^ 0x20]) + good[1:]) == 0
+    # an on-curve point outside G2
+    x = (1, 0)
+    while True:
+        y = bls.f2_sqrt(bls.f2_add(bls.f2_mul(bls.f2_sqr(x), x), bls.B2))
+        if y is not None and not bls.g2_in_subgroup((x, y)):
+            break
+        x = (x[0] + 1, 0)
+    assert hm.hm_g2_decompress_status(bls.g2_compress((x, y))) == 5
