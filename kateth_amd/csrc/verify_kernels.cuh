@@ -357,21 +357,36 @@ __global__ __launch_bounds__(256) void k_var_scatter(const fr_t* __restrict__ sc
   });
 }
 
+// thread = (bucket, k of K): entries lo+k, lo+k+K, ... of the bucket's sorted list
 __global__ __launch_bounds__(64, 2) void k_var_buckets(const uint4* __restrict__ points, const uint32_t* __restrict__ offsets,
-                                                       const uint32_t* __restrict__ entries, uint32_t nbuckets,
-                                                       g1_xyzz* __restrict__ bucket_sums) {
-  const uint32_t bkt = blockIdx.x * blockDim.x + threadIdx.x;
-  if (bkt >= nbuckets) return;
+                                                       const uint32_t* __restrict__ entries, uint32_t nbuckets, uint32_t K,
+                                                       g1_xyzz* __restrict__ partial_sums) {
+  const uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= (uint64_t)nbuckets * K) return;
+  const uint32_t bkt = (uint32_t)(id / K), k0 = (uint32_t)(id % K);
   const uint32_t lo = offsets[bkt], hi = offsets[bkt + 1];
   g1_xyzz acc;
   xyzz_set_inf(acc);
 #pragma unroll 1
-  for (uint32_t k = lo; k < hi; k++) {
+  for (uint32_t k = lo + k0; k < hi; k += K) {
     const uint32_t e = entries[k];
     fp_t x, y;
     load_affine96(x, y, points, e >> 1);
     if (e & 1u) fp_neg(y, y);
     xyzz_madd(acc, x, y);
+  }
+  partial_sums[id] = acc;
+}
+
+// thread per bucket: sum of its K partials
+__global__ __launch_bounds__(64) void k_var_fold(const g1_xyzz* __restrict__ partial_sums, uint32_t nbuckets, uint32_t K,
+                                                 g1_xyzz* __restrict__ bucket_sums) {
+  const uint32_t bkt = blockIdx.x * blockDim.x + threadIdx.x;
+  if (bkt >= nbuckets) return;
+  g1_xyzz acc = partial_sums[(uint64_t)bkt * K];
+  for (uint32_t k = 1; k < K; k++) {
+    g1_xyzz t = partial_sums[(uint64_t)bkt * K + k];
+    xyzz_add(acc, t);
   }
   bucket_sums[bkt] = acc;
 }
