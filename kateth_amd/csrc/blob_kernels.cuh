@@ -66,12 +66,16 @@ __global__ __launch_bounds__(256) void k_synth_blobs(uint64_t seed, uint64_t fir
 // status[i] = 0 / KZG_ERR_EC_*.  If `affine` != null the decoded point is stored
 // (Montgomery x,y; infinity -> all-zero entry and inf[i] = 1).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_g1_decompress(const uint8_t* __restrict__ in48, uint64_t n, int32_t* __restrict__ status,
+__global__ __launch_bounds__(64) void k_g1_decompress(const uint8_t* __restrict__ in_a, uint64_t n_a, int32_t* __restrict__ status_a,
+                                                      const uint8_t* __restrict__ in_b, uint64_t n_b, int32_t* __restrict__ status_b,
                                                       uint4* __restrict__ affine, uint8_t* __restrict__ inf) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  // two input arrays in one launch (proofs then commitments): thread t decodes a[t] or b[t - n_a]
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_a + n_b) return;
+  const bool second = t >= n_a;
+  const uint64_t i = second ? t - n_a : t;
   uint8_t buf[48];
-  const uint32_t* src = reinterpret_cast<const uint32_t*>(in48 + i * 48);
+  const uint32_t* src = reinterpret_cast<const uint32_t*>((second ? in_b : in_a) + i * 48);
 #pragma unroll
   for (int q = 0; q < 12; q++) {
     uint32_t w = src[q];
@@ -83,14 +87,14 @@ __global__ __launch_bounds__(64) void k_g1_decompress(const uint8_t* __restrict_
   fp_t x, y;
   bool is_inf = false;
   int32_t st = g1_decompress(x, y, is_inf, buf);
-  status[i] = st;
+  (second ? status_b : status_a)[i] = st;
   if (affine != nullptr) {
     if (st != 0 || is_inf) {
       bn_zero(x);
       bn_zero(y);
     }
-    store_affine96_(affine, i, x, y);
-    inf[i] = (st == 0 && is_inf) ? 1 : 0;
+    store_affine96_(affine, t, x, y);
+    inf[t] = (st == 0 && is_inf) ? 1 : 0;
   }
 }
 

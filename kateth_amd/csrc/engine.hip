@@ -55,6 +55,7 @@ struct kzg_ctx {
   host::pairing_ctx* pairing = nullptr;  // host: Frobenius constants + Miller lines of G2 and [tau]_2
   uint64_t table_bytes = 0;
   uint32_t num_cus = 256;
+  hipStream_t side_stream = nullptr;  // non-blocking stream for work that overlaps the caller's stream
   int msm_occupancy = 2;  // waves per SIMD the MSM kernel is compiled for (KATETH_AMD_MSM_OCC=3: experiment)
   // workspace (grown on demand, guarded by lock)
   mutable std::mutex lock;
@@ -163,6 +164,7 @@ extern "C" void kzg_ctx_destroy(kzg_ctx* ctx) {
   if (ctx->d_gen_affine) (void)hipFree(ctx->d_gen_affine);
   delete ctx->pairing;
   if (ctx->ws) (void)hipFree(ctx->ws);
+  if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
   for (auto& pr : ctx->prof_events) {
     (void)hipEventDestroy(pr.first);
     (void)hipEventDestroy(pr.second);
@@ -281,6 +283,10 @@ extern "C" int32_t kzg_ctx_create(const uint8_t* g1_lagrange, const uint8_t* g2_
   if (!ctx) return fail(KZG_FAIL_ARGUMENT, "out of host memory");
   ctx->device = device;
   ctx->geom = make_geom(c);
+  if (hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess) {
+    delete ctx;
+    return fail(KZG_FAIL_HIP, "hipStreamCreate failed");
+  }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cus = (uint32_t)prop.multiProcessorCount;
   memcpy(ctx->g2_tau, g2_monomial + 96, 96);

@@ -251,9 +251,9 @@ KZG_HD_NOINLINE int32_t g1_uncompress(fp_t& x, fp_t& y, bool& inf, const uint8_t
   return KZG_OK;
 }
 
-// prime-order subgroup test by the definition [r]P == O
-// (blst_p1_affine_in_g1, src/bls.rs:522).  Infinity is in the group.
-KZG_HD_NOINLINE bool g1_in_subgroup(const fp_t& x, const fp_t& y, bool inf) {
+// prime-order subgroup test by the definition [r]P == O (kept as the cross-check of the
+// fast test below; tests/test_hostmath.py compares the two).  Infinity is in the group.
+KZG_HD_NOINLINE bool g1_in_subgroup_naive(const fp_t& x, const fp_t& y, bool inf) {
   if (inf) return true;
   const uint32_t rr[8] = KZG_FR_MOD_PLAIN;
   g1_xyzz acc;
@@ -263,6 +263,43 @@ KZG_HD_NOINLINE bool g1_in_subgroup(const fp_t& x, const fp_t& y, bool inf) {
     if ((rr[i >> 5] >> (i & 31)) & 1u) xyzz_madd(acc, x, y);
   }
   return xyzz_is_inf(acc);
+}
+
+// blst_p1_affine_in_g1 (src/bls.rs:522) via the GLV endomorphism (Scott, eprint 2021/1130):
+// phi(x, y) = (beta*x, y) satisfies phi^2 + phi + 1 = 0 on E and acts on G1 as
+// multiplication by lambda = -z^2 (lambda^2 + lambda + 1 = z^4 - z^2 + 1 = r).  If
+// phi(P) = [-z^2]P for a point P = Q + T (Q in G1, T of order dividing the cofactor),
+// then ord(T) divides z^4 - z^2 + 1 = r, and gcd(cofactor, r) = 1 forces T = O.
+// So  P in G1  <=>  (beta*x, y) == -[z^2]P : two multiplications by the 64-bit |z|
+// (126 doublings + 10 additions) instead of a 255-bit ladder.
+KZG_HD_NOINLINE void g1_mul_by_z(g1_xyzz& out, const g1_xyzz& base) {
+  const uint64_t zabs = 0xd201000000010000ull;
+  g1_xyzz acc = base;
+  for (int i = 62; i >= 0; i--) {
+    xyzz_dbl(acc);
+    if ((zabs >> i) & 1ull) xyzz_add(acc, base);
+  }
+  out = acc;
+}
+KZG_HD_NOINLINE bool g1_in_subgroup(const fp_t& x, const fp_t& y, bool inf) {
+  if (inf) return true;
+  g1_xyzz p, q1, q2;
+  xyzz_from_affine(p, x, y);
+  g1_mul_by_z(q1, p);
+  g1_mul_by_z(q2, q1);  // [z^2]P
+  if (xyzz_is_inf(q2)) return false;
+  fp_t beta, t;
+  {
+    const uint32_t bm[12] = KZG_FP_BETA_MONT;
+#pragma unroll
+    for (int i = 0; i < 12; i++) beta.v[i] = bm[i];
+  }
+  fp_mul(t, x, beta);
+  fp_mul(t, t, q2.zz);
+  if (!bn_eq(t, q2.x)) return false;  // x-coordinates: beta*x == X/ZZ
+  fp_mul(t, y, q2.zzz);
+  fp_neg(t, t);
+  return bn_eq(t, q2.y);  // y == -(Y/ZZZ)
 }
 
 // Decompress for P1 (src/bls.rs:505-531): uncompress + subgroup check

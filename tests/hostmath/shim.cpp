@@ -201,3 +201,10 @@ int32_t hm_frobenius_check(const uint8_t* a48, const uint8_t* q96) {
   return 1;
 }
 }
+
+extern "C" int32_t hm_g1_subgroup_both(const uint8_t* a48) {  // bit0 = fast test, bit1 = naive [r]P test
+  fp_t x, y;
+  bool inf;
+  if (g1_uncompress(x, y, inf, a48) != 0) return -1;
+  return (g1_in_subgroup(x, y, inf) ? 1 : 0) | (g1_in_subgroup_naive(x, y, inf) ? 2 : 0);
+}

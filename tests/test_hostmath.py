@@ -195,3 +195,26 @@ def test_host_g2_decompress(hm, oracle_setup):
             break
         x = (x[0] + 1, 0)
     assert hm.hm_g2_decompress_status(bls.g2_compress((x, y))) == 5
+
+
+def test_fast_subgroup_check_agrees_with_definition(hm):
+    """endomorphism-based membership test == the definition [r]P == O, on members and non-members"""
+    rnd = random.Random(12)
+    for k in (1, 2, R - 1, rnd.randrange(R), rnd.randrange(R)):
+        assert hm.hm_g1_subgroup_both(bls.g1_compress(bls.g1_mul(bls.G1_GEN, k))) == 3
+    assert hm.hm_g1_subgroup_both(bls.g1_compress(None)) == 3
+    found = 0
+    x = 1
+    while found < 6:
+        y = bls._fp_sqrt(x**3 + 4)
+        if y is not None:
+            member = bls.g1_in_subgroup((x, y))
+            got = hm.hm_g1_subgroup_both(bls.g1_compress((x, y)))
+            assert got == (3 if member else 0)
+            found += 0 if member else 1
+        x += 1
+    # a member plus a small-order cofactor point: multiply a non-member by r to land in the cofactor part
+    t = bls.g1_mul_unreduced((x - 1, bls._fp_sqrt((x - 1) ** 3 + 4)), R) if bls._fp_sqrt((x - 1) ** 3 + 4) else None
+    if t is not None:
+        mixed = bls.g1_add(bls.g1_mul(bls.G1_GEN, 12345), t)
+        assert hm.hm_g1_subgroup_both(bls.g1_compress(mixed)) == 0
