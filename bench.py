@@ -36,7 +36,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=4096, help="blobs per GPU per step (BASELINE configs[1]: 4096)")
-    ap.add_argument("--window-bits", type=int, default=int(os.environ.get("KATETH_AMD_WINDOW_BITS", "0")))
+    ap.add_argument("--window-bits", type=int, default=int(os.environ.get("KATETH_AMD_WINDOW_BITS", "16")),
+                    help="fixed-base window c (table: c=16 -> 192 GiB of the 288 GB HBM, 16 s to build; c=15 -> 102 GiB, 9 s; c=12 -> 16 GiB, 1 s); falls back to smaller windows if the table cannot be allocated")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL, the measured path) or gloo (rehearsal: gathers via host)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary proof/verify workloads")
     ap.add_argument("--cpu-sample", type=int, default=0, help="blobs in the CPU baseline sample (0 = auto, ~10-30 s)")
@@ -56,6 +58,21 @@ def cpu_baseline(sample_blobs, setup_path, gpu_out48):
     res.pop("outputs", None)
     res["matches_gpu_bytes"] = bool(raw == gpu_out48[: len(raw)])
     return res
+
+
+def pmc_traffic(n, window_bits):
+    """HBM bytes per k_msm_fixed launch from the committed rocprofv3 PMC passes
+    (profiles/r01/pmc_traffic.json; separate --pmc FETCH_SIZE / WRITE_SIZE runs of this
+    same command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).
+    bench.py cannot run the profiler on itself, so this is the profiled value for the
+    same (batch, window) configuration, or null when none has been recorded."""
+    path = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")
+    try:
+        rec = json.load(open(path))
+        key = "n%d_c%d" % (n, window_bits)
+        return rec[key]["hbm_bytes_per_launch"] if key in rec else None
+    except (OSError, ValueError, KeyError):
+        return None
 
 
 def extra_workloads(torch, setup, dev, stream, d_blobs, d_commitments, n):
@@ -112,16 +129,27 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
     assert torch.cuda.is_available(), "bench.py needs an MI355X; the engine has no CPU fallback"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    local_dev = local_rank % max(1, ndev)  # one GPU per rank on a real node; ranks share a card only in the gloo rehearsal
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
 
     import kateth_amd
 
     setup_path = os.path.join(ROOT, "tests", "golden", "trusted_setup_4096.json")
     t0 = time.time()
-    setup = kateth_amd.Setup.load_json(setup_path, device=local_rank, window_bits=args.window_bits)
+    setup = None
+    tried = []
+    for c in [args.window_bits] + [w for w in (15, 14, 12) if w < args.window_bits]:
+        try:  # the table is sized for 288 GB of HBM; step down if this device cannot hold it
+            setup = kateth_amd.Setup.load_json(setup_path, device=local_dev, window_bits=c)
+            break
+        except kateth_amd.kzg.EngineError as err:
+            tried.append("c=%d: %s" % (c, err))
+            torch.cuda.empty_cache()
+    assert setup is not None, "context creation failed for every window size: %r" % tried
     t_setup = time.time() - t0
 
     n = args.batch
@@ -135,7 +163,12 @@ def main():
     def step():
         setup.blob_to_commitment_batch_dev(d_blobs.data_ptr(), n, d_out.data_ptr(), d_status.data_ptr(), stream)
         if world > 1:
-            dist.all_gather_into_tensor(gathered, d_out)
+            if args.backend == "nccl":
+                dist.all_gather_into_tensor(gathered, d_out)  # RCCL over xGMI: 48 B per blob
+            else:  # gloo rehearsal path: stage through the host
+                host = [torch.empty(n * 48, dtype=torch.uint8) for _ in range(world)]
+                dist.all_gather(host, d_out.cpu())
+                gathered.copy_(torch.cat(host))
 
     def fence():
         if world > 1:
@@ -208,7 +241,7 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-            "traffic": None,
+            "traffic": pmc_traffic(n, setup.window_bits),
             "kernel_ms": k_ms,
             "launches": prof["msm_launches"],
             "algorithmic_bytes_per_blob": ALG_BYTES_COMMIT,

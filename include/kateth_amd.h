@@ -171,6 +171,14 @@ int32_t kzg_synth_blobs_dev(const kzg_ctx* ctx, uint64_t seed, uint64_t first_in
 int32_t kzg_microbench_fp_mul(const kzg_ctx* ctx, uint64_t lanes, uint64_t iters, float* ms);
 
 /*
+ * On-device self-test of the hand-scheduled multiply: every lane multiplies
+ * `iters` pseudo-random operand pairs with the inline-asm v_mad_u64_u32 chains
+ * and with a plain-C multiply the compiler schedules (hazard wait states and
+ * all); *mismatches counts disagreements (Fp and Fr).  Expected: 0.
+ */
+int32_t kzg_selftest_field_mul(const kzg_ctx* ctx, uint64_t lanes, uint64_t iters, uint64_t* mismatches);
+
+/*
  * Kernel timing for bench.py's `roofline` object: between begin and end every
  * launch of the dominant kernel (k_msm_fixed) is bracketed by HIP events on the
  * stream it is launched on.  end() synchronises those events and returns the

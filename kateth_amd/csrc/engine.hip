@@ -61,6 +61,7 @@ struct kzg_ctx {
   mutable std::mutex lock;
   mutable void* ws = nullptr;
   mutable size_t ws_bytes = 0;
+  mutable hipEvent_t ws_event = nullptr;  // recorded after the last enqueued user of `ws`; the next user's stream waits on it
   // profiling (kzg_profile_begin/end): event pairs around k_msm_fixed launches
   mutable bool profiling = false;
   mutable std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
@@ -80,6 +81,17 @@ static int32_t ws_reserve(const kzg_ctx* ctx, size_t bytes) {
   size_t want = bytes + bytes / 8;
   HIP_TRY(hipMalloc(&ctx->ws, want));
   ctx->ws_bytes = want;
+  return 0;
+}
+
+// `ws` is shared by successive calls that may be enqueued on different streams: order them.
+static int32_t ws_acquire(const kzg_ctx* ctx, hipStream_t st) {
+  if (ctx->ws_event) HIP_TRY(hipStreamWaitEvent(st, ctx->ws_event, 0));
+  return 0;
+}
+static int32_t ws_release(const kzg_ctx* ctx, hipStream_t st) {
+  if (!ctx->ws_event) HIP_TRY(hipEventCreateWithFlags(&ctx->ws_event, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(ctx->ws_event, st));
   return 0;
 }
 
@@ -165,6 +177,7 @@ extern "C" void kzg_ctx_destroy(kzg_ctx* ctx) {
   delete ctx->pairing;
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
+  if (ctx->ws_event) (void)hipEventDestroy(ctx->ws_event);
   for (auto& pr : ctx->prof_events) {
     (void)hipEventDestroy(pr.first);
     (void)hipEventDestroy(pr.second);
@@ -276,7 +289,7 @@ extern "C" int32_t kzg_ctx_create(const uint8_t* g1_lagrange, const uint8_t* g2_
     return fail(KZG_FAIL_NO_DEVICE, "no HIP device visible: the kateth_amd engine has no CPU fallback");
   int device = cfg ? cfg->device : 0;
   if (device < 0 || device >= ndev) return fail(KZG_FAIL_ARGUMENT, "device ordinal out of range");
-  uint32_t c = (cfg && cfg->window_bits) ? (uint32_t)cfg->window_bits : 12u;
+  uint32_t c = (cfg && cfg->window_bits) ? (uint32_t)cfg->window_bits : 14u;  // default: 54 GiB table, 77,824 adds per blob
   if (c < 4 || c > 16) return fail(KZG_FAIL_ARGUMENT, "window_bits must be in [4,16]");
   HIP_TRY(hipSetDevice(device));
   kzg_ctx* ctx = new (std::nothrow) kzg_ctx();
@@ -335,7 +348,11 @@ extern "C" int32_t kzg_blob_to_commitment_batch_dev(const kzg_ctx* ctx, const vo
   if (!ctx || (n && (!d_blobs || !d_out48 || !d_status))) return fail(KZG_FAIL_ARGUMENT, "null argument");
   HIP_TRY(hipSetDevice(ctx->device));
   std::lock_guard<std::mutex> guard(ctx->lock);
-  return commit_dev_locked(ctx, d_blobs, n, d_out48, reinterpret_cast<int32_t*>(d_status), reinterpret_cast<hipStream_t>(hip_stream));
+  hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+  int32_t rc = ws_acquire(ctx, st);
+  if (rc == 0) rc = commit_dev_locked(ctx, d_blobs, n, d_out48, reinterpret_cast<int32_t*>(d_status), st);
+  if (rc == 0) rc = ws_release(ctx, st);
+  return rc;
 }
 
 extern "C" int32_t kzg_blob_to_commitment_batch(const kzg_ctx* ctx, const uint8_t* blobs, uint64_t n, uint8_t* out48, int32_t* status) {
@@ -419,6 +436,59 @@ extern "C" int32_t kzg_microbench_fp_mul(const kzg_ctx* ctx, uint64_t lanes, uin
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   (void)hipFree(d_out);
+  return 0;
+}
+
+template <class F>
+__device__ __forceinline__ uint32_t selftest_one(uint64_t& rng) {
+  bn<F::N> a, b, r1, r2;
+#pragma unroll
+  for (int q = 0; q < F::N; q++) {
+    rng ^= rng << 13;
+    rng ^= rng >> 7;
+    rng ^= rng << 17;
+    a.v[q] = (uint32_t)rng;
+    b.v[q] = (uint32_t)(rng >> 32);
+  }
+  // bring both below the modulus: clear top bits, then one conditional subtraction
+  a.v[F::N - 1] &= (F::mod(F::N - 1) | (F::mod(F::N - 1) >> 1) | (F::mod(F::N - 1) >> 2) | (F::mod(F::N - 1) >> 4) | (F::mod(F::N - 1) >> 8) | (F::mod(F::N - 1) >> 16));
+  b.v[F::N - 1] &= (F::mod(F::N - 1) | (F::mod(F::N - 1) >> 1) | (F::mod(F::N - 1) >> 2) | (F::mod(F::N - 1) >> 4) | (F::mod(F::N - 1) >> 8) | (F::mod(F::N - 1) >> 16));
+  reduce_once<F>(a, a, 0);
+  reduce_once<F>(b, b, 0);
+  if ((rng & 15) == 0) a = b;            // squarings
+  if ((rng & 1023) == 1) bn_zero(b);     // zero operand
+  if ((rng & 1023) == 2) {               // p - 1
+    b = modulus<F>();
+    b.v[0] -= 1;
+  }
+  mont_mul<F>(r1, a, b);
+  mont_mul_plainc<F>(r2, a, b);
+  return bn_eq(r1, r2) ? 0u : 1u;
+}
+
+__global__ __launch_bounds__(64) void k_selftest_field_mul(uint64_t iters, unsigned long long* mismatches) {
+  uint64_t rng = 0x9E3779B97F4A7C15ull * (blockIdx.x * 64ull + threadIdx.x + 1);
+  uint32_t bad = 0;
+#pragma unroll 1
+  for (uint64_t it = 0; it < iters; it++) {
+    bad += selftest_one<FpParams>(rng);
+    bad += selftest_one<FrParams>(rng);
+  }
+  if (bad) atomicAdd(mismatches, (unsigned long long)bad);
+}
+
+extern "C" int32_t kzg_selftest_field_mul(const kzg_ctx* ctx, uint64_t lanes, uint64_t iters, uint64_t* mismatches) {
+  if (!ctx || !mismatches || lanes == 0) return fail(KZG_FAIL_ARGUMENT, "null argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  unsigned long long* d = nullptr;
+  HIP_TRY(hipMalloc(&d, sizeof(unsigned long long)));
+  HIP_TRY(hipMemset(d, 0, sizeof(unsigned long long)));
+  hipLaunchKernelGGL(k_selftest_field_mul, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, nullptr, iters, d);
+  HIP_TRY(hipGetLastError());
+  unsigned long long h = 0;
+  HIP_TRY(hipMemcpy(&h, d, sizeof(h), hipMemcpyDeviceToHost));
+  (void)hipFree(d);
+  *mismatches = h;
   return 0;
 }
 

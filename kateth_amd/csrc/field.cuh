@@ -37,6 +37,7 @@ struct bn {
 struct FpParams {
   static constexpr int N = 12;
   static constexpr uint32_t INV = KZG_FP_INV32;
+  static constexpr uint64_t INV64 = KZG_FP_INV64;
   KZG_HD static constexpr uint32_t mod(int i) {
     constexpr uint32_t t[N] = KZG_FP_MOD;
     return t[i];
@@ -62,6 +63,7 @@ struct FpParams {
 struct FrParams {
   static constexpr int N = 8;
   static constexpr uint32_t INV = KZG_FR_INV32;
+  static constexpr uint64_t INV64 = KZG_FR_INV64;
   KZG_HD static constexpr uint32_t mod(int i) {
     constexpr uint32_t t[N] = KZG_FR_MOD;
     return t[i];
@@ -184,30 +186,42 @@ KZG_HD void bn_zero(bn<N>& a) {
   for (int i = 0; i < N; i++) a.v[i] = 0;
 }
 
-// r = a + b, returns carry
+// r = a + b, returns carry.  Device: native carry chain (v_add_co / v_addc_co).
 template <int N>
 KZG_HD uint32_t bn_add(bn<N>& r, const bn<N>& a, const bn<N>& b) {
-  uint64_t c = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+  unsigned int c = 0;
 #pragma unroll
+  for (int i = 0; i < N; i++) r.v[i] = __builtin_addc(a.v[i], b.v[i], c, &c);
+  return c;
+#else
+  uint64_t c = 0;
   for (int i = 0; i < N; i++) {
     c += (uint64_t)a.v[i] + b.v[i];
     r.v[i] = (uint32_t)c;
     c >>= 32;
   }
   return (uint32_t)c;
+#endif
 }
 
 // r = a - b, returns borrow (1 if a < b)
 template <int N>
 KZG_HD uint32_t bn_sub(bn<N>& r, const bn<N>& a, const bn<N>& b) {
-  int64_t c = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+  unsigned int c = 0;
 #pragma unroll
+  for (int i = 0; i < N; i++) r.v[i] = __builtin_subc(a.v[i], b.v[i], c, &c);
+  return c;
+#else
+  int64_t c = 0;
   for (int i = 0; i < N; i++) {
     c += (int64_t)a.v[i] - (int64_t)b.v[i];
     r.v[i] = (uint32_t)c;
     c >>= 32;
   }
   return (uint32_t)(c & 1);
+#endif
 }
 
 // a >= b ?
@@ -280,8 +294,58 @@ KZG_HD void dbl_mod(bn<F::N>& r, const bn<F::N>& a) {
 // Montgomery multiplication, finely integrated product scanning.
 // r = a*b*2^(-32N) mod m ; inputs < m, output < m.
 // ---------------------------------------------------------------------------
+#if !defined(__HIP_DEVICE_COMPILE__)
+// host instantiation: the same value representation (little-endian limbs, radix 2^(32N)) viewed
+// as N/2 64-bit limbs, CIOS with unsigned __int128 -- ~3x faster than the 32-bit path on a CPU;
+// only the once-per-call pairing and the tests run here.
+template <class F>
+inline void mont_mul_host64(bn<F::N>& r, const bn<F::N>& a, const bn<F::N>& b) {
+  constexpr int M = F::N / 2;
+  typedef unsigned __int128 u128;
+  uint64_t A[M], B[M], P[M], t[M + 2];
+  for (int i = 0; i < M; i++) {
+    A[i] = (uint64_t)a.v[2 * i] | ((uint64_t)a.v[2 * i + 1] << 32);
+    B[i] = (uint64_t)b.v[2 * i] | ((uint64_t)b.v[2 * i + 1] << 32);
+    P[i] = (uint64_t)F::mod(2 * i) | ((uint64_t)F::mod(2 * i + 1) << 32);
+  }
+  for (int i = 0; i < M + 2; i++) t[i] = 0;
+  for (int i = 0; i < M; i++) {
+    uint64_t c = 0;
+    for (int j = 0; j < M; j++) {
+      u128 s = (u128)A[j] * B[i] + t[j] + c;
+      t[j] = (uint64_t)s;
+      c = (uint64_t)(s >> 64);
+    }
+    u128 s = (u128)t[M] + c;
+    t[M] = (uint64_t)s;
+    t[M + 1] = (uint64_t)(s >> 64);
+    uint64_t m = t[0] * F::INV64;
+    s = (u128)m * P[0] + t[0];
+    c = (uint64_t)(s >> 64);
+    for (int j = 1; j < M; j++) {
+      s = (u128)m * P[j] + t[j] + c;
+      t[j - 1] = (uint64_t)s;
+      c = (uint64_t)(s >> 64);
+    }
+    s = (u128)t[M] + c;
+    t[M - 1] = (uint64_t)s;
+    t[M] = t[M + 1] + (uint64_t)(s >> 64);
+  }
+  bn<F::N> tt;
+  for (int i = 0; i < M; i++) {
+    tt.v[2 * i] = (uint32_t)t[i];
+    tt.v[2 * i + 1] = (uint32_t)(t[i] >> 32);
+  }
+  reduce_once<F>(r, tt, (uint32_t)t[M]);
+}
+#endif
+
 template <class F>
 KZG_HD void mont_mul(bn<F::N>& r, const bn<F::N>& a, const bn<F::N>& b) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+  mont_mul_host64<F>(r, a, b);
+  return;
+#endif
   constexpr int N = F::N;
   uint32_t m[N];
   uint32_t t[N];
@@ -329,6 +393,46 @@ KZG_HD void mont_mul(bn<F::N>& r, const bn<F::N>& a, const bn<F::N>& b) {
   KZG_UNROLL_FULL
   for (int i = 0; i < N; i++) tt.v[i] = t[i];
   reduce_once<F>(r, tt, carry);
+}
+
+// Reference Montgomery multiplication in plain C (CIOS, 64-bit temporaries): the
+// compiler schedules it and inserts every hazard wait state itself.  Used by the
+// on-device self-test that cross-checks the inline-asm chains of mont_mul.
+template <class F>
+KZG_HD void mont_mul_plainc(bn<F::N>& r, const bn<F::N>& a, const bn<F::N>& b) {
+  constexpr int N = F::N;
+  uint32_t t[N + 2];
+  KZG_UNROLL_FULL
+  for (int i = 0; i < N + 2; i++) t[i] = 0;
+  KZG_UNROLL_FULL
+  for (int i = 0; i < N; i++) {
+    uint64_t c = 0;
+    KZG_UNROLL_FULL
+    for (int j = 0; j < N; j++) {
+      uint64_t s = (uint64_t)a.v[j] * b.v[i] + t[j] + c;
+      t[j] = (uint32_t)s;
+      c = s >> 32;
+    }
+    uint64_t s = (uint64_t)t[N] + c;
+    t[N] = (uint32_t)s;
+    t[N + 1] = (uint32_t)(s >> 32);
+    uint32_t m = t[0] * F::INV;
+    s = (uint64_t)m * F::mod(0) + t[0];
+    c = s >> 32;
+    KZG_UNROLL_FULL
+    for (int j = 1; j < N; j++) {
+      s = (uint64_t)m * F::mod(j) + t[j] + c;
+      t[j - 1] = (uint32_t)s;
+      c = s >> 32;
+    }
+    s = (uint64_t)t[N] + c;
+    t[N - 1] = (uint32_t)s;
+    t[N] = t[N + 1] + (uint32_t)(s >> 32);
+  }
+  bn<N> tt;
+  KZG_UNROLL_FULL
+  for (int i = 0; i < N; i++) tt.v[i] = t[i];
+  reduce_once<F>(r, tt, t[N]);
 }
 
 template <class F>

@@ -133,6 +133,7 @@ _SIGNATURES = {
     "kzg_profile_begin": (ctypes.c_int32, [ctypes.c_void_p]),
     "kzg_profile_end": (ctypes.c_int32, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]),
     "kzg_ctx_adds_per_blob": (ctypes.c_uint64, [ctypes.c_void_p]),
+    "kzg_selftest_field_mul": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]),
     "kzg_microbench_fp_mul": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(ctypes.c_float)]),
 }
 
@@ -444,6 +445,11 @@ class Setup:
         cnt = ctypes.c_uint64(0)
         self._check(self._lib.kzg_profile_end(self._h, ctypes.byref(ms), ctypes.byref(cnt)), "kzg_profile_end")
         return {"msm_ms": ms.value, "msm_launches": cnt.value, "adds_per_blob": self._lib.kzg_ctx_adds_per_blob(self._h)}
+
+    def selftest_field_mul(self, lanes: int, iters: int) -> int:
+        bad = ctypes.c_uint64(0)
+        self._check(self._lib.kzg_selftest_field_mul(self._h, lanes, iters, ctypes.byref(bad)), "kzg_selftest_field_mul")
+        return bad.value
 
     def microbench_fp_mul(self, lanes: int, iters: int) -> float:
         ms = ctypes.c_float(0)

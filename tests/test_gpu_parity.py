@@ -392,3 +392,11 @@ def test_verify_roundtrip_at_batch_size(engine, torch_cuda):
     d_p[500 * 48:501 * 48] = d_p[0:48]
     torch.cuda.synchronize()
     assert engine.verify_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n) is False
+
+
+def test_asm_multiply_matches_compiler_scheduled_multiply(engine):
+    """hardware self-test of the inline-asm v_mad_u64_u32 / v_addc_co_u32 chains (no manual wait
+    states between the carry producer and consumer) against a plain-C multiply for which hipcc
+    inserts every hazard nop itself: one wave alone (worst case for back-to-back issue) and a full chip."""
+    assert engine.selftest_field_mul(64, 20000) == 0
+    assert engine.selftest_field_mul(256 * 4 * 64 * 2, 400) == 0
