@@ -4,73 +4,27 @@
 // verification, runs the single two-pairing check per call -- pairing.hpp).
 // There is NO CPU compute fallback: without a HIP device every entry point
 // fails with KZG_FAIL_NO_DEVICE / KZG_FAIL_HIP.
-#include <hip/hip_runtime.h>
-
-#include <stdlib.h>
-#include <string.h>
-
-#include <mutex>
-#include <new>
-#include <string>
-#include <utility>
-#include <vector>
-
-#include "../../include/kateth_amd.h"
-#include "blob_kernels.cuh"
-#include "msm_fixed.cuh"
-#include "pairing.hpp"
+#include "engine_internal.hpp"
 #include "setup_kernels.cuh"
-#include "verify_kernels.cuh"
-
-using namespace kzg;
-
 // ---------------------------------------------------------------------------
 // error plumbing
 // ---------------------------------------------------------------------------
 static thread_local std::string g_last_error;
 extern "C" const char* kzg_last_error(void) { return g_last_error.c_str(); }
 
-static int32_t fail(int32_t code, const std::string& msg) {
+int32_t fail(int32_t code, const std::string& msg) {
   g_last_error = msg;
   return code;
 }
+const std::string& last_error_text() { return g_last_error; }
 
-#define HIP_TRY(expr)                                                                                      \
-  do {                                                                                                     \
-    hipError_t _e = (expr);                                                                                \
-    if (_e != hipSuccess) return fail(KZG_FAIL_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));  \
-  } while (0)
 
 // ---------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------
-struct kzg_ctx {
-  int device = 0;
-  MsmGeom geom{};
-  uint4* d_table = nullptr;      // fixed-base table, table_entries(geom) * 96 B
-  uint4* d_bases_brp = nullptr;  // 4096 affine Lagrange points, BRP order
-  fr_t* d_roots_brp = nullptr;   // 4096 roots of unity, Montgomery, BRP order
-  fr_t* d_roots_r2 = nullptr;    // the same roots times R^2 (see k_eval_frac)
-  uint4* d_gen_affine = nullptr; // G1 generator, affine Montgomery (96 B)
-  host::pairing_ctx* pairing = nullptr;  // host: Frobenius constants + Miller lines of G2 and [tau]_2
-  uint64_t table_bytes = 0;
-  uint32_t num_cus = 256;
-  hipStream_t side_stream = nullptr;  // non-blocking stream for work that overlaps the caller's stream
-  int msm_occupancy = 2;  // waves per SIMD the MSM kernel is compiled for (KATETH_AMD_MSM_OCC=3: experiment)
-  // workspace (grown on demand, guarded by lock)
-  mutable std::mutex lock;
-  mutable void* ws = nullptr;
-  mutable size_t ws_bytes = 0;
-  mutable hipEvent_t ws_event = nullptr;  // recorded after the last enqueued user of `ws`; the next user's stream waits on it
-  // profiling (kzg_profile_begin/end): event pairs around k_msm_fixed launches
-  mutable bool profiling = false;
-  mutable std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
-  mutable size_t prof_used = 0;
-  // host copy of what the pairing needs
-  uint8_t g2_tau[96];  // g2_monomial[1] compressed (validated at create)
-};
 
-static int32_t ws_reserve(const kzg_ctx* ctx, size_t bytes) {
+
+int32_t ws_reserve(const kzg_ctx* ctx, size_t bytes) {
   if (ctx->ws_bytes >= bytes) return 0;
   if (ctx->ws) {
     HIP_TRY(hipDeviceSynchronize());
@@ -85,17 +39,16 @@ static int32_t ws_reserve(const kzg_ctx* ctx, size_t bytes) {
 }
 
 // `ws` is shared by successive calls that may be enqueued on different streams: order them.
-static int32_t ws_acquire(const kzg_ctx* ctx, hipStream_t st) {
+int32_t ws_acquire(const kzg_ctx* ctx, hipStream_t st) {
   if (ctx->ws_event) HIP_TRY(hipStreamWaitEvent(st, ctx->ws_event, 0));
   return 0;
 }
-static int32_t ws_release(const kzg_ctx* ctx, hipStream_t st) {
+int32_t ws_release(const kzg_ctx* ctx, hipStream_t st) {
   if (!ctx->ws_event) HIP_TRY(hipEventCreateWithFlags(&ctx->ws_event, hipEventDisableTiming));
   HIP_TRY(hipEventRecord(ctx->ws_event, st));
   return 0;
 }
 
-static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 static MsmGeom make_geom(uint32_t c) {
   MsmGeom g;
@@ -110,7 +63,7 @@ static MsmGeom make_geom(uint32_t c) {
   return g;
 }
 
-static uint32_t choose_splits(const kzg_ctx* ctx, uint64_t n) {
+uint32_t choose_splits(const kzg_ctx* ctx, uint64_t n) {
   // aim for >= 4 waves per SIMD-slot-pair across the chip; splits is a power of two <= 64
   const uint64_t target = (uint64_t)ctx->num_cus * 8;
   uint32_t s = 1;
@@ -147,7 +100,7 @@ extern "C" int32_t kzg_profile_end(const kzg_ctx* ctx, double* msm_ms_total, uin
 }
 
 // returns the event pair to record around the next dominant-kernel launch (or nullptrs)
-static int32_t prof_next(const kzg_ctx* ctx, hipEvent_t* e0, hipEvent_t* e1) {
+int32_t prof_next(const kzg_ctx* ctx, hipEvent_t* e0, hipEvent_t* e1) {
   *e0 = *e1 = nullptr;
   if (!ctx->profiling) return 0;
   if (ctx->prof_used == ctx->prof_events.size()) {
@@ -173,6 +126,7 @@ extern "C" void kzg_ctx_destroy(kzg_ctx* ctx) {
   if (ctx->d_bases_brp) (void)hipFree(ctx->d_bases_brp);
   if (ctx->d_roots_brp) (void)hipFree(ctx->d_roots_brp);
   if (ctx->d_roots_r2) (void)hipFree(ctx->d_roots_r2);
+  if (ctx->d_roots_sq) (void)hipFree(ctx->d_roots_sq);
   if (ctx->d_gen_affine) (void)hipFree(ctx->d_gen_affine);
   delete ctx->pairing;
   if (ctx->ws) (void)hipFree(ctx->ws);
@@ -190,6 +144,13 @@ __global__ __launch_bounds__(64) void k_setup_roots_r2(const fr_t* __restrict__ 
   if (t >= 4096) return;
   fr_t r;
   to_mont<FrParams>(r, roots[t]);
+  out[t] = r;
+}
+__global__ __launch_bounds__(64) void k_setup_roots_sq(const fr_t* __restrict__ roots, fr_t* __restrict__ out) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 2048) return;
+  fr_t r;
+  fr_sqr(r, roots[2 * t]);
   out[t] = r;
 }
 
@@ -254,6 +215,8 @@ static int32_t ctx_build(kzg_ctx* ctx, const uint8_t* g1_lagrange, const uint8_t
   hipLaunchKernelGGL(k_setup_roots, dim3(64), dim3(64), 0, st, ctx->d_roots_brp);
   HIP_TRY(hipMalloc(&ctx->d_roots_r2, 4096 * sizeof(fr_t)));
   hipLaunchKernelGGL(k_setup_roots_r2, dim3(64), dim3(64), 0, st, ctx->d_roots_brp, ctx->d_roots_r2);
+  HIP_TRY(hipMalloc(&ctx->d_roots_sq, 2048 * sizeof(fr_t)));
+  hipLaunchKernelGGL(k_setup_roots_sq, dim3(32), dim3(64), 0, st, ctx->d_roots_brp, ctx->d_roots_sq);
   HIP_TRY(hipGetLastError());
   // ---- fixed-base table -----------------------------------------------------
   const uint64_t entries = table_entries(g);
@@ -318,10 +281,6 @@ extern "C" int32_t kzg_ctx_create(const uint8_t* g1_lagrange, const uint8_t* g2_
 // ---------------------------------------------------------------------------
 // blob_to_kzg_commitment
 // ---------------------------------------------------------------------------
-template <bool BE_BYTES>
-static int32_t msm_pipeline(const kzg_ctx* ctx, const uint8_t* d_scalars, uint64_t n, uint8_t* d_out48, int32_t* d_status, g1_xyzz* partials,
-                            g1_xyzz* sums, uint32_t splits, hipStream_t st);
-
 static int32_t commit_dev_locked(const kzg_ctx* ctx, const void* d_blobs, uint64_t n, void* d_out48, int32_t* d_status, hipStream_t st) {
   if (n == 0) return 0;
   const uint64_t chunk_max = 16384;  // bounds the lane-partial scratch (12 KiB per blob)
@@ -492,7 +451,3 @@ extern "C" int32_t kzg_selftest_field_mul(const kzg_ctx* ctx, uint64_t lanes, ui
   return 0;
 }
 
-// ---------------------------------------------------------------------------
-// entry points still to come in this round
-// ---------------------------------------------------------------------------
-#include "engine_proof_verify.inc"

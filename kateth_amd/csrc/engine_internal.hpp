@@ -1,0 +1,82 @@
+// Shared by the engine translation units (engine.hip, engine_proof.hip, engine_verify.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <mutex>
+#include <new>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/kateth_amd.h"
+#include "blob_kernels.cuh"
+#include "msm_fixed.cuh"
+#include "pairing.hpp"
+
+using namespace kzg;
+
+int32_t fail(int32_t code, const std::string& msg);
+const std::string& last_error_text();
+
+#define HIP_TRY(expr)                                                                                      \
+  do {                                                                                                     \
+    hipError_t _e = (expr);                                                                                \
+    if (_e != hipSuccess) return fail(KZG_FAIL_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));  \
+  } while (0)
+
+struct kzg_ctx {
+  int device = 0;
+  MsmGeom geom{};
+  uint4* d_table = nullptr;      // fixed-base table, table_entries(geom) * 96 B
+  uint4* d_bases_brp = nullptr;  // 4096 affine Lagrange points, BRP order
+  fr_t* d_roots_brp = nullptr;   // 4096 roots of unity, Montgomery, BRP order
+  fr_t* d_roots_r2 = nullptr;    // the same roots times R^2 (see k_eval_frac)
+  fr_t* d_roots_sq = nullptr;    // 2048 squares w_{2k}^2 (Montgomery): pair denominators z^2 - w^2
+  uint4* d_gen_affine = nullptr; // G1 generator, affine Montgomery (96 B)
+  host::pairing_ctx* pairing = nullptr;  // host: Frobenius constants + Miller lines of G2 and [tau]_2
+  uint64_t table_bytes = 0;
+  uint32_t num_cus = 256;
+  hipStream_t side_stream = nullptr;  // non-blocking stream for work that overlaps the caller's stream
+  int msm_occupancy = 2;  // waves per SIMD the MSM kernel is compiled for (KATETH_AMD_MSM_OCC=3: experiment)
+  // workspace (grown on demand, guarded by lock)
+  mutable std::mutex lock;
+  mutable void* ws = nullptr;
+  mutable size_t ws_bytes = 0;
+  mutable hipEvent_t ws_event = nullptr;  // recorded after the last enqueued user of `ws`; the next user's stream waits on it
+  // profiling (kzg_profile_begin/end): event pairs around k_msm_fixed launches
+  mutable bool profiling = false;
+  mutable std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+  mutable size_t prof_used = 0;
+  // host copy of what the pairing needs
+  uint8_t g2_tau[96];  // g2_monomial[1] compressed (validated at create)
+};
+
+int32_t ws_reserve(const kzg_ctx* ctx, size_t bytes);
+int32_t ws_acquire(const kzg_ctx* ctx, hipStream_t st);
+int32_t ws_release(const kzg_ctx* ctx, hipStream_t st);
+int32_t prof_next(const kzg_ctx* ctx, hipEvent_t* e0, hipEvent_t* e1);
+uint32_t choose_splits(const kzg_ctx* ctx, uint64_t n);
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static inline unsigned blocks_for(uint64_t n, unsigned per) { return (unsigned)((n + per - 1) / per); }
+
+// launches the fixed-base MSM + reduce + compress over `n` scalar vectors already on device
+template <bool BE_BYTES>
+static int32_t msm_pipeline(const kzg_ctx* ctx, const uint8_t* d_scalars, uint64_t n, uint8_t* d_out48, int32_t* d_status, g1_xyzz* partials,
+                            g1_xyzz* sums, uint32_t splits, hipStream_t st) {
+  hipEvent_t pe0, pe1;
+  int32_t rc = prof_next(ctx, &pe0, &pe1);
+  if (rc) return rc;
+  if (pe0) HIP_TRY(hipEventRecord(pe0, st));
+  hipLaunchKernelGGL((k_msm_fixed<BE_BYTES, 2>), dim3((unsigned)(n * splits)), dim3(64), 0, st, d_scalars, splits, ctx->d_table, ctx->geom,
+                     partials, d_status);
+  HIP_TRY(hipGetLastError());
+  if (pe1) HIP_TRY(hipEventRecord(pe1, st));
+  hipLaunchKernelGGL(k_msm_reduce, dim3((unsigned)n), dim3(64), 0, st, partials, splits, n, sums);
+  hipLaunchKernelGGL(k_g1_compress, dim3(blocks_for(n, 64)), dim3(64), 0, st, sums, n, d_status, d_out48);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}

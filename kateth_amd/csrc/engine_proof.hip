@@ -1,4 +1,5 @@
-// compute_blob_kzg_proof / compute_kzg_proof entry points (included by engine.hip)
+// compute_blob_kzg_proof / compute_kzg_proof entry points
+#include "engine_internal.hpp"
 
 __global__ __launch_bounds__(256) void k_merge_status(int32_t* __restrict__ primary, const int32_t* __restrict__ secondary, uint64_t n) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -13,26 +14,6 @@ __global__ __launch_bounds__(256) void k_fr_store_be(const fr_t* __restrict__ pl
   uint4* o = reinterpret_cast<uint4*>(out32 + i * 32);
   o[0] = make_uint4(__builtin_bswap32(v.v[7]), __builtin_bswap32(v.v[6]), __builtin_bswap32(v.v[5]), __builtin_bswap32(v.v[4]));
   o[1] = make_uint4(__builtin_bswap32(v.v[3]), __builtin_bswap32(v.v[2]), __builtin_bswap32(v.v[1]), __builtin_bswap32(v.v[0]));
-}
-
-static inline unsigned blocks_for(uint64_t n, unsigned per) { return (unsigned)((n + per - 1) / per); }
-
-// launches the fixed-base MSM + reduce + compress over `n` scalar vectors already on device
-template <bool BE_BYTES>
-static int32_t msm_pipeline(const kzg_ctx* ctx, const uint8_t* d_scalars, uint64_t n, uint8_t* d_out48, int32_t* d_status, g1_xyzz* partials,
-                            g1_xyzz* sums, uint32_t splits, hipStream_t st) {
-  hipEvent_t pe0, pe1;
-  int32_t rc = prof_next(ctx, &pe0, &pe1);
-  if (rc) return rc;
-  if (pe0) HIP_TRY(hipEventRecord(pe0, st));
-  hipLaunchKernelGGL((k_msm_fixed<BE_BYTES, 2>), dim3((unsigned)(n * splits)), dim3(64), 0, st, d_scalars, splits, ctx->d_table, ctx->geom,
-                     partials, d_status);
-  HIP_TRY(hipGetLastError());
-  if (pe1) HIP_TRY(hipEventRecord(pe1, st));
-  hipLaunchKernelGGL(k_msm_reduce, dim3((unsigned)n), dim3(64), 0, st, partials, splits, n, sums);
-  hipLaunchKernelGGL(k_g1_compress, dim3(blocks_for(n, 64)), dim3(64), 0, st, sums, n, d_status, d_out48);
-  HIP_TRY(hipGetLastError());
-  return 0;
 }
 
 // proofs for n (blob, commitment) or (blob, z) items resident on the device.
@@ -60,9 +41,10 @@ static int32_t proof_dev_locked(const kzg_ctx* ctx, const uint8_t* d_blobs, cons
     off = align_up(off + bytes, 256);
     return o;
   };
-  size_t o_z[2], o_y[2], o_cs[2], o_q[2];
+  size_t o_z[2], o_y[2], o_cs[2], o_q[2], o_ir[2];
   for (int sl = 0; sl < 2; sl++) {
     o_z[sl] = take(cn * sizeof(fr_t));
+    o_ir[sl] = take(cn * sizeof(fr_t));
     o_y[sl] = take(cn * sizeof(fr_t));
     o_cs[sl] = take(cn * sizeof(int32_t));
     o_q[sl] = take(cn * 4096 * sizeof(fr_t));
@@ -101,6 +83,7 @@ static int32_t proof_dev_locked(const kzg_ctx* ctx, const uint8_t* d_blobs, cons
     const uint64_t m = (n - base < cn) ? (n - base) : cn;
     fr_t* z = reinterpret_cast<fr_t*>(ws + o_z[sl]);
     fr_t* y = reinterpret_cast<fr_t*>(ws + o_y[sl]);
+    fr_t* invr = reinterpret_cast<fr_t*>(ws + o_ir[sl]);
     int32_t* cstat = reinterpret_cast<int32_t*>(ws + o_cs[sl]);
     fr_t* q = reinterpret_cast<fr_t*>(ws + o_q[sl]);
     const uint8_t* blobs = d_blobs + base * (uint64_t)KZG_BYTES_PER_BLOB;
@@ -114,7 +97,8 @@ static int32_t proof_dev_locked(const kzg_ctx* ctx, const uint8_t* d_blobs, cons
     } else {
       hipLaunchKernelGGL(k_fr_parse, dim3(blocks_for(m, 64)), dim3(64), 0, side, d_z32 + base * 32, m, z, cstat);
     }
-    hipLaunchKernelGGL(k_poly<true>, dim3((unsigned)m), dim3(512), 0, side, blobs, z, ctx->d_roots_brp, y, q, d_status + base);
+    hipLaunchKernelGGL(k_poly_root_inverse, dim3(blocks_for(m, 64)), dim3(64), 0, side, z, m, invr);
+    hipLaunchKernelGGL(k_poly<true>, dim3((unsigned)m), dim3(512), 0, side, blobs, z, ctx->d_roots_brp, invr, y, q, d_status + base);
     hipLaunchKernelGGL(k_merge_status, dim3(blocks_for(m, 256)), dim3(256), 0, side, d_status + base, cstat, m);
     (void)hipEventRecord(ev_prep[k], side);
   };
@@ -200,5 +184,3 @@ extern "C" int32_t kzg_compute_proof_batch(const kzg_ctx* ctx, const uint8_t* bl
   return proof_host(ctx, blobs, z32, 32, false, n, out_proof48, out_y32, status);
 }
 
-// ---- verification entry points: see engine_verify.inc ------------------------------------------
-#include "engine_verify.inc"

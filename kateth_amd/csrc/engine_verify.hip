@@ -1,8 +1,24 @@
-// verify_blob_kzg_proof_batch and the single-item verification entry points
-// (included by engine.hip).  Device work: per-item validation, challenges,
+// verify_blob_kzg_proof_batch and the single-item verification entry points.  Device work: per-item validation, challenges,
 // evaluations, transcript digests, random-linear-combination MSMs.  Host work:
 // hashing ~n/8 bytes of transcript nodes, the W-step Horner combine of the
 // MSM windows, and the single two-pairing check (pairing.hpp).
+
+#include <chrono>
+
+#include "engine_internal.hpp"
+#include "verify_kernels.cuh"
+struct TraceTimer {  // KATETH_AMD_TRACE=1: host-side wall-clock marks on stderr
+  bool on;
+  std::chrono::steady_clock::time_point t0;
+  const char* what;
+  explicit TraceTimer(const char* w) : on(getenv("KATETH_AMD_TRACE") != nullptr), t0(std::chrono::steady_clock::now()), what(w) {}
+  void mark(const char* label) {
+    if (!on) return;
+    auto t1 = std::chrono::steady_clock::now();
+    fprintf(stderr, "[kateth_amd trace] %s: %s +%.3f ms\n", what, label, std::chrono::duration<double, std::milli>(t1 - t0).count());
+    t0 = t1;
+  }
+};
 
 struct kzg_verify_session {
   const kzg_ctx* ctx = nullptr;
@@ -87,14 +103,24 @@ static bool host_affine_from_be96(host::g1_host_affine& a, const uint8_t* in96) 
   return true;
 }
 
-// variable-base MSM over `nterms` device-resident terms; result on the host
-static int32_t msm_var(const kzg_ctx* ctx, const uint4* d_points, const uint8_t* d_inf, const fr_t* d_scalars, uint64_t nterms, hipStream_t st,
-                       g1_xyzz& result) {
-  xyzz_set_inf(result);
+// variable-base MSM over `nterms` device-resident terms, split into an asynchronous launch
+// (kernels + window read-back enqueued on `st`) and a finish (synchronise, Horner on the host)
+// so that independent MSMs can run concurrently on different streams.
+struct MsmVarJob {
+  VarGeom g{};
+  uint8_t* buf = nullptr;
+  std::vector<g1_xyzz> win;
+  hipStream_t st = nullptr;
+  bool active = false;
+};
+
+static int32_t msm_var_launch(MsmVarJob& job, const uint4* d_points, const uint8_t* d_inf, const fr_t* d_scalars, uint64_t nterms, hipStream_t st) {
+  job.active = false;
+  job.st = st;
   if (nterms == 0) return 0;
   const VarGeom g = choose_var_geom(nterms);
+  job.g = g;
   const uint32_t nb = g.W * g.half;
-  const uint32_t segs = (g.half + VAR_SEG - 1) / VAR_SEG;
   size_t off = 0;
   auto take = [&](size_t bytes) {
     size_t o = off;
@@ -105,41 +131,56 @@ static int32_t msm_var(const kzg_ctx* ctx, const uint4* d_points, const uint8_t*
   const size_t o_entries = take((size_t)nterms * g.W * 4);
   // split every bucket over K threads so that a thread chains ~16 additions
   uint64_t load = nterms / g.half + 1;
-  uint32_t K = (uint32_t)((load + 15) / 16);
-  if (K < 1) K = 1;
-  if (K > 256) K = 256;
+  uint32_t K = 1;  // power of two <= 64 (k_var_fold sums the K partials of a bucket inside one wave)
+  while (K < 64 && (uint64_t)K * 16 < load) K <<= 1;
   const size_t o_part = take((size_t)nb * K * sizeof(g1_xyzz));
   const size_t o_bsum = take((size_t)nb * sizeof(g1_xyzz));
-  const size_t o_seg = take((size_t)g.W * segs * sizeof(g1_xyzz));
   const size_t o_win = take((size_t)g.W * sizeof(g1_xyzz));
-  uint8_t* buf = nullptr;
-  HIP_TRY(hipMalloc(&buf, off));
+  HIP_TRY(hipMalloc(&job.buf, off));
+  uint8_t* buf = job.buf;
   uint32_t* counts = (uint32_t*)(buf + o_counts);
   uint32_t* offsets = (uint32_t*)(buf + o_offsets);
   uint32_t* cursors = (uint32_t*)(buf + o_cursors);
   uint32_t* entries = (uint32_t*)(buf + o_entries);
   g1_xyzz* bpart = (g1_xyzz*)(buf + o_part);
   g1_xyzz* bsum = (g1_xyzz*)(buf + o_bsum);
-  g1_xyzz* segsum = (g1_xyzz*)(buf + o_seg);
   g1_xyzz* winsum = (g1_xyzz*)(buf + o_win);
+  job.win.resize(g.W);
+  job.active = true;
+  HIP_TRY(hipMemsetAsync(counts, 0, (size_t)(nb + 1) * 4, st));
+  hipLaunchKernelGGL(k_var_count, dim3(blocks_for(nterms, 256)), dim3(256), 0, st, d_scalars, d_inf, nterms, g, counts);
+  hipLaunchKernelGGL(k_var_scan, dim3(1), dim3(1024), 0, st, counts, nb, offsets, cursors);
+  hipLaunchKernelGGL(k_var_scatter, dim3(blocks_for(nterms, 256)), dim3(256), 0, st, d_scalars, d_inf, nterms, g, cursors, entries);
+  hipLaunchKernelGGL(k_var_buckets, dim3(blocks_for((uint64_t)nb * K, 64)), dim3(64), 0, st, d_points, offsets, entries, nb, K, bpart);
+  hipLaunchKernelGGL(k_var_fold, dim3(blocks_for((uint64_t)nb * K, 64)), dim3(64), 0, st, bpart, nb, K, bsum);
+  hipLaunchKernelGGL(k_var_windows, dim3(g.W), dim3(64), 0, st, bsum, g, winsum);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(job.win.data(), winsum, (size_t)g.W * sizeof(g1_xyzz), hipMemcpyDeviceToHost, st));
+  return 0;
+}
+
+static int32_t msm_var_finish(MsmVarJob& job, g1_xyzz& result) {
+  xyzz_set_inf(result);
+  if (!job.active) return 0;
   int32_t rc = 0;
-  do {
-    if (hipMemsetAsync(counts, 0, (size_t)(nb + 1) * 4, st) != hipSuccess) { rc = fail(KZG_FAIL_HIP, "memset"); break; }
-    hipLaunchKernelGGL(k_var_count, dim3(blocks_for(nterms, 256)), dim3(256), 0, st, d_scalars, d_inf, nterms, g, counts);
-    hipLaunchKernelGGL(k_var_scan, dim3(1), dim3(1024), 0, st, counts, nb, offsets, cursors);
-    hipLaunchKernelGGL(k_var_scatter, dim3(blocks_for(nterms, 256)), dim3(256), 0, st, d_scalars, d_inf, nterms, g, cursors, entries);
-    hipLaunchKernelGGL(k_var_buckets, dim3(blocks_for((uint64_t)nb * K, 64)), dim3(64), 0, st, d_points, offsets, entries, nb, K, bpart);
-    hipLaunchKernelGGL(k_var_fold, dim3(blocks_for(nb, 64)), dim3(64), 0, st, bpart, nb, K, bsum);
-    hipLaunchKernelGGL(k_var_segments, dim3(blocks_for((uint64_t)g.W * segs, 64)), dim3(64), 0, st, bsum, g, segs, segsum);
-    hipLaunchKernelGGL(k_var_windows, dim3(g.W), dim3(64), 0, st, segsum, segs, winsum);
-    if (hipGetLastError() != hipSuccess) { rc = fail(KZG_FAIL_HIP, "variable-base MSM launch failed"); break; }
-    std::vector<g1_xyzz> win(g.W);
-    if (hipMemcpyAsync(win.data(), winsum, (size_t)g.W * sizeof(g1_xyzz), hipMemcpyDeviceToHost, st) != hipSuccess ||
-        hipStreamSynchronize(st) != hipSuccess) { rc = fail(KZG_FAIL_HIP, "variable-base MSM readback failed"); break; }
-    host_horner(result, win, g);
-  } while (0);
-  (void)hipFree(buf);
+  if (hipStreamSynchronize(job.st) != hipSuccess) rc = fail(KZG_FAIL_HIP, "variable-base MSM synchronize failed");
+  if (rc == 0) host_horner(result, job.win, job.g);
+  (void)hipFree(job.buf);
+  job.buf = nullptr;
+  job.active = false;
   return rc;
+}
+
+static int32_t msm_var(const kzg_ctx* ctx, const uint4* d_points, const uint8_t* d_inf, const fr_t* d_scalars, uint64_t nterms, hipStream_t st,
+                       g1_xyzz& result) {
+  (void)ctx;
+  MsmVarJob job;
+  int32_t rc = msm_var_launch(job, d_points, d_inf, d_scalars, nterms, st);
+  if (rc) {
+    if (job.buf) (void)hipFree(job.buf);
+    return rc;
+  }
+  return msm_var_finish(job, result);
 }
 
 static void scan_first_error(const int32_t* st, uint64_t n, int32_t* idx, int32_t* code) {
@@ -158,6 +199,7 @@ extern "C" int32_t kzg_verify_phase1_dev(const kzg_ctx* ctx, const void* d_blobs
   if (!ctx || !out_root32 || !err6 || !session || (n && (!d_blobs || !d_commitments48 || !d_proofs48)))
     return fail(KZG_FAIL_ARGUMENT, "null argument");
   *session = nullptr;
+  TraceTimer tt("phase1");
   HIP_TRY(hipSetDevice(ctx->device));
   hipStream_t st = (hipStream_t)hip_stream;
   kzg_verify_session* s = new (std::nothrow) kzg_verify_session();
@@ -174,21 +216,18 @@ extern "C" int32_t kzg_verify_phase1_dev(const kzg_ctx* ctx, const void* d_blobs
     return o;
   };
   const size_t o_aff = take((2 * n + 1) * 96), o_inf = take(2 * n + 1), o_z = take(n * 32 + 32), o_y = take(n * 32 + 32),
-               o_scal = take((2 * n + 1) * 32), o_stat = take(3 * n * 4 + 4), o_num = take(n * 32 + 32), o_den = take(n * 32 + 32),
-               o_dom = take(n * 4 + 4), o_leaves = take(n * 32 + 32), o_nodes = take(groups * 32 + 32);
+               o_scal = take((2 * n + 1) * 32), o_stat = take(3 * n * 4 + 4), o_leaves = take(n * 32 + 32), o_nodes = take(groups * 32 + 32);
   if (hipMalloc(&s->buf, off) != hipSuccess) {
     delete s;
     return fail(KZG_FAIL_HIP, "hipMalloc(verify session) failed");
   }
+  tt.mark("alloc");
   s->aff = (uint4*)(s->buf + o_aff);
   s->inf = s->buf + o_inf;
   s->z = (fr_t*)(s->buf + o_z);
   s->y = (fr_t*)(s->buf + o_y);
   s->scal = (fr_t*)(s->buf + o_scal);
   int32_t* stat = (int32_t*)(s->buf + o_stat);
-  fr_t* num = (fr_t*)(s->buf + o_num);
-  fr_t* den = (fr_t*)(s->buf + o_den);
-  int32_t* dom = (int32_t*)(s->buf + o_dom);
   uint32_t* leaves = (uint32_t*)(s->buf + o_leaves);
   uint32_t* nodes = (uint32_t*)(s->buf + o_nodes);
   int32_t rc = 0;
@@ -205,8 +244,10 @@ extern "C" int32_t kzg_verify_phase1_dev(const kzg_ctx* ctx, const void* d_blobs
       const uint8_t* blobs = (const uint8_t*)d_blobs;
       const uint8_t* com = (const uint8_t*)d_commitments48;
       const uint8_t* prf = (const uint8_t*)d_proofs48;
-      // point decoding (Fp-multiply bound) runs on the side stream, concurrently with the
-      // SHA-256 challenge + evaluation chain (integer/logic bound) on the caller's stream
+      // SHA-256 challenge first, alone: its 1,024 long-lived waves (one per SIMD at n = 65,536) must be
+      // spread evenly -- launched next to the decode kernel they were placed around its waves and the
+      // kernel took 3x longer (profiles/r01: 23 ms vs 7.5 ms).  The point decoding then runs on the side
+      // stream concurrently with the evaluation kernel, whose short blocks rebalance dynamically.
       hipEvent_t ev_fork = nullptr, ev_join = nullptr;
       if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
           hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess) {
@@ -214,13 +255,12 @@ extern "C" int32_t kzg_verify_phase1_dev(const kzg_ctx* ctx, const void* d_blobs
         break;
       }
       hipStream_t side = ctx->side_stream;
+      hipLaunchKernelGGL(k_challenge, dim3(blocks_for(n, 64)), dim3(64), 0, st, blobs, com, n, s->z);
       (void)hipEventRecord(ev_fork, st);
       (void)hipStreamWaitEvent(side, ev_fork, 0);
       hipLaunchKernelGGL(k_g1_decompress, dim3(blocks_for(2 * n, 64)), dim3(64), 0, side, prf, n, stat + 2 * n, com, n, stat + n, s->aff, s->inf);
       (void)hipEventRecord(ev_join, side);
-      hipLaunchKernelGGL(k_challenge, dim3(blocks_for(n, 64)), dim3(64), 0, st, blobs, com, n, s->z);
-      hipLaunchKernelGGL(k_eval_frac, dim3((unsigned)n), dim3(64), 0, st, blobs, s->z, ctx->d_roots_brp, ctx->d_roots_r2, num, den, dom, stat);
-      hipLaunchKernelGGL(k_eval_finish, dim3(blocks_for(n, 64)), dim3(64), 0, st, blobs, s->z, num, den, dom, n, s->y);
+      hipLaunchKernelGGL(k_eval_frac, dim3((unsigned)n), dim3(64), 0, st, blobs, s->z, ctx->d_roots_brp, ctx->d_roots_r2, ctx->d_roots_sq, s->y, stat);
       (void)hipStreamWaitEvent(st, ev_join, 0);
       (void)hipEventDestroy(ev_fork);
       (void)hipEventDestroy(ev_join);
@@ -245,6 +285,7 @@ extern "C" int32_t kzg_verify_phase1_dev(const kzg_ctx* ctx, const void* d_blobs
     kzg_verify_session_destroy(s);
     return rc;
   }
+  tt.mark("gpu kernels + readback");
   scan_first_error(h_stat.data(), n, &err6[0], &err6[1]);
   scan_first_error(h_stat.data() + n, n, &err6[2], &err6[3]);
   scan_first_error(h_stat.data() + 2 * n, n, &err6[4], &err6[5]);
@@ -253,6 +294,7 @@ extern "C" int32_t kzg_verify_phase1_dev(const kzg_ctx* ctx, const void* d_blobs
   std::vector<uint8_t> nb(groups * 32);
   for (uint64_t k = 0; k < groups * 8; k++) store_be32(nb.data() + 4 * k, h_nodes[k]);
   sha256_bytes(out_root32, nb.data(), nb.size());
+  tt.mark("status scan + root hash");
   *session = s;
   return 0;
 }
@@ -261,6 +303,7 @@ extern "C" int32_t kzg_verify_phase2_dev(kzg_verify_session* s, const uint8_t* r
                                          uint8_t* out192) {
   if (!s || !roots32 || !out192 || world == 0) return fail(KZG_FAIL_ARGUMENT, "null argument");
   const kzg_ctx* ctx = s->ctx;
+  TraceTimer tt("phase2");
   HIP_TRY(hipSetDevice(ctx->device));
   hipStream_t st = s->st;
   const uint64_t n = s->n;
@@ -297,9 +340,20 @@ extern "C" int32_t kzg_verify_phase2_dev(kzg_verify_session* s, const uint8_t* r
       hipLaunchKernelGGL(k_batch_ysum_finish, dim3(1), dim3(256), 0, st, d_ysum, nblk, s->scal + 2 * n);
       if (hipGetLastError() != hipSuccess) { rc = fail(KZG_FAIL_HIP, "verify phase 2 launch failed"); break; }
       // A = sum r_i * proof_i ; B = sum (r_i z_i) proof_i + sum r_i commitment_i - (sum r_i y_i) G
-      rc = msm_var(ctx, s->aff, s->inf, s->scal + n, n, st, Ax);
-      if (rc) break;
-      rc = msm_var(ctx, s->aff, s->inf, s->scal, 2 * n + 1, st, Bx);
+      tt.mark("seed + scalars enqueue");
+      // the two lincombs are independent: A on the side stream, B on the caller's stream
+      hipEvent_t ev = nullptr;
+      if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { rc = fail(KZG_FAIL_HIP, "event create failed"); break; }
+      (void)hipEventRecord(ev, st);
+      (void)hipStreamWaitEvent(ctx->side_stream, ev, 0);
+      (void)hipEventDestroy(ev);
+      MsmVarJob ja, jb;
+      rc = msm_var_launch(ja, s->aff, s->inf, s->scal + n, n, ctx->side_stream);
+      if (rc == 0) rc = msm_var_launch(jb, s->aff, s->inf, s->scal, 2 * n + 1, st);
+      int32_t rca = msm_var_finish(ja, Ax);
+      int32_t rcb = msm_var_finish(jb, Bx);
+      if (rc == 0) rc = rca ? rca : rcb;
+      tt.mark("msm A || msm B (incl. host horner)");
     } while (0);
     (void)hipStreamSynchronize(st);
     (void)hipFree(d_rpow2);
@@ -307,6 +361,7 @@ extern "C" int32_t kzg_verify_phase2_dev(kzg_verify_session* s, const uint8_t* r
     if (rc) return rc;
     host_affine_from_xyzz(A, Ax);
     host_affine_from_xyzz(B, Bx);
+    tt.mark("to affine");
   }
   host_affine_to_be96(out192, A);
   host_affine_to_be96(out192 + 96, B);
@@ -327,9 +382,11 @@ extern "C" int32_t kzg_verify_batch_finish(const kzg_ctx* ctx, const uint8_t* pa
     if (!b.inf) xyzz_madd(B, b.x, b.y);
   }
   host::g1_host_affine a, b;
+  TraceTimer tt("finish");
   host_affine_from_xyzz(a, A);
   host_affine_from_xyzz(b, B);
   *ok = host::verify_pairings_fixed(*ctx->pairing, a, b) ? 1 : 0;
+  tt.mark("pairing");
   return 0;
 }
 

@@ -21,10 +21,10 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define KZG_HD __host__ __device__ __forceinline__
-#define KZG_HD_NOINLINE __host__ __device__ __noinline__
+#define KZG_HD_NOINLINE inline __host__ __device__ __noinline__
 #else
 #define KZG_HD inline __attribute__((always_inline))
-#define KZG_HD_NOINLINE __attribute__((noinline))
+#define KZG_HD_NOINLINE inline __attribute__((noinline))
 #endif
 
 namespace kzg {

@@ -104,7 +104,7 @@ __device__ __forceinline__ void wave_reduce_xyzz(g1_xyzz& acc, g1_xyzz* lds, int
 // big-endian, validated here: Blob::from_slice, src/blob.rs:26-37); otherwise
 // canonical little-endian limbs produced on device (quotient polynomial).
 template <bool BE_BYTES, int OCC>
-__global__ __launch_bounds__(64, OCC) void k_msm_fixed(const uint8_t* __restrict__ scalars, uint32_t splits,
+static __global__ __launch_bounds__(64, OCC) void k_msm_fixed(const uint8_t* __restrict__ scalars, uint32_t splits,
                                                   const uint4* __restrict__ table, MsmGeom g,
                                                   g1_xyzz* __restrict__ partials, int32_t* __restrict__ status) {
   const int lane = threadIdx.x;
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(64, OCC) void k_msm_fixed(const uint8_t* __restrict
 
 // One wave per item: sums the 64 * splits lane partials of k_msm_fixed (6-level tree
 // through LDS) into one XYZZ point per item.
-__global__ __launch_bounds__(64) void k_msm_reduce(const g1_xyzz* __restrict__ partials, uint32_t splits, uint64_t n,
+static __global__ __launch_bounds__(64) void k_msm_reduce(const g1_xyzz* __restrict__ partials, uint32_t splits, uint64_t n,
                                                    g1_xyzz* __restrict__ sums) {
   __shared__ g1_xyzz lds[32];
   const int lane = threadIdx.x;
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(64) void k_msm_reduce(const g1_xyzz* __restrict__ p
 
 // One thread per item: XYZZ -> affine -> 48-byte compressed encoding
 // (K3: blst_p1_compress, src/bls.rs:499).  Items whose status is non-zero get 48 zero bytes.
-__global__ __launch_bounds__(64) void k_g1_compress(const g1_xyzz* __restrict__ sums, uint64_t n, const int32_t* __restrict__ status,
+static __global__ __launch_bounds__(64) void k_g1_compress(const g1_xyzz* __restrict__ sums, uint64_t n, const int32_t* __restrict__ status,
                                                     uint8_t* __restrict__ out48) {
   const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= n) return;

@@ -11,7 +11,7 @@ __device__ __forceinline__ uint32_t bitrev12(uint32_t i) { return __builtin_bitr
 // thread t: decompress + subgroup-check g1_lagrange[t] (file order), store the
 // affine Montgomery point at the bit-reversed index (src/kzg/setup.rs:59-65,
 // src/math.rs:72-74).  status[t] = KZG_ERR_* or 0; infinity -> flagged as 100.
-__global__ __launch_bounds__(64) void k_setup_g1(const uint8_t* __restrict__ in48, uint4* __restrict__ bases_brp, int32_t* __restrict__ status) {
+static __global__ __launch_bounds__(64) void k_setup_g1(const uint8_t* __restrict__ in48, uint4* __restrict__ bases_brp, int32_t* __restrict__ status) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= 4096) return;
   fp_t x, y;
@@ -23,7 +23,7 @@ __global__ __launch_bounds__(64) void k_setup_g1(const uint8_t* __restrict__ in4
 }
 
 // thread i: window bases Q[j][i] = 2^(c*j) * L_i for j = 0..W-1 (affine).
-__global__ __launch_bounds__(64) void k_table_window_bases(const uint4* __restrict__ bases_brp, uint4* __restrict__ win_bases, MsmGeom g) {
+static __global__ __launch_bounds__(64) void k_table_window_bases(const uint4* __restrict__ bases_brp, uint4* __restrict__ win_bases, MsmGeom g) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= 4096) return;
   fp_t x, y;
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(64) void k_table_window_bases(const uint4* __restri
 
 // thread (i) of window j: chain d*Q for d = 1..entries, XYZZ results to tmp
 // (tmp index = i*entries + d-1).
-__global__ __launch_bounds__(64) void k_table_chain(const uint4* __restrict__ win_bases, uint32_t j, uint32_t entries, g1_xyzz* __restrict__ tmp) {
+static __global__ __launch_bounds__(64) void k_table_chain(const uint4* __restrict__ win_bases, uint32_t j, uint32_t entries, g1_xyzz* __restrict__ tmp) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= 4096) return;
   fp_t x, y;
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(64) void k_table_chain(const uint4* __restrict__ wi
 // thread: normalises KN consecutive XYZZ entries with one shared inversion
 // (Montgomery's trick on zz*zzz) and writes affine table entries.
 template <int KN>
-__global__ __launch_bounds__(64) void k_table_normalize(const g1_xyzz* __restrict__ tmp, uint64_t count, uint4* __restrict__ table, uint64_t table_off) {
+static __global__ __launch_bounds__(64) void k_table_normalize(const g1_xyzz* __restrict__ tmp, uint64_t count, uint4* __restrict__ table, uint64_t table_off) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t first = t * KN;
   if (first >= count) return;
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(64) void k_table_normalize(const g1_xyzz* __restric
 
 // roots_of_unity_brp (src/math.rs:16-29 + BRP, src/kzg/setup.rs:74-75), Montgomery form.
 // thread t computes omega^t by square-and-multiply and stores at bitrev12(t).
-__global__ __launch_bounds__(64) void k_setup_roots(fr_t* __restrict__ roots_brp) {
+static __global__ __launch_bounds__(64) void k_setup_roots(fr_t* __restrict__ roots_brp) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= 4096) return;
   fr_t w;

@@ -17,6 +17,15 @@ KZG_HD uint32_t rotr32(uint32_t x, int n) {
 #endif
 }
 
+// a ^ b ^ c in one instruction on gfx950 (v_bitop3_b32, truth table 0x96)
+KZG_HD uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+#else
+  return a ^ b ^ c;
+#endif
+}
+
 KZG_HD void sha256_init(sha256_state& s) {
   s.h[0] = 0x6a09e667u;
   s.h[1] = 0xbb67ae85u;
@@ -55,15 +64,15 @@ KZG_HD void sha256_block(sha256_state& s, const uint32_t* win) {
       wi = w[i];
     } else {
       uint32_t w15 = w[(i - 15) & 15], w2 = w[(i - 2) & 15];
-      uint32_t s0 = rotr32(w15, 7) ^ rotr32(w15, 18) ^ (w15 >> 3);
-      uint32_t s1 = rotr32(w2, 17) ^ rotr32(w2, 19) ^ (w2 >> 10);
+      uint32_t s0 = xor3(rotr32(w15, 7), rotr32(w15, 18), w15 >> 3);
+      uint32_t s1 = xor3(rotr32(w2, 17), rotr32(w2, 19), w2 >> 10);
       wi = w[i & 15] + s0 + w[(i - 7) & 15] + s1;
       w[i & 15] = wi;
     }
-    uint32_t S1 = rotr32(e, 6) ^ rotr32(e, 11) ^ rotr32(e, 25);
+    uint32_t S1 = xor3(rotr32(e, 6), rotr32(e, 11), rotr32(e, 25));
     uint32_t ch = (e & f) ^ (~e & g);
     uint32_t t1 = h + S1 + ch + sha256_k(i) + wi;
-    uint32_t S0 = rotr32(a, 2) ^ rotr32(a, 13) ^ rotr32(a, 22);
+    uint32_t S0 = xor3(rotr32(a, 2), rotr32(a, 13), rotr32(a, 22));
     uint32_t mj = (a & b) ^ (a & c) ^ (b & c);
     uint32_t t2 = S0 + mj;
     h = g;

@@ -15,10 +15,10 @@ namespace kzg {
 // barycentric sum  S = sum_i e_i w_i / (z - w_i)  is accumulated as ONE fraction
 // per lane,  (N, D) <- (N*d_i + e_i*w_i*D, D*d_i),  d_i = z - w_i  (4 Fr mults
 // per element, nothing stored), the 64 lane fractions are merged by a shuffle
-// tree, and the single division per blob happens in k_eval_finish with one
-// blob per lane.  roots_r2[i] = w_i * R^2 (doubly Montgomery) lets the plain
-// blob element be multiplied in directly: mont_mul(e_plain, w_i R^2) = (e w_i) R.
-// Output per blob: N, D (Montgomery), and for an in-domain z the index m.
+// tree.  roots_r2[i] = w_i * R^2 (doubly Montgomery) lets the plain blob element
+// be multiplied in directly: mont_mul(e_plain, w_i R^2) = (e w_i) R.
+// Because prod_i (z - w_i) = z^4096 - 1, the merged denominator cancels the
+// barycentric factor and y = N / 4096: the whole evaluation needs no inversion.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ fr_t shfl_down_fr(const fr_t& a, int delta) {
   fr_t r;
@@ -27,38 +27,69 @@ __device__ __forceinline__ fr_t shfl_down_fr(const fr_t& a, int delta) {
   return r;
 }
 
-__global__ __launch_bounds__(64) void k_eval_frac(const uint8_t* __restrict__ blobs, const fr_t* __restrict__ z_plain,
-                                                  const fr_t* __restrict__ roots_brp, const fr_t* __restrict__ roots_r2,
-                                                  fr_t* __restrict__ num, fr_t* __restrict__ den, int32_t* __restrict__ domain_idx,
-                                                  int32_t* __restrict__ status) {
+static __global__ __launch_bounds__(64) void k_eval_frac(const uint8_t* __restrict__ blobs, const fr_t* __restrict__ z_plain,
+                                                         const fr_t* __restrict__ roots_brp, const fr_t* __restrict__ roots_r2,
+                                                         const fr_t* __restrict__ roots_sq, fr_t* __restrict__ y_plain,
+                                                         int32_t* __restrict__ status) {
+  // Bit-reversed order puts w and -w next to each other (roots_brp[2k+1] = -roots_brp[2k]), so a
+  // PAIR of elements contributes
+  //   e0 w/(z - w) - e1 w/(z + w) = w [ (e0 - e1) z + (e0 + e1) w ] / (z^2 - w^2)
+  // : 3 multiplies for the numerator (the denominator is a subtraction from the precomputed
+  // w^2 table) + 3 for the fraction update = 3 Fr multiplies per element instead of 4.
+  // Montgomery bookkeeping: e0, e1 are plain; mont_mul(plain, X*R) = plain*X (plain), and
+  // mont_mul(plain, X*R^2) = plain*X*R (Montgomery).
   const int lane = threadIdx.x;
   const uint64_t b = blockIdx.x;
   const uint8_t* blob = blobs + b * 131072ull;
-  fr_t z;
+  fr_t z, z2;
   to_mont<FrParams>(z, z_plain[b]);
-  fr_t N, D = fr_one();
+  fr_sqr(z2, z);
+  fr_t N, D = fr_one(), e_dom;
   bn_zero(N);
+  bn_zero(e_dom);
   bool bad = false;
   int dom = -1;
 #pragma unroll 1
-  for (int k = 0; k < 64; k++) {
-    const int i = k * 64 + lane;
+  for (int k = 0; k < 32; k++) {
+    const int pr = k * 64 + lane;  // pair index: elements 2*pr, 2*pr + 1 (64 contiguous bytes)
     uint32_t sc[8];
-    load_scalar_be_(sc, blob + (uint64_t)i * 32u);
-    fr_t e;
+    fr_t e0, e1;
+    load_scalar_be_(sc, blob + (uint64_t)pr * 64u);
 #pragma unroll
-    for (int q = 0; q < 8; q++) e.v[q] = sc[q];
-    if (!fr_is_canonical(e)) {
+    for (int q = 0; q < 8; q++) e0.v[q] = sc[q];
+    load_scalar_be_(sc, blob + (uint64_t)pr * 64u + 32u);
+#pragma unroll
+    for (int q = 0; q < 8; q++) e1.v[q] = sc[q];
+    if (!fr_is_canonical(e0)) {
       bad = true;
-      bn_zero(e);
+      bn_zero(e0);
     }
-    fr_t d, a, t;
-    fr_sub(d, z, roots_brp[i]);
-    if (bn_is_zero(d)) {
-      dom = i;  // z == w_i: the evaluation is e_i itself (poly.rs:14-18); keep the fraction intact
+    if (!fr_is_canonical(e1)) {
+      bad = true;
+      bn_zero(e1);
+    }
+    const fr_t w = roots_brp[2 * pr];
+    fr_t d;
+    fr_sub(d, z2, roots_sq[pr]);  // z^2 - w^2
+    if (bn_is_zero(d)) {          // z == w or z == -w: the evaluation is that element (poly.rs:14-18)
+      fr_t t;
+      fr_sub(t, z, w);
+      if (bn_is_zero(t)) {
+        dom = 2 * pr;
+        e_dom = e0;
+      } else {
+        dom = 2 * pr + 1;
+        e_dom = e1;
+      }
       continue;
     }
-    fr_mul(a, e, roots_r2[i]);  // (e_i w_i) in Montgomery form
+    fr_t sm, df, u, v, a, t;
+    fr_add(sm, e0, e1);
+    fr_sub(df, e0, e1);
+    fr_mul(u, df, z);  // plain (e0 - e1) z
+    fr_mul(v, sm, w);  // plain (e0 + e1) w
+    fr_add(u, u, v);
+    fr_mul(a, u, roots_r2[2 * pr]);  // Montgomery  w [ ... ]
     fr_mul(t, a, D);
     fr_mul(N, N, d);
     fr_add(N, N, t);
@@ -77,51 +108,28 @@ __global__ __launch_bounds__(64) void k_eval_frac(const uint8_t* __restrict__ bl
   int dom_any = dom;
 #pragma unroll
   for (int delta = 32; delta >= 1; delta >>= 1) {
-    const int o = __shfl_down(dom_any, delta, 64);
+    const int o = __shfl_xor(dom_any, delta, 64);
     dom_any = o > dom_any ? o : dom_any;
   }
-  if (lane == 0) {
-    num[b] = N;
-    den[b] = D;
-    domain_idx[b] = dom_any;
-  }
-  if (__any(bad) && lane == 0) atomicOr(&status[b], KZG_ERR_BLOB_INVALID_FIELD_ELEMENT);
-}
-
-// one thread per blob: y = N/D * (z^4096 - 1)/4096, or e_m for an in-domain z
-__global__ __launch_bounds__(64) void k_eval_finish(const uint8_t* __restrict__ blobs, const fr_t* __restrict__ z_plain,
-                                                    const fr_t* __restrict__ num, const fr_t* __restrict__ den,
-                                                    const int32_t* __restrict__ domain_idx, uint64_t n, fr_t* __restrict__ y_plain) {
-  const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= n) return;
-  const int dom = domain_idx[b];
+  // The merged denominator is prod_k (z^2 - w_k^2) = z^4096 - 1 exactly, so
+  //   y = (N / D) * (z^4096 - 1) / 4096 = N / 4096          -- no inversion at all.
   fr_t y;
-  if (dom >= 0) {
-    uint32_t sc[8];
-    load_scalar_be_(sc, blobs + b * 131072ull + (uint64_t)dom * 32u);
+  if (dom_any >= 0) {
+    const int owner = (dom_any >> 1) & 63;  // pair index pr = k*64 + lane
 #pragma unroll
-    for (int q = 0; q < 8; q++) y.v[q] = sc[q];
-    if (!fr_is_canonical(y)) bn_zero(y);
-    y_plain[b] = y;
-    return;
-  }
-  fr_t z, zn, f, di;
-  to_mont<FrParams>(z, z_plain[b]);
-  zn = z;
-  for (int q = 0; q < 12; q++) fr_sqr(zn, zn);
-  fr_sub(zn, zn, fr_one());
-  {
-    const uint32_t c4096[8] = KZG_FR_INV4096_MONT;
+    for (int q = 0; q < 8; q++) y.v[q] = __shfl(e_dom.v[q], owner, 64);  // already plain
+  } else {
+    fr_t f;
+    {
+      const uint32_t c4096[8] = KZG_FR_INV4096_MONT;
 #pragma unroll
-    for (int q = 0; q < 8; q++) f.v[q] = c4096[q];
+      for (int q = 0; q < 8; q++) f.v[q] = c4096[q];
+    }
+    fr_mul(y, N, f);
+    from_mont<FrParams>(y, y);
   }
-  fr_mul(f, f, zn);
-  fr_inv(di, den[b]);
-  fr_mul(y, num[b], di);
-  fr_mul(y, y, f);
-  fr_t yp;
-  from_mont<FrParams>(yp, y);
-  y_plain[b] = yp;
+  if (lane == 0) y_plain[b] = y;
+  if (__any(bad) && lane == 0) atomicOr(&status[b], KZG_ERR_BLOB_INVALID_FIELD_ELEMENT);
 }
 
 // ---------------------------------------------------------------------------
@@ -132,7 +140,7 @@ __global__ __launch_bounds__(64) void k_eval_finish(const uint8_t* __restrict__ 
 // node_g = H(leaf_{256g} .. leaf_{256g+255}), and the host hashes
 // "RCKZGBATCH___V1_" || u128(4096) || u128(n) || node_0 || ... into the seed.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_transcript_leaves(const uint8_t* __restrict__ commitments48, const uint8_t* __restrict__ proofs48,
+static __global__ __launch_bounds__(256) void k_transcript_leaves(const uint8_t* __restrict__ commitments48, const uint8_t* __restrict__ proofs48,
                                                           const fr_t* __restrict__ z_plain, const fr_t* __restrict__ y_plain, uint64_t n,
                                                           uint32_t* __restrict__ leaves /* n x 8 words, big-endian word values */) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -165,7 +173,7 @@ __global__ __launch_bounds__(256) void k_transcript_leaves(const uint8_t* __rest
   for (int q = 0; q < 8; q++) leaves[i * 8 + q] = s.h[q];
 }
 
-__global__ __launch_bounds__(64) void k_transcript_nodes(const uint32_t* __restrict__ leaves, uint64_t n, uint32_t* __restrict__ nodes) {
+static __global__ __launch_bounds__(64) void k_transcript_nodes(const uint32_t* __restrict__ leaves, uint64_t n, uint32_t* __restrict__ nodes) {
   const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t groups = (n + 255) / 256;
   if (g >= groups) return;
@@ -211,7 +219,7 @@ __global__ __launch_bounds__(64) void k_transcript_nodes(const uint32_t* __restr
 //                         sc[i] = r_i            (for commitment_i in B)   -- same array as sa
 //   and the per-thread partial of  s = sum r_i y_i  reduced per block into ysum_blocks.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_batch_scalars(const fr_t* __restrict__ rpow2, const fr_t* __restrict__ z_plain,
+static __global__ __launch_bounds__(256) void k_batch_scalars(const fr_t* __restrict__ rpow2, const fr_t* __restrict__ z_plain,
                                                        const fr_t* __restrict__ y_plain, uint64_t n, uint64_t first_index,
                                                        fr_t* __restrict__ sa, fr_t* __restrict__ sb, fr_t* __restrict__ ysum_blocks) {
   __shared__ fr_t red[256];
@@ -248,7 +256,7 @@ __global__ __launch_bounds__(256) void k_batch_scalars(const fr_t* __restrict__ 
 }
 
 // s = sum of the block partials; writes -s (plain) as the scalar of the generator term
-__global__ __launch_bounds__(256) void k_batch_ysum_finish(const fr_t* __restrict__ ysum_blocks, uint32_t nblocks, fr_t* __restrict__ out_neg_plain) {
+static __global__ __launch_bounds__(256) void k_batch_ysum_finish(const fr_t* __restrict__ ysum_blocks, uint32_t nblocks, fr_t* __restrict__ out_neg_plain) {
   __shared__ fr_t red[256];
   fr_t acc;
   bn_zero(acc);
@@ -279,8 +287,8 @@ __global__ __launch_bounds__(256) void k_batch_ysum_finish(const fr_t* __restric
 //   (host-side exclusive scan is replaced by k_var_scan, one block)
 //   k_var_scatter  : term ids into per-bucket lists
 //   k_var_buckets  : one thread per bucket, complete mixed adds in XYZZ
-//   k_var_segments : per window, segments of SEG buckets: running sums + offset multiple
-//   k_var_windows  : per window, tree-sum of the segment results
+//   k_var_fold     : wave-tree sum of the K partials of each bucket
+//   k_var_windows  : per window, sum_d d*B_d as the sum of all suffix sums (scan + tree in one wave)
 // The W window sums go back to the host, which does the Horner combine
 // (W*c doublings -- a serial chain that one CPU core finishes in < 1 ms).
 // Terms: point index t in [0, nterms), affine points + infinity flags.
@@ -309,7 +317,7 @@ __device__ __forceinline__ void var_digits(const fr_t& s_plain, const VarGeom& g
   }
 }
 
-__global__ __launch_bounds__(256) void k_var_count(const fr_t* __restrict__ scalars, const uint8_t* __restrict__ inf, uint64_t nterms,
+static __global__ __launch_bounds__(256) void k_var_count(const fr_t* __restrict__ scalars, const uint8_t* __restrict__ inf, uint64_t nterms,
                                                    VarGeom g, uint32_t* __restrict__ counts) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= nterms || inf[t]) return;
@@ -317,7 +325,7 @@ __global__ __launch_bounds__(256) void k_var_count(const fr_t* __restrict__ scal
 }
 
 // exclusive scan of `len` counters into offsets (single 1024-thread block, chunked)
-__global__ __launch_bounds__(1024) void k_var_scan(const uint32_t* __restrict__ counts, uint32_t len, uint32_t* __restrict__ offsets,
+static __global__ __launch_bounds__(1024) void k_var_scan(const uint32_t* __restrict__ counts, uint32_t len, uint32_t* __restrict__ offsets,
                                                    uint32_t* __restrict__ cursors) {
   __shared__ uint32_t sh[1024];
   __shared__ uint32_t carry;
@@ -347,7 +355,7 @@ __global__ __launch_bounds__(1024) void k_var_scan(const uint32_t* __restrict__ 
   if (t == 0) offsets[len] = carry;
 }
 
-__global__ __launch_bounds__(256) void k_var_scatter(const fr_t* __restrict__ scalars, const uint8_t* __restrict__ inf, uint64_t nterms,
+static __global__ __launch_bounds__(256) void k_var_scatter(const fr_t* __restrict__ scalars, const uint8_t* __restrict__ inf, uint64_t nterms,
                                                      VarGeom g, uint32_t* __restrict__ cursors, uint32_t* __restrict__ entries) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= nterms || inf[t]) return;
@@ -358,7 +366,7 @@ __global__ __launch_bounds__(256) void k_var_scatter(const fr_t* __restrict__ sc
 }
 
 // thread = (bucket, k of K): entries lo+k, lo+k+K, ... of the bucket's sorted list
-__global__ __launch_bounds__(64, 2) void k_var_buckets(const uint4* __restrict__ points, const uint32_t* __restrict__ offsets,
+static __global__ __launch_bounds__(64, 2) void k_var_buckets(const uint4* __restrict__ points, const uint32_t* __restrict__ offsets,
                                                        const uint32_t* __restrict__ entries, uint32_t nbuckets, uint32_t K,
                                                        g1_xyzz* __restrict__ partial_sums) {
   const uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -378,70 +386,85 @@ __global__ __launch_bounds__(64, 2) void k_var_buckets(const uint4* __restrict__
   partial_sums[id] = acc;
 }
 
-// thread per bucket: sum of its K partials
-__global__ __launch_bounds__(64) void k_var_fold(const g1_xyzz* __restrict__ partial_sums, uint32_t nbuckets, uint32_t K,
-                                                 g1_xyzz* __restrict__ bucket_sums) {
-  const uint32_t bkt = blockIdx.x * blockDim.x + threadIdx.x;
-  if (bkt >= nbuckets) return;
-  g1_xyzz acc = partial_sums[(uint64_t)bkt * K];
-  for (uint32_t k = 1; k < K; k++) {
-    g1_xyzz t = partial_sums[(uint64_t)bkt * K + k];
-    xyzz_add(acc, t);
-  }
-  bucket_sums[bkt] = acc;
-}
-
-// acc = k * p for a small k (k < 2^16), complete
-__device__ __noinline__ void xyzz_mul_small(g1_xyzz& out, const g1_xyzz& p, uint32_t k) {
+// One wave folds the K partial sums of 64/K buckets: K is a power of two <= 64, lanes
+// [g*K, (g+1)*K) hold bucket g's partials and are summed by a segmented tree through LDS.
+static __global__ __launch_bounds__(64) void k_var_fold(const g1_xyzz* __restrict__ partial_sums, uint32_t nbuckets, uint32_t K,
+                                                        g1_xyzz* __restrict__ bucket_sums) {
+  __shared__ g1_xyzz lds[32];
+  const int lane = threadIdx.x;
+  const uint64_t id = (uint64_t)blockIdx.x * 64 + lane;
+  const uint32_t bkt = (uint32_t)(id / K);
   g1_xyzz acc;
-  xyzz_set_inf(acc);
-  for (int bit = 15; bit >= 0; bit--) {
-    xyzz_dbl(acc);
-    if ((k >> bit) & 1u) xyzz_add(acc, p);
+  if (bkt < nbuckets)
+    acc = partial_sums[id];
+  else
+    xyzz_set_inf(acc);
+#pragma unroll 1
+  for (uint32_t step = 1; step < K; step <<= 1) {
+    const uint32_t m = 2 * step - 1;
+    if ((lane & m) == step) lds[lane >> 1] = acc;
+    __syncthreads();
+    if ((lane & m) == 0) {
+      g1_xyzz other = lds[(lane + step) >> 1];
+      g1_xyzz mine = acc;
+      xyzz_add(mine, other);
+      acc = mine;
+    }
+    __syncthreads();
   }
-  out = acc;
+  if ((lane & (K - 1)) == 0 && bkt < nbuckets) bucket_sums[bkt] = acc;
 }
 
-// thread = (window j, segment s): buckets d in (s*SEG, s*SEG + SEG], result
-//   sum_{d in segment} d * B_d = sum (d - s*SEG) B_d + s*SEG * sum B_d
-constexpr uint32_t VAR_SEG = 16;
-__global__ __launch_bounds__(64) void k_var_segments(const g1_xyzz* __restrict__ bucket_sums, VarGeom g, uint32_t segs_per_window,
-                                                     g1_xyzz* __restrict__ seg_sums) {
-  const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
-  if (id >= g.W * segs_per_window) return;
-  const uint32_t j = id / segs_per_window, s = id % segs_per_window;
-  const uint32_t first = s * VAR_SEG;  // bucket index (d-1) of the segment's lowest bucket
-  uint32_t cnt = g.half - first;
-  if (cnt > VAR_SEG) cnt = VAR_SEG;
-  g1_xyzz running, acc;
-  xyzz_set_inf(running);
-  xyzz_set_inf(acc);
-  for (int k = (int)cnt - 1; k >= 0; k--) {
-    g1_xyzz b = bucket_sums[(uint64_t)j * g.half + first + k];
-    xyzz_add(running, b);
-    xyzz_add(acc, running);
-  }
-  if (first) {
-    g1_xyzz off;
-    xyzz_mul_small(off, running, first);
-    xyzz_add(acc, off);
-  }
-  seg_sums[id] = acc;
-}
-
-// one wave per window: sum its segment results
-__global__ __launch_bounds__(64) void k_var_windows(const g1_xyzz* __restrict__ seg_sums, uint32_t segs_per_window, g1_xyzz* __restrict__ window_sums) {
+// One wave per window:  sum_d d * B_d  =  sum over j of the suffix sums  sum_{d >= j} B_d .
+// Lane l owns `per` consecutive buckets; local suffix sums, a 6-step suffix scan of the lane
+// totals across the wave (Hillis-Steele through LDS), then a tree sum of all suffix sums:
+// ~2*per + 13 sequential additions, no scalar multiplications.
+static __global__ __launch_bounds__(64) void k_var_windows(const g1_xyzz* __restrict__ bucket_sums, VarGeom g, g1_xyzz* __restrict__ window_sums) {
+  __shared__ g1_xyzz buf[2][64];
   __shared__ g1_xyzz lds[32];
   const int lane = threadIdx.x;
   const uint32_t j = blockIdx.x;
-  g1_xyzz acc;
-  xyzz_set_inf(acc);
-  for (uint32_t s = lane; s < segs_per_window; s += 64) {
-    g1_xyzz t = seg_sums[(uint64_t)j * segs_per_window + s];
-    xyzz_add(acc, t);
+  const uint32_t per = (g.half + 63) / 64;
+  const g1_xyzz* B = bucket_sums + (uint64_t)j * g.half;
+  // local pass (descending): run = suffix sum within the lane, tot = sum of the lane's suffix sums
+  g1_xyzz run, tot;
+  xyzz_set_inf(run);
+  xyzz_set_inf(tot);
+  uint32_t owned = 0;
+  for (int k = (int)per - 1; k >= 0; k--) {
+    const uint32_t idx = lane * per + k;
+    if (idx < g.half) {
+      g1_xyzz b = B[idx];
+      xyzz_add(run, b);
+      xyzz_add(tot, run);
+      owned++;
+    }
   }
-  wave_reduce_xyzz(acc, lds, lane);
-  if (lane == 0) window_sums[j] = acc;
+  // exclusive suffix scan of `run` over lanes: X_l = sum_{l' > l} run_{l'}
+  int cur = 0;
+  buf[0][lane] = run;
+  __syncthreads();
+#pragma unroll 1
+  for (int off = 1; off < 64; off <<= 1) {
+    g1_xyzz v = buf[cur][lane];
+    if (lane + off < 64) {
+      g1_xyzz o = buf[cur][lane + off];
+      xyzz_add(v, o);
+    }
+    buf[cur ^ 1][lane] = v;
+    __syncthreads();
+    cur ^= 1;
+  }
+  // inclusive suffix sum is buf[cur][lane]; exclusive = that of lane+1
+  g1_xyzz X;
+  if (lane + 1 < 64)
+    X = buf[cur][lane + 1];
+  else
+    xyzz_set_inf(X);
+  // each of the lane's `owned` suffix sums gains X: tot += owned * X  (owned <= per, tiny)
+  for (uint32_t k = 0; k < owned; k++) xyzz_add(tot, X);
+  wave_reduce_xyzz(tot, lds, lane);
+  if (lane == 0) window_sums[j] = tot;
 }
 
 #endif

@@ -400,3 +400,99 @@ def test_asm_multiply_matches_compiler_scheduled_multiply(engine):
     inserts every hazard nop itself: one wave alone (worst case for back-to-back issue) and a full chip."""
     assert engine.selftest_field_mul(64, 20000) == 0
     assert engine.selftest_field_mul(256 * 4 * 64 * 2, 400) == 0
+
+
+# ---------------------------------------------------------------------------
+# further edge cases in the spirit of the consensus-spec-tests categories
+# ---------------------------------------------------------------------------
+def test_kzg_proof_special_points_vs_live_oracle(engine, oracle_setup):
+    """z = 0, 1, r-1, and roots of unity from both halves of the bit-reversed domain"""
+    from oracle.pyref import bls, poly
+    from oracle.pyref import blob as oblob
+
+    blob = synth_blob(11, 0x77)
+    elements = oblob.from_slice(blob)
+    roots = oracle_setup.roots_of_unity_brp
+    for z in (0, 1, R - 1, roots[1], roots[4095], roots[2049]):
+        y, pi = poly.prove(elements, z, oracle_setup)
+        proof, yy = engine.proof(blob, be32(z))
+        assert yy == be32(y) and proof == bls.g1_compress(pi), hex(z)
+        c = engine.blob_to_commitment(blob)
+        assert engine.verify_proof(proof, c, be32(z), yy) is True
+
+
+def test_verify_proof_infinity_and_constant_polynomial(engine):
+    from oracle.pyref import bls
+
+    c_val = 0x1234
+    commitment = bls.g1_compress(bls.g1_mul(bls.G1_GEN, c_val))  # commitment to the constant polynomial c
+    z = be32(0xABCDEF)
+    assert engine.verify_proof(INF48, commitment, z, be32(c_val)) is True
+    assert engine.verify_proof(INF48, commitment, z, be32(c_val + 1)) is False
+    assert engine.verify_proof(INF48, INF48, z, be32(0)) is True  # zero polynomial
+    assert engine.verify_proof(INF48, INF48, z, be32(1)) is False
+    assert engine.verify_proof(GEN48, INF48, z, be32(0)) is False
+
+
+def test_batch_positions_of_invalid_items(engine, golden):
+    import kateth_amd
+
+    blobs, cs, ps = _golden_triplets(golden, 4)
+    for pos in (0, 3):
+        bad = list(ps)
+        bad[pos] = bytes([0xE0]) + bytes(47)
+        with pytest.raises(kateth_amd.KzgError):
+            engine.verify_blob_proof_batch(blobs, cs, bad)
+        badb = list(blobs)
+        bb = bytearray(badb[pos])
+        bb[-32:] = b"\xff" * 32
+        badb[pos] = bytes(bb)
+        with pytest.raises(kateth_amd.KzgError) as e:
+            engine.verify_blob_proof_batch(badb, cs, ps)
+        assert e.value.inner.kind == "InvalidFieldElement"
+    # duplicated items are fine (and still verify)
+    assert engine.verify_blob_proof_batch(blobs + blobs, cs + cs, ps + ps) is True
+
+
+def test_all_max_and_boundary_field_elements(engine, oracle_setup):
+    """blob of all r-1 (the largest valid element): commitment = [-1] * G ; proof/verify round trip"""
+    from oracle.pyref import bls
+
+    blob = be32(R - 1) * 4096
+    c = engine.blob_to_commitment(blob)
+    assert c == bls.g1_compress(bls.g1_neg(bls.G1_GEN))
+    p = engine.blob_proof(blob, c)
+    assert p == INF48  # constant polynomial
+    assert engine.verify_blob_proof(blob, c, p) is True
+
+
+def test_ragged_batch_sizes_agree_with_single_items(engine, torch_cuda):
+    """odd batch sizes (1, 3, 67, 130: different splits-per-blob and tail handling) give, item for item,
+    the same bytes as one big batch; verification accepts every prefix."""
+    torch = torch_cuda
+    n = 130
+    d_blobs = torch.empty(n * 131072, dtype=torch.uint8, device="cuda")
+    engine.synth_blobs_dev(0xFACE, 100, n, d_blobs.data_ptr())
+    d_c = torch.empty(n * 48, dtype=torch.uint8, device="cuda")
+    d_p = torch.empty(n * 48, dtype=torch.uint8, device="cuda")
+    d_st = torch.empty(n, dtype=torch.int32, device="cuda")
+    engine.blob_to_commitment_batch_dev(d_blobs.data_ptr(), n, d_c.data_ptr(), d_st.data_ptr())
+    engine.compute_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), n, d_p.data_ptr(), d_st.data_ptr())
+    torch.cuda.synchronize()
+    assert int(d_st.abs().sum()) == 0
+    c_all, p_all = d_c.cpu().numpy().tobytes(), d_p.cpu().numpy().tobytes()
+    for m in (1, 3, 67):
+        c2 = torch.empty(m * 48, dtype=torch.uint8, device="cuda")
+        p2 = torch.empty(m * 48, dtype=torch.uint8, device="cuda")
+        engine.blob_to_commitment_batch_dev(d_blobs.data_ptr(), m, c2.data_ptr(), d_st.data_ptr())
+        engine.compute_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), m, p2.data_ptr(), d_st.data_ptr())
+        torch.cuda.synchronize()
+        assert c2.cpu().numpy().tobytes() == c_all[: 48 * m]
+        assert p2.cpu().numpy().tobytes() == p_all[: 48 * m]
+        assert engine.verify_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), m) is True
+    assert engine.verify_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n) is True
+    # an offset sub-range (items 60..129) is also a valid batch
+    off = 60
+    assert engine.verify_blob_proof_batch_dev(d_blobs.data_ptr() + off * 131072, d_c.data_ptr() + off * 48, d_p.data_ptr() + off * 48, n - off) is True
+    # mismatched pairing of an otherwise valid proof is rejected
+    assert engine.verify_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr() + 48, n - 1) is False
