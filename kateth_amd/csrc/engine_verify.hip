@@ -30,6 +30,10 @@ struct kzg_verify_session {
   fr_t* z = nullptr;       // [n] plain
   fr_t* y = nullptr;       // [n] plain
   fr_t* scal = nullptr;    // [2n+1] plain: r_i*z_i (n), r_i (n), -sum r_i*y_i
+  uint8_t* msm_a = nullptr;  // scratch of the two lincomb MSMs (carved from buf: no allocation in phase 2)
+  uint8_t* msm_b = nullptr;
+  fr_t* rpow2 = nullptr;     // [64] r^(2^k)
+  fr_t* ysum = nullptr;      // per-block partial sums of r_i*y_i
   bool failed = false;
 };
 
@@ -106,45 +110,69 @@ static bool host_affine_from_be96(host::g1_host_affine& a, const uint8_t* in96) 
 // variable-base MSM over `nterms` device-resident terms, split into an asynchronous launch
 // (kernels + window read-back enqueued on `st`) and a finish (synchronise, Horner on the host)
 // so that independent MSMs can run concurrently on different streams.
-struct MsmVarJob {
+struct MsmVarLayout {
   VarGeom g{};
-  uint8_t* buf = nullptr;
-  std::vector<g1_xyzz> win;
-  hipStream_t st = nullptr;
-  bool active = false;
+  uint32_t nb = 0, K = 1;
+  size_t o_counts = 0, o_offsets = 0, o_cursors = 0, o_entries = 0, o_part = 0, o_bsum = 0, o_win = 0, total = 0;
 };
-
-static int32_t msm_var_launch(MsmVarJob& job, const uint4* d_points, const uint8_t* d_inf, const fr_t* d_scalars, uint64_t nterms, hipStream_t st) {
-  job.active = false;
-  job.st = st;
-  if (nterms == 0) return 0;
-  const VarGeom g = choose_var_geom(nterms);
-  job.g = g;
-  const uint32_t nb = g.W * g.half;
+static MsmVarLayout msm_var_layout(uint64_t nterms) {
+  MsmVarLayout L;
+  if (nterms == 0) return L;
+  L.g = choose_var_geom(nterms);
+  L.nb = L.g.W * L.g.half;
   size_t off = 0;
   auto take = [&](size_t bytes) {
     size_t o = off;
     off = align_up(off + bytes, 256);
     return o;
   };
-  const size_t o_counts = take((size_t)(nb + 1) * 4), o_offsets = take((size_t)(nb + 1) * 4), o_cursors = take((size_t)(nb + 1) * 4);
-  const size_t o_entries = take((size_t)nterms * g.W * 4);
-  // split every bucket over K threads so that a thread chains ~16 additions
-  uint64_t load = nterms / g.half + 1;
-  uint32_t K = 1;  // power of two <= 64 (k_var_fold sums the K partials of a bucket inside one wave)
-  while (K < 64 && (uint64_t)K * 16 < load) K <<= 1;
-  const size_t o_part = take((size_t)nb * K * sizeof(g1_xyzz));
-  const size_t o_bsum = take((size_t)nb * sizeof(g1_xyzz));
-  const size_t o_win = take((size_t)g.W * sizeof(g1_xyzz));
-  HIP_TRY(hipMalloc(&job.buf, off));
+  L.o_counts = take((size_t)(L.nb + 1) * 4);
+  L.o_offsets = take((size_t)(L.nb + 1) * 4);
+  L.o_cursors = take((size_t)(L.nb + 1) * 4);
+  L.o_entries = take((size_t)nterms * L.g.W * 4);
+  // split every bucket over K threads (power of two <= 64) so that a thread chains ~16 additions
+  uint64_t load = nterms / L.g.half + 1;
+  while (L.K < 64 && (uint64_t)L.K * 16 < load) L.K <<= 1;
+  L.o_part = take((size_t)L.nb * L.K * sizeof(g1_xyzz));
+  L.o_bsum = take((size_t)L.nb * sizeof(g1_xyzz));
+  L.o_win = take((size_t)L.g.W * sizeof(g1_xyzz));
+  L.total = off;
+  return L;
+}
+
+struct MsmVarJob {
+  VarGeom g{};
+  uint8_t* buf = nullptr;
+  bool owns_buf = false;
+  std::vector<g1_xyzz> win;
+  hipStream_t st = nullptr;
+  bool active = false;
+};
+
+static int32_t msm_var_launch(MsmVarJob& job, const uint4* d_points, const uint8_t* d_inf, const fr_t* d_scalars, uint64_t nterms, hipStream_t st,
+                              uint8_t* prealloc = nullptr) {
+  job.active = false;
+  job.st = st;
+  if (nterms == 0) return 0;
+  const MsmVarLayout L = msm_var_layout(nterms);
+  const VarGeom g = L.g;
+  job.g = g;
+  const uint32_t nb = L.nb, K = L.K;
+  if (prealloc) {
+    job.buf = prealloc;
+    job.owns_buf = false;
+  } else {
+    HIP_TRY(hipMalloc(&job.buf, L.total));
+    job.owns_buf = true;
+  }
   uint8_t* buf = job.buf;
-  uint32_t* counts = (uint32_t*)(buf + o_counts);
-  uint32_t* offsets = (uint32_t*)(buf + o_offsets);
-  uint32_t* cursors = (uint32_t*)(buf + o_cursors);
-  uint32_t* entries = (uint32_t*)(buf + o_entries);
-  g1_xyzz* bpart = (g1_xyzz*)(buf + o_part);
-  g1_xyzz* bsum = (g1_xyzz*)(buf + o_bsum);
-  g1_xyzz* winsum = (g1_xyzz*)(buf + o_win);
+  uint32_t* counts = (uint32_t*)(buf + L.o_counts);
+  uint32_t* offsets = (uint32_t*)(buf + L.o_offsets);
+  uint32_t* cursors = (uint32_t*)(buf + L.o_cursors);
+  uint32_t* entries = (uint32_t*)(buf + L.o_entries);
+  g1_xyzz* bpart = (g1_xyzz*)(buf + L.o_part);
+  g1_xyzz* bsum = (g1_xyzz*)(buf + L.o_bsum);
+  g1_xyzz* winsum = (g1_xyzz*)(buf + L.o_win);
   job.win.resize(g.W);
   job.active = true;
   HIP_TRY(hipMemsetAsync(counts, 0, (size_t)(nb + 1) * 4, st));
@@ -165,7 +193,7 @@ static int32_t msm_var_finish(MsmVarJob& job, g1_xyzz& result) {
   int32_t rc = 0;
   if (hipStreamSynchronize(job.st) != hipSuccess) rc = fail(KZG_FAIL_HIP, "variable-base MSM synchronize failed");
   if (rc == 0) host_horner(result, job.win, job.g);
-  (void)hipFree(job.buf);
+  if (job.owns_buf) (void)hipFree(job.buf);
   job.buf = nullptr;
   job.active = false;
   return rc;
@@ -177,7 +205,7 @@ static int32_t msm_var(const kzg_ctx* ctx, const uint4* d_points, const uint8_t*
   MsmVarJob job;
   int32_t rc = msm_var_launch(job, d_points, d_inf, d_scalars, nterms, st);
   if (rc) {
-    if (job.buf) (void)hipFree(job.buf);
+    if (job.buf && job.owns_buf) (void)hipFree(job.buf);
     return rc;
   }
   return msm_var_finish(job, result);
@@ -216,7 +244,9 @@ extern "C" int32_t kzg_verify_phase1_dev(const kzg_ctx* ctx, const void* d_blobs
     return o;
   };
   const size_t o_aff = take((2 * n + 1) * 96), o_inf = take(2 * n + 1), o_z = take(n * 32 + 32), o_y = take(n * 32 + 32),
-               o_scal = take((2 * n + 1) * 32), o_stat = take(3 * n * 4 + 4), o_leaves = take(n * 32 + 32), o_nodes = take(groups * 32 + 32);
+               o_scal = take((2 * n + 1) * 32), o_stat = take(3 * n * 4 + 4), o_leaves = take(n * 32 + 32), o_nodes = take(groups * 32 + 32),
+               o_msm_a = take(msm_var_layout(n).total + 256), o_msm_b = take(msm_var_layout(2 * n + 1).total + 256), o_rpow = take(64 * 32),
+               o_ysum = take(((n + 255) / 256 + 1) * 32);
   if (hipMalloc(&s->buf, off) != hipSuccess) {
     delete s;
     return fail(KZG_FAIL_HIP, "hipMalloc(verify session) failed");
@@ -227,6 +257,10 @@ extern "C" int32_t kzg_verify_phase1_dev(const kzg_ctx* ctx, const void* d_blobs
   s->z = (fr_t*)(s->buf + o_z);
   s->y = (fr_t*)(s->buf + o_y);
   s->scal = (fr_t*)(s->buf + o_scal);
+  s->msm_a = s->buf + o_msm_a;
+  s->msm_b = s->buf + o_msm_b;
+  s->rpow2 = (fr_t*)(s->buf + o_rpow);
+  s->ysum = (fr_t*)(s->buf + o_ysum);
   int32_t* stat = (int32_t*)(s->buf + o_stat);
   uint32_t* leaves = (uint32_t*)(s->buf + o_leaves);
   uint32_t* nodes = (uint32_t*)(s->buf + o_nodes);
@@ -327,11 +361,9 @@ extern "C" int32_t kzg_verify_phase2_dev(kzg_verify_session* s, const uint8_t* r
     fr_t rpow2[64];
     rpow2[0] = r;
     for (int k = 1; k < 64; k++) fr_sqr(rpow2[k], rpow2[k - 1]);
-    fr_t* d_rpow2 = nullptr;
-    fr_t* d_ysum = nullptr;
+    fr_t* d_rpow2 = s->rpow2;
+    fr_t* d_ysum = s->ysum;
     const unsigned nblk = blocks_for(n, 256);
-    HIP_TRY(hipMalloc(&d_rpow2, sizeof(rpow2)));
-    HIP_TRY(hipMalloc(&d_ysum, (size_t)nblk * sizeof(fr_t)));
     int32_t rc = 0;
     g1_xyzz Ax, Bx;
     do {
@@ -348,16 +380,14 @@ extern "C" int32_t kzg_verify_phase2_dev(kzg_verify_session* s, const uint8_t* r
       (void)hipStreamWaitEvent(ctx->side_stream, ev, 0);
       (void)hipEventDestroy(ev);
       MsmVarJob ja, jb;
-      rc = msm_var_launch(ja, s->aff, s->inf, s->scal + n, n, ctx->side_stream);
-      if (rc == 0) rc = msm_var_launch(jb, s->aff, s->inf, s->scal, 2 * n + 1, st);
+      rc = msm_var_launch(ja, s->aff, s->inf, s->scal + n, n, ctx->side_stream, s->msm_a);
+      if (rc == 0) rc = msm_var_launch(jb, s->aff, s->inf, s->scal, 2 * n + 1, st, s->msm_b);
       int32_t rca = msm_var_finish(ja, Ax);
       int32_t rcb = msm_var_finish(jb, Bx);
       if (rc == 0) rc = rca ? rca : rcb;
       tt.mark("msm A || msm B (incl. host horner)");
     } while (0);
     (void)hipStreamSynchronize(st);
-    (void)hipFree(d_rpow2);
-    (void)hipFree(d_ysum);
     if (rc) return rc;
     host_affine_from_xyzz(A, Ax);
     host_affine_from_xyzz(B, Bx);

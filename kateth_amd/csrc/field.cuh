@@ -58,6 +58,10 @@ struct FpParams {
     constexpr uint32_t t[N] = KZG_FP_HALF;
     return t[i];
   }
+  KZG_HD static constexpr uint32_t mod2(int i) {
+    constexpr uint32_t t[N] = KZG_FP_MOD2;
+    return t[i];
+  }
 };
 
 struct FrParams {
@@ -82,6 +86,10 @@ struct FrParams {
   }
   KZG_HD static constexpr uint32_t half(int i) {
     constexpr uint32_t t[N] = KZG_FR_HALF;
+    return t[i];
+  }
+  KZG_HD static constexpr uint32_t mod2(int i) {
+    constexpr uint32_t t[N] = KZG_FR_MOD2;
     return t[i];
   }
 };
@@ -298,7 +306,7 @@ KZG_HD void dbl_mod(bn<F::N>& r, const bn<F::N>& a) {
 // host instantiation: the same value representation (little-endian limbs, radix 2^(32N)) viewed
 // as N/2 64-bit limbs, CIOS with unsigned __int128 -- ~3x faster than the 32-bit path on a CPU;
 // only the once-per-call pairing and the tests run here.
-template <class F>
+template <class F, bool LAZY = false>
 inline void mont_mul_host64(bn<F::N>& r, const bn<F::N>& a, const bn<F::N>& b) {
   constexpr int M = F::N / 2;
   typedef unsigned __int128 u128;
@@ -336,14 +344,17 @@ inline void mont_mul_host64(bn<F::N>& r, const bn<F::N>& a, const bn<F::N>& b) {
     tt.v[2 * i] = (uint32_t)t[i];
     tt.v[2 * i + 1] = (uint32_t)(t[i] >> 32);
   }
-  reduce_once<F>(r, tt, (uint32_t)t[M]);
+  if (LAZY)
+    r = tt;  // inputs < 2p and 4p < radix  =>  result < 2p, no final subtraction
+  else
+    reduce_once<F>(r, tt, (uint32_t)t[M]);
 }
 #endif
 
-template <class F>
-KZG_HD void mont_mul(bn<F::N>& r, const bn<F::N>& a, const bn<F::N>& b) {
+template <class F, bool LAZY>
+KZG_HD void mont_mul_core(bn<F::N>& r, const bn<F::N>& a, const bn<F::N>& b) {
 #if !defined(__HIP_DEVICE_COMPILE__)
-  mont_mul_host64<F>(r, a, b);
+  mont_mul_host64<F, LAZY>(r, a, b);
   return;
 #endif
   constexpr int N = F::N;
@@ -392,7 +403,59 @@ KZG_HD void mont_mul(bn<F::N>& r, const bn<F::N>& a, const bn<F::N>& b) {
   bn<N> tt;
   KZG_UNROLL_FULL
   for (int i = 0; i < N; i++) tt.v[i] = t[i];
-  reduce_once<F>(r, tt, carry);
+  if (LAZY) {
+    (void)carry;
+    r = tt;
+  } else {
+    reduce_once<F>(r, tt, carry);
+  }
+}
+
+template <class F>
+KZG_HD void mont_mul(bn<F::N>& r, const bn<F::N>& a, const bn<F::N>& b) {
+  mont_mul_core<F, false>(r, a, b);
+}
+
+// ---- lazy-reduction variants: representatives in [0, 2m) -------------------------------------
+// Valid because 4m < 2^(32N) for both fields (p < 2^381, r < 2^255):  a, b < 2m  =>
+// (a*b + q*m) / 2^(32N) < m (4m / 2^(32N) + 1) < 2m, so the Montgomery product needs no final
+// subtraction; add/sub fold back into [0, 2m) with one conditional +-2m.
+template <class F>
+KZG_HD void mont_mul_lazy(bn<F::N>& r, const bn<F::N>& a, const bn<F::N>& b) {
+  mont_mul_core<F, true>(r, a, b);
+}
+template <class F>
+KZG_HD bn<F::N> modulus2() {
+  bn<F::N> m;
+  KZG_UNROLL_FULL
+  for (int i = 0; i < F::N; i++) m.v[i] = F::mod2(i);
+  return m;
+}
+template <class F>
+KZG_HD void add_lazy(bn<F::N>& r, const bn<F::N>& a, const bn<F::N>& b) {
+  bn<F::N> t, s2;
+  bn_add(t, a, b);  // < 4m: no carry out of the top limb
+  uint32_t borrow = bn_sub(s2, t, modulus2<F>());
+  KZG_UNROLL_FULL
+  for (int i = 0; i < F::N; i++) r.v[i] = borrow ? t.v[i] : s2.v[i];
+}
+template <class F>
+KZG_HD void sub_lazy(bn<F::N>& r, const bn<F::N>& a, const bn<F::N>& b) {
+  bn<F::N> t, u;
+  uint32_t borrow = bn_sub(t, a, b);
+  bn_add(u, t, modulus2<F>());
+  KZG_UNROLL_FULL
+  for (int i = 0; i < F::N; i++) r.v[i] = borrow ? u.v[i] : t.v[i];
+}
+// value in [0, 2m) congruent to 0 ?
+template <class F>
+KZG_HD bool is_zero_lazy(const bn<F::N>& a) {
+  return bn_is_zero(a) || bn_eq(a, modulus<F>());
+}
+// [0, 2m) -> canonical [0, m)
+template <class F>
+KZG_HD void canonicalize(bn<F::N>& a) {
+  reduce_once<F>(a, a, 0);
 }
 
 // Reference Montgomery multiplication in plain C (CIOS, 64-bit temporaries): the

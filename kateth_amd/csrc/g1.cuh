@@ -126,6 +126,48 @@ KZG_HD void xyzz_madd(g1_xyzz& p, const fp_t& x2, const fp_t& y2) {
   fp_mul(p.zzz, p.zzz, ppp);
 }
 
+// p += (x2, y2) with the accumulator kept in LAZY form (coordinates in [0, 2p)); (x2, y2) canonical.
+// Same formulas as xyzz_madd; saves the final conditional subtraction of all ten multiplies.
+// Used only by the fixed-base MSM hot loop; callers canonicalise the accumulator afterwards.
+KZG_HD void xyzz_madd_lazy(g1_xyzz& p, const fp_t& x2, const fp_t& y2) {
+  if (bn_is_zero(p.zz) && bn_is_zero(p.zzz)) {  // identity (only ever set exactly to zero)
+    xyzz_from_affine(p, x2, y2);
+    return;
+  }
+  fp_t u2, s2, pp, ppp, q, r, t;
+  mont_mul_lazy<FpParams>(u2, x2, p.zz);
+  mont_mul_lazy<FpParams>(s2, y2, p.zzz);
+  sub_lazy<FpParams>(u2, u2, p.x);  // P
+  sub_lazy<FpParams>(r, s2, p.y);   // R
+  if (is_zero_lazy<FpParams>(u2)) {  // rare: P == +-Q
+    if (is_zero_lazy<FpParams>(r))
+      xyzz_mdbl_inl(p, x2, y2);
+    else
+      xyzz_set_inf(p);
+    return;
+  }
+  mont_mul_lazy<FpParams>(pp, u2, u2);
+  mont_mul_lazy<FpParams>(ppp, u2, pp);
+  mont_mul_lazy<FpParams>(q, p.x, pp);
+  mont_mul_lazy<FpParams>(t, r, r);
+  sub_lazy<FpParams>(t, t, ppp);
+  sub_lazy<FpParams>(t, t, q);
+  sub_lazy<FpParams>(t, t, q);  // X3
+  sub_lazy<FpParams>(q, q, t);
+  mont_mul_lazy<FpParams>(q, r, q);
+  mont_mul_lazy<FpParams>(s2, p.y, ppp);
+  sub_lazy<FpParams>(p.y, q, s2);
+  p.x = t;
+  mont_mul_lazy<FpParams>(p.zz, p.zz, pp);
+  mont_mul_lazy<FpParams>(p.zzz, p.zzz, ppp);
+}
+KZG_HD void xyzz_canonicalize(g1_xyzz& p) {
+  canonicalize<FpParams>(p.x);
+  canonicalize<FpParams>(p.y);
+  canonicalize<FpParams>(p.zz);
+  canonicalize<FpParams>(p.zzz);
+}
+
 // p += q   (add-2008-s), complete
 KZG_HD_NOINLINE void xyzz_add(g1_xyzz& p, const g1_xyzz& q) {
   if (xyzz_is_inf(q)) return;

@@ -169,9 +169,10 @@ static __global__ __launch_bounds__(64, OCC) void k_msm_fixed(const uint8_t* __r
     }
     if (cvalid) {
       if (cneg) fp_neg(cy, cy);
-      xyzz_madd(acc, cx, cy);
+      xyzz_madd_lazy(acc, cx, cy);  // accumulator coordinates stay in [0, 2p) inside the loop
     }
   }
+  xyzz_canonicalize(acc);
 
   // lane sums go to HBM (12 KB per wave); the cross-lane tree and the encoding run in
   // k_msm_finalize so that this kernel has no calls and no LDS

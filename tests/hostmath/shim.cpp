@@ -208,3 +208,19 @@ extern "C" int32_t hm_g1_subgroup_both(const uint8_t* a48) {  // bit0 = fast tes
   if (g1_uncompress(x, y, inf, a48) != 0) return -1;
   return (g1_in_subgroup(x, y, inf) ? 1 : 0) | (g1_in_subgroup_naive(x, y, inf) ? 2 : 0);
 }
+
+// lazy-reduction mixed add (MSM hot loop) against the canonical one over a chain of points
+extern "C" int32_t hm_g1_sum_lazy(uint8_t* out48, const uint8_t* pts48, int n) {
+  g1_xyzz acc;
+  xyzz_set_inf(acc);
+  for (int i = 0; i < n; i++) {
+    fp_t x, y;
+    bool inf;
+    int32_t st = g1_uncompress(x, y, inf, pts48 + 48 * i);
+    if (st) return st;
+    if (!inf) xyzz_madd_lazy(acc, x, y);
+  }
+  xyzz_canonicalize(acc);
+  g1_compress_xyzz(out48, acc);
+  return 0;
+}

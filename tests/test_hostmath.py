@@ -218,3 +218,22 @@ def test_fast_subgroup_check_agrees_with_definition(hm):
     if t is not None:
         mixed = bls.g1_add(bls.g1_mul(bls.G1_GEN, 12345), t)
         assert hm.hm_g1_subgroup_both(bls.g1_compress(mixed)) == 0
+
+
+def test_lazy_madd_matches_canonical(hm):
+    """the lazy-reduction mixed add of the MSM hot loop (coordinates in [0, 2p)) gives the same point"""
+    rnd = random.Random(21)
+    g = bls.G1_GEN
+    pts = [bls.g1_mul(g, rnd.randrange(1, R)) for _ in range(40)]
+    enc = [bls.g1_compress(p) for p in pts]
+    out = ctypes.create_string_buffer(48)
+    assert hm.hm_g1_sum_lazy(out, b"".join(enc), len(enc)) == 0
+    want = None
+    for p in pts:
+        want = bls.g1_add(want, p)
+    assert out.raw == bls.g1_compress(want)
+    # special cases through the lazy path: P + P, P - P, leading infinity
+    assert hm.hm_g1_sum_lazy(out, enc[0] + enc[0], 2) == 0 and out.raw == bls.g1_compress(bls.g1_mul(pts[0], 2))
+    assert hm.hm_g1_sum_lazy(out, enc[1] + enc[2] + bls.g1_compress(bls.g1_neg(bls.g1_add(pts[1], pts[2]))), 3) == 0 and out.raw == bls.g1_compress(None)
+    assert hm.hm_g1_sum_lazy(out, enc[3] + enc[4] + bls.g1_compress(bls.g1_add(pts[3], pts[4])), 3) == 0
+    assert out.raw == bls.g1_compress(bls.g1_mul(bls.g1_add(pts[3], pts[4]), 2))
