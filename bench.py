@@ -111,6 +111,21 @@ def extra_workloads(torch, setup, dev, stream, d_blobs, d_commitments, n):
     out["verify_blob_kzg_proof_batch"] = {"workload": "batch=%d (blob, commitment, proof) triples resident in HBM, includes the host pairing" % nv,
                                           "blobs_per_s": nv / dt, "ms_per_batch": 1e3 * dt, "result": bool(ok),
                                           "algorithmic_GBps": nv * 131168 / dt / 1e9, "hbm_frac_of_8TBps": nv * 131168 / dt / 8e12}
+    # single-item latencies (BASELINE configs[0] shape: one blob, as benches/kzg.rs:35-43 times them)
+    lat = {}
+    for name, fn in (
+        ("blob_to_kzg_commitment", lambda: setup.blob_to_commitment_batch_dev(d_blobs.data_ptr(), 1, d_commitments.data_ptr(), d_status.data_ptr(), stream)),
+        ("compute_blob_kzg_proof", lambda: setup.compute_blob_proof_batch_dev(d_blobs.data_ptr(), d_commitments.data_ptr(), 1, d_proofs.data_ptr(), d_status.data_ptr(), stream)),
+        ("verify_blob_kzg_proof", lambda: setup.verify_blob_proof_batch_dev(d_blobs.data_ptr(), d_commitments.data_ptr(), d_proofs.data_ptr(), 1, stream)),
+    ):
+        fn()
+        torch.cuda.synchronize()
+        t0 = _t.perf_counter()
+        for _ in range(5):
+            fn()
+            torch.cuda.synchronize()
+        lat[name] = 1e3 * (_t.perf_counter() - t0) / 5
+    out["single_blob_latency_ms"] = lat
     # a corrupted proof must flip the result
     vp[48 * 7:48 * 8] = vp[0:48]
     torch.cuda.synchronize()
@@ -226,7 +241,9 @@ def main():
         },
     }
     if rank == 0:
-        # measured integer-ALU ceiling: dependent Fp Montgomery multiplies, 8 waves/SIMD, whole chip
+        # measured integer-ALU ceiling: dependent Fp Montgomery multiplies (the lazy-reduction multiply of the
+        # hot loop), 8 waves/SIMD, whole chip.  The kernel also does ~7 add/sub per 10 multiplies, so
+        # valu_frac < 1 even at full VALU occupancy.
         lanes = 256 * 4 * 64 * 8
         setup.microbench_fp_mul(lanes, 200)
         prof["fp_mul_peak_per_s"] = lanes * 2000 / (setup.microbench_fp_mul(lanes, 2000) * 1e-3)
