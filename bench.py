@@ -111,6 +111,17 @@ def extra_workloads(torch, setup, dev, stream, d_blobs, d_commitments, n):
     out["verify_blob_kzg_proof_batch"] = {"workload": "batch=%d (blob, commitment, proof) triples resident in HBM, includes the host pairing" % nv,
                                           "blobs_per_s": nv / dt, "ms_per_batch": 1e3 * dt, "result": bool(ok),
                                           "algorithmic_GBps": nv * 131168 / dt / 1e9, "hbm_frac_of_8TBps": nv * 131168 / dt / 8e12}
+    # CPU baseline for the same metric: C port of the reference's verify path on the first 32 triples
+    try:
+        from oracle.cport import binding
+
+        m = min(32, n)
+        hb = d_blobs[: m * BYTES_PER_BLOB].cpu().numpy().tobytes()
+        hc = d_commitments[: m * 48].cpu().numpy().tobytes()
+        hp = d_proofs[: m * 48].cpu().numpy().tobytes()
+        out["verify_blob_kzg_proof_batch"]["cpu_baseline"] = binding.time_verify(os.path.join(ROOT, "tests", "golden", "trusted_setup_4096.json"), hb, hc, hp, m)
+    except Exception as err:  # noqa: BLE001
+        out["verify_blob_kzg_proof_batch"]["cpu_baseline"] = {"value": None, "error": repr(err)}
     # single-item latencies (BASELINE configs[0] shape: one blob, as benches/kzg.rs:35-43 times them)
     lat = {}
     for name, fn in (

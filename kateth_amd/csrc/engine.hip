@@ -130,6 +130,7 @@ extern "C" void kzg_ctx_destroy(kzg_ctx* ctx) {
   if (ctx->d_gen_affine) (void)hipFree(ctx->d_gen_affine);
   delete ctx->pairing;
   if (ctx->ws) (void)hipFree(ctx->ws);
+  if (ctx->ba_scratch) (void)hipFree(ctx->ba_scratch);
   if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
   if (ctx->ws_event) (void)hipEventDestroy(ctx->ws_event);
   for (auto& pr : ctx->prof_events) {
@@ -266,7 +267,7 @@ extern "C" int32_t kzg_ctx_create(const uint8_t* g1_lagrange, const uint8_t* g2_
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cus = (uint32_t)prop.multiProcessorCount;
   memcpy(ctx->g2_tau, g2_monomial + 96, 96);
-  if (const char* e = getenv("KATETH_AMD_MSM_OCC")) ctx->msm_occupancy = (atoi(e) == 3) ? 3 : 2;
+  if (const char* e = getenv("KATETH_AMD_MSM_BATCH_AFFINE")) ctx->msm_batch_affine = atoi(e) != 0;
   int32_t rc = ctx_build(ctx, g1_lagrange, g2_monomial);
   if (rc != 0) {
     std::string keep = g_last_error;

@@ -41,7 +41,10 @@ struct kzg_ctx {
   uint64_t table_bytes = 0;
   uint32_t num_cus = 256;
   hipStream_t side_stream = nullptr;  // non-blocking stream for work that overlaps the caller's stream
-  int msm_occupancy = 2;  // waves per SIMD the MSM kernel is compiled for (KATETH_AMD_MSM_OCC=3: experiment)
+  int msm_occupancy = 2;  // waves per SIMD the MSM kernel is compiled for
+  bool msm_batch_affine = false;  // KATETH_AMD_MSM_BATCH_AFFINE=1: k_msm_fixed_ba (pairs pre-added in affine coordinates)
+  mutable void* ba_scratch = nullptr;
+  mutable size_t ba_scratch_bytes = 0;
   // workspace (grown on demand, guarded by lock)
   mutable std::mutex lock;
   mutable void* ws = nullptr;
@@ -71,8 +74,26 @@ static int32_t msm_pipeline(const kzg_ctx* ctx, const uint8_t* d_scalars, uint64
   int32_t rc = prof_next(ctx, &pe0, &pe1);
   if (rc) return rc;
   if (pe0) HIP_TRY(hipEventRecord(pe0, st));
-  hipLaunchKernelGGL((k_msm_fixed<BE_BYTES, 2>), dim3((unsigned)(n * splits)), dim3(64), 0, st, d_scalars, splits, ctx->d_table, ctx->geom,
-                     partials, d_status);
+  if (ctx->msm_batch_affine) {
+    // scratch: (pairs + 1) suffix products of 48 B per lane
+    const uint32_t T = (4096u / splits / 64u) * ctx->geom.W;
+    const size_t need = (size_t)n * splits * ((T + 1) / 2 + 1) * 64 * sizeof(fp_t);
+    if (ctx->ba_scratch_bytes < need) {
+      if (ctx->ba_scratch) {
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipFree(ctx->ba_scratch));
+        ctx->ba_scratch = nullptr;
+        ctx->ba_scratch_bytes = 0;
+      }
+      HIP_TRY(hipMalloc(&ctx->ba_scratch, need));
+      ctx->ba_scratch_bytes = need;
+    }
+    hipLaunchKernelGGL((k_msm_fixed_ba<BE_BYTES>), dim3((unsigned)(n * splits)), dim3(64), 0, st, d_scalars, splits, ctx->d_table, ctx->geom,
+                       partials, d_status, reinterpret_cast<fp_t*>(ctx->ba_scratch));
+  } else {
+    hipLaunchKernelGGL((k_msm_fixed<BE_BYTES, 2>), dim3((unsigned)(n * splits)), dim3(64), 0, st, d_scalars, splits, ctx->d_table, ctx->geom,
+                       partials, d_status);
+  }
   HIP_TRY(hipGetLastError());
   if (pe1) HIP_TRY(hipEventRecord(pe1, st));
   hipLaunchKernelGGL(k_msm_reduce, dim3((unsigned)n), dim3(64), 0, st, partials, splits, n, sums);

@@ -219,3 +219,173 @@ static __global__ __launch_bounds__(64) void k_g1_compress(const g1_xyzz* __rest
 
 #endif  // __HIPCC__
 }  // namespace kzg
+
+// ---------------------------------------------------------------------------------------------
+// Batch-affine variant of the fixed-base MSM (experimental, selected with KATETH_AMD_MSM_BATCH_AFFINE=1).
+//
+// A lane's table entries are taken in PAIRS and each pair is first added in affine coordinates,
+//   lambda = (y1 - y0)/(x1 - x0),  x3 = lambda^2 - x0 - x1,  y3 = lambda (x0 - x3) - y0,
+// with ONE field inversion per lane for all of its pairs (Montgomery's trick: suffix products of
+// the denominators d_k = x1 - x0 are streamed to an HBM scratch area in a backward pass, the lane
+// inverts their total once, and a forward pass peels off 1/d_k).  An affine pair-sum costs
+// 6 multiplies + 1/512 of an inversion and then enters the XYZZ accumulator with one mixed add
+// (10): 16.9 multiplies per two table entries instead of 20.
+// Digits use Booth recoding (digit j depends only on bits [cj-1, cj+c) of the scalar), which gives
+// the random access the backward pass needs; the signed-digit table is the same.
+// Pairs that are not "regular" (a zero digit, equal x: doubling or cancellation) bypass the batch
+// and go through the complete mixed add directly.
+// ---------------------------------------------------------------------------------------------
+#if defined(__HIPCC__)
+namespace kzg {
+
+// Booth digit j of a 256-bit scalar (8 limbs): returns |d| (0..2^(c-1)) and sign
+__device__ __forceinline__ uint32_t booth_digit(const uint32_t* sc, uint32_t j, uint32_t c, bool& neg) {
+  const int bit = (int)(c * j) - 1;  // lowest bit of the (c+1)-bit group
+  uint32_t v;
+  if (bit < 0) {
+    v = (sc[0] << 1);
+  } else {
+    const uint32_t wi = (uint32_t)bit >> 5, sh = (uint32_t)bit & 31u;
+    uint32_t w0 = 0, w1 = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < 8; q++) {
+      w0 = (q == wi) ? sc[q] : w0;
+      w1 = (q == wi + 1) ? sc[q] : w1;
+    }
+    const uint64_t two = ((uint64_t)w1 << 32) | w0;
+    v = (uint32_t)(two >> sh);
+  }
+  v &= (2u << c) - 1u;
+  const uint32_t top = (v >> c) & 1u;
+  const uint32_t mag = (v + 1u) >> 1;  // raw + carry-in
+  neg = top != 0;
+  return neg ? ((1u << c) - mag) : mag;
+}
+
+template <bool BE_BYTES>
+__global__ __launch_bounds__(64, 2) void k_msm_fixed_ba(const uint8_t* __restrict__ scalars, uint32_t splits, const uint4* __restrict__ table,
+                                                        MsmGeom g, g1_xyzz* __restrict__ partials, int32_t* __restrict__ status,
+                                                        fp_t* __restrict__ scratch) {
+  const int lane = threadIdx.x;
+  const uint64_t unit = blockIdx.x;
+  const uint64_t blob = unit / splits;
+  const uint32_t split = (uint32_t)(unit % splits);
+  const uint32_t pts_per_split = 4096u / splits;
+  const uint32_t per_lane = pts_per_split / 64u;
+  const uint8_t* base = scalars + blob * (uint64_t)KZG_BYTES_PER_BLOB_;
+  const uint32_t T = per_lane * g.W;     // entries of this lane
+  const uint32_t NP = (T + 1) / 2;       // pairs (the last one may be a single)
+  fp_t* my = scratch + (unit * (uint64_t)(NP + 1)) * 64 + lane;  // suffix product of pair k at my[k*64]
+
+  bool bad = false;
+  uint32_t sc[8];
+  uint32_t cur_k = 0xffffffffu;
+  // entry t -> table index (or none); keeps the scalar of point t / W in registers
+  auto entry = [&](uint32_t t, bool& present, bool& neg) -> uint64_t {
+    const uint32_t k = t / g.W, j = t - k * g.W;
+    const uint32_t i = split * pts_per_split + k * 64u + (uint32_t)lane;
+    if (k != cur_k) {
+      load_scalar<BE_BYTES>(sc, base + (uint64_t)i * 32u);
+      if (BE_BYTES) {
+        fr_t v;
+#pragma unroll
+        for (int q = 0; q < 8; q++) v.v[q] = sc[q];
+        if (!fr_is_canonical(v)) {
+          bad = true;
+#pragma unroll
+          for (int q = 0; q < 8; q++) sc[q] = 0;
+        }
+      }
+      cur_k = k;
+    }
+    const uint32_t d = booth_digit(sc, j, g.c, neg);
+    present = d != 0;
+    return present ? table_index(g, j, i, d) : 0;
+  };
+  auto load_x = [&](fp_t& x, uint64_t idx) {
+    const uint4* p = table + idx * 6;
+    uint4 a0 = p[0], a1 = p[1], a2 = p[2];
+    x.v[0] = a0.x; x.v[1] = a0.y; x.v[2] = a0.z; x.v[3] = a0.w;
+    x.v[4] = a1.x; x.v[5] = a1.y; x.v[6] = a1.z; x.v[7] = a1.w;
+    x.v[8] = a2.x; x.v[9] = a2.y; x.v[10] = a2.z; x.v[11] = a2.w;
+  };
+
+  // ---- pass A (backward): suffix products of the regular pairs' denominators ----
+  fp_t suf = fp_one();
+  my[(uint64_t)NP * 64] = suf;
+#pragma unroll 1
+  for (int k = (int)NP - 1; k >= 0; k--) {
+    const uint32_t t0 = 2u * (uint32_t)k, t1 = t0 + 1u;
+    bool p1 = false, n1 = false, p0, n0;
+    uint64_t i1 = 0;
+    if (t1 < T) i1 = entry(t1, p1, n1);
+    const uint64_t i0 = entry(t0, p0, n0);
+    if (p0 && p1) {
+      fp_t x0, x1, d;
+      load_x(x0, i0);
+      load_x(x1, i1);
+      fp_sub(d, x1, x0);
+      if (!bn_is_zero(d)) fp_mul(suf, suf, d);
+    }
+    my[(uint64_t)k * 64] = suf;
+  }
+  // ---- one inversion per lane ----
+  fp_t inv;
+  {
+    fp_t tot = suf;
+    fp_inv(inv, tot);
+  }
+  // ---- pass B (forward): peel off 1/d_k, affine pair sums, accumulate ----
+  g1_xyzz acc;
+  xyzz_set_inf(acc);
+  cur_k = 0xffffffffu;
+#pragma unroll 1
+  for (uint32_t k = 0; k < NP; k++) {
+    const uint32_t t0 = 2u * k, t1 = t0 + 1u;
+    bool p0, n0, p1 = false, n1 = false;
+    const uint64_t i0 = entry(t0, p0, n0);
+    uint64_t i1 = 0;
+    if (t1 < T) i1 = entry(t1, p1, n1);
+    fp_t x0, y0, x1, y1;
+    if (p0) {
+      load_affine96(x0, y0, table, i0);
+      if (n0) fp_neg(y0, y0);
+    }
+    if (p1) {
+      load_affine96(x1, y1, table, i1);
+      if (n1) fp_neg(y1, y1);
+    }
+    bool regular = false;
+    fp_t d;
+    if (p0 && p1) {
+      fp_sub(d, x1, x0);
+      regular = !bn_is_zero(d);
+    }
+    if (regular) {
+      fp_t nxt = my[(uint64_t)(k + 1) * 64];
+      fp_t id, lam, x3, y3, t;
+      fp_mul(id, inv, nxt);   // 1/d_k
+      fp_mul(inv, inv, d);    // inverse of the remaining suffix
+      fp_sub(t, y1, y0);
+      fp_mul(lam, t, id);
+      fp_sqr(x3, lam);
+      fp_sub(x3, x3, x0);
+      fp_sub(x3, x3, x1);
+      fp_sub(t, x0, x3);
+      fp_mul(y3, lam, t);
+      fp_sub(y3, y3, y0);
+      xyzz_madd_lazy(acc, x3, y3);
+    } else {
+      if (p0) xyzz_madd_lazy(acc, x0, y0);
+      if (p1) xyzz_madd_lazy(acc, x1, y1);
+    }
+  }
+  xyzz_canonicalize(acc);
+  partials[unit * 64 + lane] = acc;
+  if (BE_BYTES) {
+    if (__any(bad) && lane == 0) atomicOr(&status[blob], KZG_ERR_BLOB_INVALID_FIELD_ELEMENT);
+  }
+}
+
+}  // namespace kzg
+#endif

@@ -28,6 +28,12 @@ def load():
     lib.cport_time_commitments.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_char_p]
     lib.cport_time_commitments_blob_parallel.restype = ctypes.c_double
     lib.cport_time_commitments_blob_parallel.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_char_p]
+    lib.cport_verify_batch_prepairing.restype = ctypes.c_int
+    lib.cport_verify_batch_prepairing.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int,
+                                                  ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p]
+    lib.cport_time_verify_prepairing.restype = ctypes.c_double
+    lib.cport_time_verify_prepairing.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]
+    lib.cport_sha256.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t]
     return lib
 
 
@@ -62,6 +68,18 @@ class CSetup:
         out = ctypes.create_string_buffer(48 * n)
         secs = self.lib.cport_time_commitments_blob_parallel(self.h, blobs, n, reps, threads, out)
         return secs, out.raw
+
+    def verify_batch_prepairing(self, blobs: bytes, commitments: bytes, proofs: bytes, n: int, batch_inverse: bool = False):
+        """reference-literal verify_blob_proof_batch up to the pairing: (rc, z bytes, y bytes, A48, B48)"""
+        z = ctypes.create_string_buffer(32 * n)
+        y = ctypes.create_string_buffer(32 * n)
+        a = ctypes.create_string_buffer(48)
+        b = ctypes.create_string_buffer(48)
+        rc = self.lib.cport_verify_batch_prepairing(self.h, blobs, commitments, proofs, n, int(batch_inverse), z, y, a, b)
+        return rc, z.raw, y.raw, a.raw, b.raw
+
+    def time_verify_prepairing(self, blobs: bytes, commitments: bytes, proofs: bytes, n: int, batch_inverse: bool = False) -> float:
+        return self.lib.cport_time_verify_prepairing(self.h, blobs, commitments, proofs, n, int(batch_inverse))
 
     def close(self):
         if self.h:
@@ -121,3 +139,25 @@ def time_commitment(lib_unused, setup_path, sample_blobs, seed, gpu_outputs=None
     }
     res["_raw_outputs"] = out_single
     return res
+
+
+def time_verify(setup_path, blobs: bytes, commitments: bytes, proofs: bytes, n: int):
+    """cpu_baseline leg for verify_blob_kzg_proof_batch: the reference's algorithm (sequential blobs, one
+    Euclidean inversion per element, naive lincombs) up to the single pairing, on the first n triples
+    of the benchmark's own inputs; also the labelled batch-inversion variant."""
+    lib = load()
+    cs = CSetup(lib, setup_path, subgroup_checks=False, threads=1)
+    t_ref = cs.time_verify_prepairing(blobs, commitments, proofs, n, False)
+    t_batch = cs.time_verify_prepairing(blobs, commitments, proofs, n, True)
+    cs.close()
+    return {
+        "value": n / t_ref,
+        "unit": "blobs/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": "%d (blob, commitment, proof) triples of the benchmark batch, single thread like the reference's loop (src/kzg/setup.rs:235-242); "
+        "per-element Euclidean inversion: %.2f blobs/s; with batch inversion instead (not what the reference does): %.2f blobs/s; the final pairing (constant per call) is not included"
+        % (n, n / t_ref, n / t_batch),
+        "batch_inverse_variant_value": n / t_batch,
+        "label": "CPU restatement of kateth/blst path (C port) -- not kateth itself",
+    }

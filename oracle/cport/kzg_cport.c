@@ -123,6 +123,33 @@ static void fr_inv(fr* r, const fr* a) {
   for (int i = 254; i >= 0; i--) { fr_mul(&acc, &acc, &acc); if ((e.l[i >> 6] >> (i & 63)) & 1) fr_mul(&acc, &acc, a); }
   *r = acc;
 }
+/* blst_fr_eucl_inverse (src/bls.rs:305) restated as a binary extended Euclid (HAC 14.61 style) on
+   plain integers: the CPU baseline's per-element inversions (src/kzg/poly.rs:26,49) should cost what a
+   Euclidean inverse costs, not what a 255-bit Fermat ladder costs.  Input/output Montgomery. */
+static inline int fr_is_even(const fr* a) { return (a->l[0] & 1) == 0; }
+static inline void fr_shr1(fr* a, u64 top) { for (int i = 0; i < NR - 1; i++) a->l[i] = (a->l[i] >> 1) | (a->l[i + 1] << 63); a->l[NR - 1] = (a->l[NR - 1] >> 1) | (top << 63); }
+static inline int fr_geq_raw(const fr* a, const fr* b) { fr t; return !fr_raw_sub(&t, a, b); }
+static void fr_eucl_inverse(fr* r, const fr* a_mont) {
+  fr a; fr_to_plain(&a, a_mont);
+  if (fr_is_zero(&a)) { memset(r, 0, sizeof *r); return; }
+  fr u = a, v = FR_R, x1 = {{1, 0, 0, 0}}, x2 = {{0, 0, 0, 0}};
+  const fr one = {{1, 0, 0, 0}};
+  while (!fr_eq(&u, &one) && !fr_eq(&v, &one)) {
+    while (fr_is_even(&u)) {
+      fr_shr1(&u, 0);
+      if (fr_is_even(&x1)) fr_shr1(&x1, 0); else { u64 c = fr_raw_add(&x1, &x1, &FR_R); fr_shr1(&x1, c); }
+    }
+    while (fr_is_even(&v)) {
+      fr_shr1(&v, 0);
+      if (fr_is_even(&x2)) fr_shr1(&x2, 0); else { u64 c = fr_raw_add(&x2, &x2, &FR_R); fr_shr1(&x2, c); }
+    }
+    if (fr_geq_raw(&u, &v)) { fr_raw_sub(&u, &u, &v); fr_sub(&x1, &x1, &x2); }
+    else { fr_raw_sub(&v, &v, &u); fr_sub(&x2, &x2, &x1); }
+  }
+  fr res = fr_eq(&u, &one) ? x1 : x2;  /* plain a^-1 */
+  fr_from_plain(r, &res);
+}
+
 /* Fr::from_be_slice (src/bls.rs:130-139): 0 ok, 1 not in field */
 static int fr_from_be_checked(fr* mont, const uint8_t* b) {
   fr p, t; fr_from_be32(&p, b);
@@ -460,6 +487,137 @@ double cport_time_commitments_blob_parallel(const cport_setup* s, const uint8_t*
   clock_gettime(CLOCK_MONOTONIC, &t1);
   return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }
+/* ------------------------------------------------------------- SHA-256 (blst_sha256, src/bls.rs:194) --- */
+static const uint32_t SHA_K[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174,
+    0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967,
+    0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
+    0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+static inline uint32_t ror(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+static void sha256_blocks(uint32_t h[8], const uint8_t* p, size_t nblocks) {
+  for (size_t b = 0; b < nblocks; b++, p += 64) {
+    uint32_t w[64];
+    for (int i = 0; i < 16; i++) w[i] = ((uint32_t)p[4 * i] << 24) | ((uint32_t)p[4 * i + 1] << 16) | ((uint32_t)p[4 * i + 2] << 8) | p[4 * i + 3];
+    for (int i = 16; i < 64; i++) { uint32_t s0 = ror(w[i - 15], 7) ^ ror(w[i - 15], 18) ^ (w[i - 15] >> 3), s1 = ror(w[i - 2], 17) ^ ror(w[i - 2], 19) ^ (w[i - 2] >> 10); w[i] = w[i - 16] + s0 + w[i - 7] + s1; }
+    uint32_t a = h[0], bb = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+    for (int i = 0; i < 64; i++) {
+      uint32_t t1 = hh + (ror(e, 6) ^ ror(e, 11) ^ ror(e, 25)) + ((e & f) ^ (~e & g)) + SHA_K[i] + w[i];
+      uint32_t t2 = (ror(a, 2) ^ ror(a, 13) ^ ror(a, 22)) + ((a & bb) ^ (a & c) ^ (bb & c));
+      hh = g; g = f; f = e; e = d + t1; d = c; c = bb; bb = a; a = t1 + t2;
+    }
+    h[0] += a; h[1] += bb; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+  }
+}
+static void sha256(uint8_t out[32], const uint8_t* msg, size_t len) {
+  uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+  size_t full = len / 64; sha256_blocks(h, msg, full);
+  uint8_t tail[128] = {0}; size_t rem = len - 64 * full; memcpy(tail, msg + 64 * full, rem); tail[rem] = 0x80;
+  size_t nb = (rem + 9 <= 64) ? 1 : 2; u64 bits = (u64)len * 8;
+  for (int i = 0; i < 8; i++) tail[nb * 64 - 1 - i] = (uint8_t)(bits >> (8 * i));
+  sha256_blocks(h, tail, nb);
+  for (int i = 0; i < 8; i++) { out[4 * i] = h[i] >> 24; out[4 * i + 1] = h[i] >> 16; out[4 * i + 2] = h[i] >> 8; out[4 * i + 3] = h[i]; }
+}
+/* Fr::hash_to (src/bls.rs:189-205): digest as big-endian integer, reduced mod r, to Montgomery */
+static void fr_hash_to(fr* out_mont, const uint8_t* msg, size_t len) {
+  uint8_t d[32]; sha256(d, msg, len);
+  fr v, t; fr_from_be32(&v, d);
+  if (!fr_raw_sub(&t, &v, &FR_R)) v = t;
+  if (!fr_raw_sub(&t, &v, &FR_R)) v = t;
+  fr_from_plain(out_mont, &v);
+}
+/* Blob::challenge (src/blob.rs:78-97): re-serialises every element (Fr::to_be_bytes) like the reference */
+static void blob_challenge(fr* z_mont, const fr* elements_mont, const uint8_t* commitment48) {
+  uint8_t* data = (uint8_t*)malloc(32 + 131072 + 48);
+  memcpy(data, "FSBLOBVERIFY_V1_", 16); memset(data + 16, 0, 16); data[30] = 0x10;
+  for (int i = 0; i < 4096; i++) { fr p; fr_to_plain(&p, &elements_mont[i]); fr_to_be32(data + 32 + 32 * i, &p); }
+  memcpy(data + 32 + 131072, commitment48, 48);
+  fr_hash_to(z_mont, data, 32 + 131072 + 48);
+  free(data);
+}
+/* Polynomial::evaluate (src/kzg/poly.rs:10-33): one division (= one Euclidean inversion) per element */
+static void poly_evaluate(fr* y_mont, const fr* e_mont, const fr* z_mont, const cport_setup* s, int batch_inverse) {
+  for (int i = 0; i < 4096; i++) if (fr_eq(z_mont, &s->roots_brp[i])) { *y_mont = e_mont[i]; return; }
+  fr acc; memset(&acc, 0, sizeof acc);
+  if (!batch_inverse) {
+    for (int i = 0; i < 4096; i++) {
+      fr num, den, inv, term; fr_mul(&num, &e_mont[i], &s->roots_brp[i]); fr_sub(&den, z_mont, &s->roots_brp[i]);
+      fr_eucl_inverse(&inv, &den); fr_mul(&term, &num, &inv); fr_add(&acc, &acc, &term);
+    }
+  } else { /* labelled variant: Montgomery batch inversion (not what the reference does) */
+    fr* pre = (fr*)malloc(sizeof(fr) * 4096); fr run = FR_ONE;
+    for (int i = 0; i < 4096; i++) { fr den; fr_sub(&den, z_mont, &s->roots_brp[i]); pre[i] = run; fr_mul(&run, &run, &den); }
+    fr inv; fr_eucl_inverse(&inv, &run);
+    for (int i = 4095; i >= 0; i--) {
+      fr den, di, num, term; fr_sub(&den, z_mont, &s->roots_brp[i]); fr_mul(&di, &inv, &pre[i]); fr_mul(&inv, &inv, &den);
+      fr_mul(&num, &e_mont[i], &s->roots_brp[i]); fr_mul(&term, &num, &di); fr_add(&acc, &acc, &term);
+    }
+    free(pre);
+  }
+  fr zn = *z_mont; for (int k = 0; k < 12; k++) fr_mul(&zn, &zn, &zn);
+  fr_sub(&zn, &zn, &FR_ONE);
+  fr n4096 = {{4096, 0, 0, 0}}, nm, ninv; fr_from_plain(&nm, &n4096); fr_eucl_inverse(&ninv, &nm);
+  fr_mul(&zn, &zn, &ninv); fr_mul(y_mont, &acc, &zn);
+}
+/* Setup::verify_blob_proof_batch up to (not including) the pairing: src/kzg/setup.rs:223-245 and :115-156.
+   Follows the reference literally: r from (domain, 4096, n) only (quirk Q1), rpowers via Fr::pow with the
+   pow(x,0)=x quirk (Q2), three NAIVE lincombs (one 255-bit scalar multiplication per term) and n more for
+   [-y_i]G.  Outputs: z (n x 32 B BE), y (n x 32 B BE), A = proof_lincomb (48 B), B = c_minus_y + proof_z (48 B).
+   Returns 0 or the first error code in the reference's order. */
+static void fr_pow_reference(fr* out, const fr* x, u64 power) { /* src/bls.rs:169-187 */
+  fr o = *x, tmp = FR_ONE;
+  while (power != 1 && power != 0) { if (power & 1) { fr_mul(&tmp, &o, &tmp); power -= 1; } fr_mul(&o, &o, &o); power >>= 1; }
+  fr_mul(out, &o, &tmp);
+}
+int cport_verify_batch_prepairing(const cport_setup* s, const uint8_t* blobs, const uint8_t* commitments48, const uint8_t* proofs48, int n, int batch_inverse,
+                                  uint8_t* z_out, uint8_t* y_out, uint8_t* a48, uint8_t* b48) {
+  fr* el = (fr*)malloc(sizeof(fr) * 4096 * (size_t)n);
+  g1a* cs = (g1a*)malloc(sizeof(g1a) * n); g1a* ps = (g1a*)malloc(sizeof(g1a) * n);
+  fr* zs = (fr*)malloc(sizeof(fr) * n); fr* ys = (fr*)malloc(sizeof(fr) * n);
+  int rc = 0;
+  for (int i = 0; i < n && !rc; i++) rc = blob_from_slice(el + 4096 * (size_t)i, blobs + (size_t)i * 131072);
+  for (int i = 0; i < n && !rc; i++) { rc = g1_uncompress(&cs[i], commitments48 + 48 * i); if (!rc && !g1_in_subgroup(&cs[i])) rc = 5; }
+  for (int i = 0; i < n && !rc; i++) { rc = g1_uncompress(&ps[i], proofs48 + 48 * i); if (!rc && !g1_in_subgroup(&ps[i])) rc = 5; }
+  if (!rc) {
+    for (int i = 0; i < n; i++) {  /* src/kzg/setup.rs:235-242 (sequential) */
+      blob_challenge(&zs[i], el + 4096 * (size_t)i, commitments48 + 48 * i);
+      poly_evaluate(&ys[i], el + 4096 * (size_t)i, &zs[i], s, batch_inverse);
+      fr p; fr_to_plain(&p, &zs[i]); fr_to_be32(z_out + 32 * i, &p); fr_to_plain(&p, &ys[i]); fr_to_be32(y_out + 32 * i, &p);
+    }
+    uint8_t data[48]; memcpy(data, "RCKZGBATCH___V1_", 16); memset(data + 16, 0, 32); data[30] = 0x10;
+    for (int k = 0; k < 8; k++) data[47 - k] = (uint8_t)((u64)n >> (8 * k));
+    fr r; fr_hash_to(&r, data, 48);
+    /* generator */
+    g1a gen; { static const uint8_t G48[48] = {0x97,0xf1,0xd3,0xa7,0x31,0x97,0xd7,0x94,0x26,0x95,0x63,0x8c,0x4f,0xa9,0xac,0x0f,0xc3,0x68,0x8c,0x4f,0x97,0x74,0xb9,0x05,0xa1,0x4e,0x3a,0x3f,0x17,0x1b,0xac,0x58,0x6c,0x55,0xe8,0x3f,0xf9,0x7a,0x1a,0xef,0xfb,0x3a,0xf0,0x0a,0xdb,0x22,0xc6,0xbb}; g1_uncompress(&gen, G48); }
+    g1j negG; { g1a ng = gen; fp_neg(&ng.y, &ng.y); g1j_from_affine(&negG, &ng); }
+    g1j A, Bz, Bc; g1j_set_inf(&A); g1j_set_inf(&Bz); g1j_set_inf(&Bc);
+    for (int i = 0; i < n; i++) {
+      fr rp, zr, rpp, zrp, yp; fr_pow_reference(&rp, &r, (u64)i); fr_mul(&zr, &zs[i], &rp);
+      fr_to_plain(&rpp, &rp); fr_to_plain(&zrp, &zr); fr_to_plain(&yp, &ys[i]);
+      g1j pj, cj, t; g1j_from_affine(&pj, &ps[i]); g1j_from_affine(&cj, &cs[i]);
+      g1j_mul(&t, &pj, &rpp); g1j_add(&A, &A, &t);           /* proof_lincomb        :152 */
+      g1j_mul(&t, &pj, &zrp); g1j_add(&Bz, &Bz, &t);         /* proof_z_lincomb      :153 */
+      g1j cmy; g1j_mul(&t, &negG, &yp); g1j_add(&cmy, &cj, &t); /* C_i + [-y_i]G     :149 */
+      g1j_mul(&t, &cmy, &rpp); g1j_add(&Bc, &Bc, &t);        /* comm_minus_eval_lincomb :155 */
+    }
+    g1j B; g1j_add(&B, &Bc, &Bz);
+    g1a aa, ba; g1j_to_affine(&aa, &A); g1j_to_affine(&ba, &B); g1_compress(a48, &aa); g1_compress(b48, &ba);
+  }
+  free(el); free(cs); free(ps); free(zs); free(ys);
+  return rc;
+}
+double cport_time_verify_prepairing(const cport_setup* s, const uint8_t* blobs, const uint8_t* c48, const uint8_t* p48, int n, int batch_inverse) {
+  struct timespec t0, t1; uint8_t a[48], b[48]; uint8_t* z = (uint8_t*)malloc(32 * (size_t)n); uint8_t* y = (uint8_t*)malloc(32 * (size_t)n);
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  cport_verify_batch_prepairing(s, blobs, c48, p48, n, batch_inverse, z, y, a, b);
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  free(z); free(y);
+  return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}
+void cport_fr_eucl_inv_plain(uint8_t* out32be, const uint8_t* a32be) {
+  init_consts(); fr a, r; fr_from_be32(&a, a32be); fr_from_plain(&a, &a); fr_eucl_inverse(&r, &a); fr_to_plain(&r, &r); fr_to_be32(out32be, &r);
+}
+void cport_sha256(uint8_t* out32, const uint8_t* msg, size_t len) { sha256(out32, msg, len); }
+
 void cport_set_threads(cport_setup* s, int threads) { s->threads = threads > 0 ? threads : 1; }
 
 /* small exported helpers for tests/test_cport.py */

@@ -81,3 +81,43 @@ def test_threaded_equals_single(csetup):
     csetup.set_threads(4)
     _, b = csetup.blob_to_commitment(blob)
     assert a == b
+
+
+def test_verify_prepairing_matches_oracle_and_pairs(lib, csetup, oracle_setup):
+    """the C port's reference-literal verify path: z, y equal the golden vectors; its two lincomb points
+    satisfy the pairing equation (checked with the Python oracle's pairing); a swapped proof does not."""
+    import ctypes as ct
+
+    golden = json.load(open(os.path.join(GOLDEN, "kzg_vectors.json")))
+    recs = golden["blobs"][:3]
+    blobs = b"".join(synth.blob_bytes(golden["seed"], r["index"]) for r in recs)
+    cs = b"".join(bytes.fromhex(r["commitment"]) for r in recs)
+    ps = b"".join(bytes.fromhex(r["proof"]) for r in recs)
+    for batch_inverse in (False, True):
+        rc, z, y, a48, b48 = csetup.verify_batch_prepairing(blobs, cs, ps, 3, batch_inverse)
+        assert rc == 0
+        for k, r in enumerate(recs):
+            assert z[32 * k:32 * k + 32].hex() == r["challenge_z"]
+            assert y[32 * k:32 * k + 32].hex() == r["eval_y"]
+        A, B = bls.g1_decompress(a48), bls.g1_decompress(b48)
+        assert bls.verify_pairings((A, oracle_setup.g2_monomial[1]), (B, bls.G2_GEN))
+    rc, z, y, a48, b48 = csetup.verify_batch_prepairing(blobs, cs, ps[48:96] + ps[:48] + ps[96:], 3, False)
+    assert rc == 0
+    assert not bls.verify_pairings((bls.g1_decompress(a48), oracle_setup.g2_monomial[1]), (bls.g1_decompress(b48), bls.G2_GEN))
+    # errors in the reference's order
+    bad = bytearray(blobs)
+    bad[0:32] = R.to_bytes(32, "big")
+    assert csetup.verify_batch_prepairing(bytes(bad), bytes([cs[0] & 0x7F]) + cs[1:], ps, 3)[0] == 2
+    assert csetup.verify_batch_prepairing(blobs, bytes([cs[0] & 0x7F]) + cs[1:], ps, 3)[0] == 3
+    # primitives
+    out = ct.create_string_buffer(32)
+    rnd = random.Random(8)
+    for x in (1, 2, R - 1, rnd.randrange(R), rnd.randrange(R)):
+        lib.cport_fr_eucl_inv_plain(out, x.to_bytes(32, "big"))
+        assert int.from_bytes(out.raw, "big") == pow(x, -1, R)
+    import hashlib
+
+    for ln in (0, 55, 56, 64, 1000):
+        msg = bytes(rnd.randrange(256) for _ in range(ln))
+        lib.cport_sha256(out, msg, ln)
+        assert out.raw == hashlib.sha256(msg).digest()
