@@ -266,7 +266,6 @@ extern "C" int32_t kzg_ctx_create(const uint8_t* g1_lagrange, const uint8_t* g2_
   }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cus = (uint32_t)prop.multiProcessorCount;
-  memcpy(ctx->g2_tau, g2_monomial + 96, 96);
   if (const char* e = getenv("KATETH_AMD_MSM_BATCH_AFFINE")) ctx->msm_batch_affine = atoi(e) != 0;
   int32_t rc = ctx_build(ctx, g1_lagrange, g2_monomial);
   if (rc != 0) {

@@ -41,7 +41,6 @@ struct kzg_ctx {
   uint64_t table_bytes = 0;
   uint32_t num_cus = 256;
   hipStream_t side_stream = nullptr;  // non-blocking stream for work that overlaps the caller's stream
-  int msm_occupancy = 2;  // waves per SIMD the MSM kernel is compiled for
   bool msm_batch_affine = false;  // KATETH_AMD_MSM_BATCH_AFFINE=1: k_msm_fixed_ba (pairs pre-added in affine coordinates)
   mutable void* ba_scratch = nullptr;
   mutable size_t ba_scratch_bytes = 0;
@@ -54,8 +53,6 @@ struct kzg_ctx {
   mutable bool profiling = false;
   mutable std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
   mutable size_t prof_used = 0;
-  // host copy of what the pairing needs
-  uint8_t g2_tau[96];  // g2_monomial[1] compressed (validated at create)
 };
 
 int32_t ws_reserve(const kzg_ctx* ctx, size_t bytes);

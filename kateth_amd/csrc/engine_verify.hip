@@ -34,7 +34,6 @@ struct kzg_verify_session {
   uint8_t* msm_b = nullptr;
   fr_t* rpow2 = nullptr;     // [64] r^(2^k)
   fr_t* ysum = nullptr;      // per-block partial sums of r_i*y_i
-  bool failed = false;
 };
 
 extern "C" void kzg_verify_session_destroy(kzg_verify_session* s) {
@@ -323,7 +322,6 @@ extern "C" int32_t kzg_verify_phase1_dev(const kzg_ctx* ctx, const void* d_blobs
   scan_first_error(h_stat.data(), n, &err6[0], &err6[1]);
   scan_first_error(h_stat.data() + n, n, &err6[2], &err6[3]);
   scan_first_error(h_stat.data() + 2 * n, n, &err6[4], &err6[5]);
-  s->failed = (err6[0] >= 0 || err6[2] >= 0 || err6[4] >= 0);
   // local transcript root = SHA-256 over the node digests (big-endian bytes)
   std::vector<uint8_t> nb(groups * 32);
   for (uint64_t k = 0; k < groups * 8; k++) store_be32(nb.data() + 4 * k, h_nodes[k]);

@@ -120,18 +120,6 @@ KZG_HD void mac(acc96& A, uint32_t a, uint32_t b) {
 #endif
 }
 
-// A += a*k with k a compile-time constant kept in an SGPR
-KZG_HD void mac_k(acc96& A, uint32_t a, uint32_t k) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
-      : "+v"(A.lo), "+v"(A.hi)
-      : "v"(a), "s"(k)
-      : "vcc");
-#else
-  mac(A, a, k);
-#endif
-}
-
 KZG_HD void acc_shift(acc96& A) {
   A.lo = (A.lo >> 32) | ((uint64_t)A.hi << 32);
   A.hi = 0;

@@ -19,8 +19,8 @@
 // consecutive addresses -> coalesced), recodes each scalar into signed base-2^c
 // digits in registers, prefetches the next table entry while the current
 // mixed add runs, and keeps its partial sum in 48 VGPRs (XYZZ).  The 64 lane
-// sums are combined by a 6-level tree through LDS; partials of a blob are
-// summed and compressed by k_msm_finalize.
+// sums go to HBM; k_msm_reduce combines them by a 6-level tree through LDS and
+// k_g1_compress emits the 48-byte encodings.
 #pragma once
 #include "g1.cuh"
 

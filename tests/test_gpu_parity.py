@@ -496,3 +496,26 @@ def test_ragged_batch_sizes_agree_with_single_items(engine, torch_cuda):
     assert engine.verify_blob_proof_batch_dev(d_blobs.data_ptr() + off * 131072, d_c.data_ptr() + off * 48, d_p.data_ptr() + off * 48, n - off) is True
     # mismatched pairing of an otherwise valid proof is rejected
     assert engine.verify_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr() + 48, n - 1) is False
+
+
+def test_batch_affine_msm_variant_is_bit_exact(golden, monkeypatch):
+    """the experimental batch-affine fixed-base MSM (KATETH_AMD_MSM_BATCH_AFFINE=1: Booth digits, pairs
+    pre-added in affine coordinates with one inversion per lane) must produce the same bytes"""
+    import kateth_amd
+
+    monkeypatch.setenv("KATETH_AMD_MSM_BATCH_AFFINE", "1")
+    s = kateth_amd.Setup.load_json(TRUSTED_SETUP, window_bits=7)  # odd window count exercises the unpaired tail
+    try:
+        recs = golden["blobs"][:3]
+        blobs = b"".join(synth_blob(r["index"]) for r in recs) + be32(1) * 4096 + bytes(131072) + be32(R - 1) * 4096
+        out, status = s.blob_to_commitment_batch(blobs)
+        assert status == [0] * 6
+        for k, r in enumerate(recs):
+            assert out[48 * k:48 * k + 48].hex() == r["commitment"]
+        assert out[144:192] == GEN48 and out[192:240] == INF48
+        proofs, st = s.compute_blob_proof_batch(blobs[: 3 * 131072], b"".join(bytes.fromhex(r["commitment"]) for r in recs))
+        assert st == [0, 0, 0]
+        for k, r in enumerate(recs):
+            assert proofs[48 * k:48 * k + 48].hex() == r["proof"]
+    finally:
+        s.close()
