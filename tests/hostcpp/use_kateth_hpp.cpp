@@ -1,0 +1,37 @@
+// Compile-and-link check of the C++ host mirror (kateth_amd/host/kateth.hpp) against the C ABI.
+// On a machine without a GPU it must fail loudly with KZG_FAIL_NO_DEVICE; with one it runs a tiny round trip.
+#include <cstdio>
+#include <vector>
+
+#include "../../kateth_amd/host/kateth.hpp"
+
+int main(int argc, char** argv) {
+  std::vector<uint8_t> g1(4096 * 48), g2(65 * 96);
+  if (argc >= 3) {  // raw setup bytes supplied by the test
+    FILE* f = fopen(argv[1], "rb");
+    if (!f || fread(g1.data(), 1, g1.size(), f) != g1.size()) return 10;
+    fclose(f);
+    f = fopen(argv[2], "rb");
+    if (!f || fread(g2.data(), 1, g2.size(), f) != g2.size()) return 11;
+    fclose(f);
+  }
+  try {
+    auto setup = kateth::Setup<4096, 65>::load(g1.data(), g2.data(), 0, 8);
+    std::vector<uint8_t> blob(kateth::Setup<>::BLOB_BYTES, 0);
+    for (size_t i = 0; i < 4096; i++) blob[32 * i + 31] = 1;  // all-ones blob -> commitment = G1 generator
+    kateth::Bytes48 c = setup.blob_to_commitment(blob.data(), blob.size());
+    kateth::Bytes48 p = setup.blob_proof(blob.data(), blob.size(), c);
+    bool ok = setup.verify_blob_proof(blob.data(), blob.size(), c, p);
+    std::printf("commitment[0]=%02x proof[0]=%02x verify=%d\n", c[0], p[0], (int)ok);
+    try {
+      setup.blob_to_commitment(blob.data(), blob.size() - 1);
+      return 3;
+    } catch (const kateth::Error& e) {
+      if (e.kind != kateth::ErrorKind::BlobInvalidLen) return 4;
+    }
+    return (ok && c[0] == 0x97 && p[0] == 0xc0) ? 0 : 2;
+  } catch (const kateth::EngineFailure& e) {
+    std::printf("engine failure %d: %s\n", e.code, e.what());
+    return e.code == KZG_FAIL_NO_DEVICE ? 42 : 5;
+  }
+}

@@ -94,3 +94,40 @@ def test_load_setup_errors_mirror_reference(tmp_path):
     p.write_text(json.dumps({"g1_lagrange": raw["g1_lagrange"], "g2_monomial": raw["g2_monomial"][:3]}))
     with pytest.raises(kateth_amd.LoadSetupError, match="InvalidLenG2Monomial"):  # src/kzg/setup.rs:55-57
         kateth_amd.Setup.load_json(str(p))
+
+
+def _build_cpp_example(tmp_path):
+    from kateth_amd import kzg
+
+    exe = str(tmp_path / "use_kateth_hpp")
+    src = os.path.join(ROOT, "tests", "hostcpp", "use_kateth_hpp.cpp")
+    hip = "/opt/rocm/lib/libamdhip64.so"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", src, "-o", exe, kzg.library_path(), hip, "-Wl,-rpath," + os.path.dirname(kzg.library_path()), "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def test_cpp_host_mirror_links_and_fails_loudly_without_gpu(lib, tmp_path):
+    """kateth_amd/host/kateth.hpp (the compiled-language mirror of kateth's Setup API) compiles, links
+    against the C ABI + the system HIP runtime, and -- with no GPU -- reports KZG_FAIL_NO_DEVICE."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present (covered by the gpu test)")
+    exe = _build_cpp_example(tmp_path)
+    rc = subprocess.call([exe])
+    assert rc == 42
+
+
+@pytest.mark.gpu
+def test_cpp_host_mirror_round_trip_on_gpu(tmp_path):
+    import json
+
+    raw = json.load(open(os.path.join(ROOT, "tests", "golden", "trusted_setup_4096.json")))
+    g1 = tmp_path / "g1.bin"
+    g2 = tmp_path / "g2.bin"
+    g1.write_bytes(b"".join(bytes.fromhex(s[2:]) for s in raw["g1_lagrange"]))
+    g2.write_bytes(b"".join(bytes.fromhex(s[2:]) for s in raw["g2_monomial"]))
+    exe = _build_cpp_example(tmp_path)
+    out = subprocess.run([exe, str(g1), str(g2)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "verify=1" in out.stdout
