@@ -311,23 +311,47 @@ __global__ __launch_bounds__(64, 2) void k_msm_fixed_ba(const uint8_t* __restric
   };
 
   // ---- pass A (backward): suffix products of the regular pairs' denominators ----
+  // The pass is one multiply per gathered pair, so the gathers are issued two pairs ahead
+  // (x-coordinates only, 2 x 24 VGPRs) to keep their latency off the critical path.
   fp_t suf = fp_one();
   my[(uint64_t)NP * 64] = suf;
-#pragma unroll 1
-  for (int k = (int)NP - 1; k >= 0; k--) {
+  fp_t ax0[2], ax1[2];
+  bool aboth[2] = {false, false};
+  auto fetch_a = [&](int k, int slot) {
+    aboth[slot] = false;
+    if (k < 0) return;
     const uint32_t t0 = 2u * (uint32_t)k, t1 = t0 + 1u;
     bool p1 = false, n1 = false, p0, n0;
     uint64_t i1 = 0;
     if (t1 < T) i1 = entry(t1, p1, n1);
     const uint64_t i0 = entry(t0, p0, n0);
     if (p0 && p1) {
-      fp_t x0, x1, d;
-      load_x(x0, i0);
-      load_x(x1, i1);
-      fp_sub(d, x1, x0);
+      load_x(ax0[slot], i0);
+      load_x(ax1[slot], i1);
+      aboth[slot] = true;
+    }
+  };
+  fetch_a((int)NP - 1, 0);
+  fetch_a((int)NP - 2, 1);
+#pragma unroll 1
+  for (int k = (int)NP - 1; k >= 0; k -= 2) {
+    // slot 0 holds pair k, slot 1 pair k-1 (static slots: the loop body handles two pairs)
+    if (aboth[0]) {
+      fp_t d;
+      fp_sub(d, ax1[0], ax0[0]);
       if (!bn_is_zero(d)) fp_mul(suf, suf, d);
     }
     my[(uint64_t)k * 64] = suf;
+    fetch_a(k - 2, 0);
+    if (k - 1 >= 0) {
+      if (aboth[1]) {
+        fp_t d;
+        fp_sub(d, ax1[1], ax0[1]);
+        if (!bn_is_zero(d)) fp_mul(suf, suf, d);
+      }
+      my[(uint64_t)(k - 1) * 64] = suf;
+      fetch_a(k - 3, 1);
+    }
   }
   // ---- one inversion per lane ----
   fp_t inv;
@@ -341,20 +365,20 @@ __global__ __launch_bounds__(64, 2) void k_msm_fixed_ba(const uint8_t* __restric
   cur_k = 0xffffffffu;
 #pragma unroll 1
   for (uint32_t k = 0; k < NP; k++) {
+    // no register prefetch here: the forward pass is multiply-bound (17 multiplies per pair) and already at
+    // the 256-VGPR budget of two waves per SIMD -- a one-pair-ahead prefetch spilled (432 B scratch) and
+    // cost 10 %; the second wave of the SIMD covers the gather latency instead.
     const uint32_t t0 = 2u * k, t1 = t0 + 1u;
     bool p0, n0, p1 = false, n1 = false;
     const uint64_t i0 = entry(t0, p0, n0);
     uint64_t i1 = 0;
     if (t1 < T) i1 = entry(t1, p1, n1);
-    fp_t x0, y0, x1, y1;
-    if (p0) {
-      load_affine96(x0, y0, table, i0);
-      if (n0) fp_neg(y0, y0);
-    }
-    if (p1) {
-      load_affine96(x1, y1, table, i1);
-      if (n1) fp_neg(y1, y1);
-    }
+    fp_t x0, y0, x1, y1, nxt;
+    if (p0) load_affine96(x0, y0, table, i0);
+    if (p1) load_affine96(x1, y1, table, i1);
+    nxt = my[(uint64_t)(k + 1) * 64];
+    if (p0 && n0) fp_neg(y0, y0);
+    if (p1 && n1) fp_neg(y1, y1);
     bool regular = false;
     fp_t d;
     if (p0 && p1) {
@@ -362,7 +386,6 @@ __global__ __launch_bounds__(64, 2) void k_msm_fixed_ba(const uint8_t* __restric
       regular = !bn_is_zero(d);
     }
     if (regular) {
-      fp_t nxt = my[(uint64_t)(k + 1) * 64];
       fp_t id, lam, x3, y3, t;
       fp_mul(id, inv, nxt);   // 1/d_k
       fp_mul(inv, inv, d);    // inverse of the remaining suffix
