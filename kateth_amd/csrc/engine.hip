@@ -130,7 +130,6 @@ extern "C" void kzg_ctx_destroy(kzg_ctx* ctx) {
   if (ctx->d_gen_affine) (void)hipFree(ctx->d_gen_affine);
   delete ctx->pairing;
   if (ctx->ws) (void)hipFree(ctx->ws);
-  if (ctx->ba_scratch) (void)hipFree(ctx->ba_scratch);
   if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
   if (ctx->ws_event) (void)hipEventDestroy(ctx->ws_event);
   for (auto& pr : ctx->prof_events) {
@@ -236,7 +235,7 @@ static int32_t ctx_build(kzg_ctx* ctx, const uint8_t* g1_lagrange, const uint8_t
     constexpr int KN = 8;
     const uint64_t threads = (count + KN - 1) / KN;
     hipLaunchKernelGGL(k_table_normalize<KN>, dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, st, d_tmp, count, ctx->d_table,
-                       table_index(g, j, 0, 1));
+                       table_index(g, j, 0, 1), ctx->msm_radix28);
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipDeviceSynchronize());
@@ -266,7 +265,7 @@ extern "C" int32_t kzg_ctx_create(const uint8_t* g1_lagrange, const uint8_t* g2_
   }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cus = (uint32_t)prop.multiProcessorCount;
-  if (const char* e = getenv("KATETH_AMD_MSM_BATCH_AFFINE")) ctx->msm_batch_affine = atoi(e) != 0;
+  if (const char* e = getenv("KATETH_AMD_MSM_RADIX")) ctx->msm_radix28 = atoi(e) != 32;
   int32_t rc = ctx_build(ctx, g1_lagrange, g2_monomial);
   if (rc != 0) {
     std::string keep = g_last_error;

@@ -41,9 +41,9 @@ struct kzg_ctx {
   uint64_t table_bytes = 0;
   uint32_t num_cus = 256;
   hipStream_t side_stream = nullptr;  // non-blocking stream for work that overlaps the caller's stream
-  bool msm_batch_affine = false;  // KATETH_AMD_MSM_BATCH_AFFINE=1: k_msm_fixed_ba (pairs pre-added in affine coordinates)
-  mutable void* ba_scratch = nullptr;
-  mutable size_t ba_scratch_bytes = 0;
+  // true (default): table in 2^392-Montgomery form, k_msm_fixed28 (radix-2^28 limbs, fp28.cuh);
+  // KATETH_AMD_MSM_RADIX=32 at context creation: 2^384-Montgomery table, k_msm_fixed (12 x 32-bit limbs)
+  bool msm_radix28 = true;
   // workspace (grown on demand, guarded by lock)
   mutable std::mutex lock;
   mutable void* ws = nullptr;
@@ -71,26 +71,12 @@ static int32_t msm_pipeline(const kzg_ctx* ctx, const uint8_t* d_scalars, uint64
   int32_t rc = prof_next(ctx, &pe0, &pe1);
   if (rc) return rc;
   if (pe0) HIP_TRY(hipEventRecord(pe0, st));
-  if (ctx->msm_batch_affine) {
-    // scratch: (pairs + 1) suffix products of 48 B per lane
-    const uint32_t T = (4096u / splits / 64u) * ctx->geom.W;
-    const size_t need = (size_t)n * splits * ((T + 1) / 2 + 1) * 64 * sizeof(fp_t);
-    if (ctx->ba_scratch_bytes < need) {
-      if (ctx->ba_scratch) {
-        HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipFree(ctx->ba_scratch));
-        ctx->ba_scratch = nullptr;
-        ctx->ba_scratch_bytes = 0;
-      }
-      HIP_TRY(hipMalloc(&ctx->ba_scratch, need));
-      ctx->ba_scratch_bytes = need;
-    }
-    hipLaunchKernelGGL((k_msm_fixed_ba<BE_BYTES>), dim3((unsigned)(n * splits)), dim3(64), 0, st, d_scalars, splits, ctx->d_table, ctx->geom,
-                       partials, d_status, reinterpret_cast<fp_t*>(ctx->ba_scratch));
-  } else {
+  if (ctx->msm_radix28)
+    hipLaunchKernelGGL((k_msm_fixed28<BE_BYTES>), dim3((unsigned)(n * splits)), dim3(64), 0, st, d_scalars, splits, ctx->d_table, ctx->geom,
+                       partials, d_status);
+  else
     hipLaunchKernelGGL((k_msm_fixed<BE_BYTES, 2>), dim3((unsigned)(n * splits)), dim3(64), 0, st, d_scalars, splits, ctx->d_table, ctx->geom,
                        partials, d_status);
-  }
   HIP_TRY(hipGetLastError());
   if (pe1) HIP_TRY(hipEventRecord(pe1, st));
   hipLaunchKernelGGL(k_msm_reduce, dim3((unsigned)n), dim3(64), 0, st, partials, splits, n, sums);

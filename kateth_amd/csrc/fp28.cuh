@@ -1,0 +1,414 @@
+// Fp of BLS12-381 in a carry-free radix-2^28 representation, for the fixed-base MSM hot loop only.
+//
+// Why a second representation: on gfx950 the only wide integer multiply is v_mad_u64_u32
+// (32x32 + 64 -> 64, full rate).  With saturated 32-bit limbs (field.cuh) the 64-bit column
+// accumulator overflows after one product, so every product needs a second instruction
+// (v_addc_co_u32 into a third word): 2 x 288 VALU instructions per Montgomery product, plus the
+// VCC wait states hipcc adds around carry chains.  With 14 limbs of 28 bits a column of
+// 14 + 14 products (each < 2^58 or so) fits one 64-bit accumulator: 392 v_mad_u64_u32 and NO carry
+// instruction, squarings do 105 instead of 196 products, and additions/subtractions are 14
+// independent 32-bit operations with no carry chain at all (limbs are allowed to grow, bounds are
+// tracked statically in the comments below and re-checked at run time in the CPU build by
+// KZG_FP28_CHECK, tests/test_hostmath.py).
+//
+// Value = sum l[i] * 2^(28 i).  Montgomery radix 2^392.  "N-form" = output of a Montgomery product:
+// limbs 0..12 < 2^28, value < 2p.  Replaces blst_fp arithmetic behind blst_p1s_mult_pippenger
+// (src/bls.rs:416-437) together with field.cuh.
+#pragma once
+#include "g1.cuh"
+
+namespace kzg {
+
+constexpr int F28_N = 14;
+constexpr int F28_W = 28;
+constexpr uint32_t F28_MASK = (1u << F28_W) - 1u;
+
+struct fp28 {
+  uint32_t l[F28_N];
+};
+
+#define KZG_F28_TABLE(fn, MACRO)                 \
+  KZG_HD constexpr uint32_t fn(int i) {          \
+    constexpr uint32_t t[F28_N] = MACRO;         \
+    return t[i];                                 \
+  }
+KZG_F28_TABLE(f28_p, KZG_FP28_MOD)
+KZG_F28_TABLE(f28_one_limb, KZG_FP28_ONE)
+KZG_F28_TABLE(f28_r384_limb, KZG_FP28_R384)
+KZG_F28_TABLE(f28_2p_t1, KZG_FP28_2P_T1)
+KZG_F28_TABLE(f28_4p_t1, KZG_FP28_4P_T1)
+KZG_F28_TABLE(f28_16p_t1, KZG_FP28_16P_T1)
+KZG_F28_TABLE(f28_8p_t3, KZG_FP28_8P_T3)
+#undef KZG_F28_TABLE
+
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(KZG_FP28_CHECK)
+// CPU test build: every column sum is also formed in 128 bits and every limb subtraction is
+// checked, so a violated bound aborts the test instead of silently wrapping.
+extern "C" void kzg_fp28_check_failed(const char* what);
+struct f28_col {
+  unsigned __int128 wide;
+  uint64_t v;
+};
+#define F28_COL_INIT(A) \
+  f28_col A { 0, 0 }
+#define F28_MAC(A, x, y)                                            \
+  do {                                                              \
+    (A).wide += (unsigned __int128)(uint32_t)(x) * (uint32_t)(y);   \
+    (A).v += (uint64_t)(uint32_t)(x) * (uint32_t)(y);               \
+    if ((A).wide >> 64) kzg_fp28_check_failed("column overflow");   \
+  } while (0)
+#define F28_LO(A) ((uint32_t)(A).v)
+#define F28_SHIFT(A)      \
+  do {                    \
+    (A).v >>= F28_W;      \
+    (A).wide = (A).v;     \
+  } while (0)
+#define F28_SUBCHK(a, m, b)                                                              \
+  do {                                                                                   \
+    if ((uint64_t)(a) + (uint64_t)(m) < (uint64_t)(b)) kzg_fp28_check_failed("limb underflow"); \
+    if ((uint64_t)(a) + (uint64_t)(m) - (uint64_t)(b) >> 32) kzg_fp28_check_failed("limb overflow"); \
+  } while (0)
+#define F28_ADDCHK(a, b)                                                          \
+  do {                                                                            \
+    if (((uint64_t)(a) + (uint64_t)(b)) >> 32) kzg_fp28_check_failed("limb overflow"); \
+  } while (0)
+#else
+#define F28_COL_INIT(A) uint64_t A = 0
+#define F28_MAC(A, x, y) (A) += (uint64_t)(uint32_t)(x) * (uint32_t)(y)
+#define F28_LO(A) ((uint32_t)(A))
+#define F28_SHIFT(A) (A) >>= F28_W
+#define F28_SUBCHK(a, m, b) \
+  do {                      \
+  } while (0)
+#define F28_ADDCHK(a, b) \
+  do {                   \
+  } while (0)
+#endif
+
+// ---- representation changes ---------------------------------------------------------------------
+// 12 x 32-bit limbs (value < 2^384) -> 14 x 28-bit limbs, strictly normalised
+KZG_HD void f28_from_bn(fp28& r, const fp_t& a) {
+  KZG_UNROLL_FULL
+  for (int i = 0; i < F28_N; i++) {
+    const int bit = F28_W * i, w = bit >> 5, s = bit & 31;
+    const uint32_t lo = a.v[w];
+    const uint32_t hi = (w + 1 < 12) ? a.v[w + 1] : 0u;
+    const uint64_t two = ((uint64_t)hi << 32) | lo;
+    r.l[i] = (uint32_t)(two >> s) & F28_MASK;
+  }
+}
+// strictly normalised limbs (all < 2^28) and value < 2^384 -> 12 x 32-bit limbs
+KZG_HD void f28_to_bn(fp_t& r, const fp28& a) {
+  KZG_UNROLL_FULL
+  for (int w = 0; w < 12; w++) {
+    const int bit = 32 * w, i = bit / F28_W, s = bit % F28_W;
+    uint64_t v = (uint64_t)a.l[i] >> s;
+    if (i + 1 < F28_N) v |= (uint64_t)a.l[i + 1] << (F28_W - s);
+    if (i + 2 < F28_N && 2 * F28_W - s < 32) v |= (uint64_t)a.l[i + 2] << (2 * F28_W - s);
+    r.v[w] = (uint32_t)v;
+  }
+}
+
+// one carry pass, all limbs at once (no serial chain): limbs 0..12 end up <= 2^28 - 1 + (max limb >> 28)
+KZG_HD void f28_carry_pass(fp28& a) {
+  uint32_t hi[F28_N];
+  KZG_UNROLL_FULL
+  for (int i = 0; i < F28_N - 1; i++) hi[i] = a.l[i] >> F28_W;
+  KZG_UNROLL_FULL
+  for (int i = F28_N - 1; i >= 1; i--) {
+    const uint32_t lo = (i < F28_N - 1) ? (a.l[i] & F28_MASK) : a.l[i];
+    F28_ADDCHK(lo, hi[i - 1]);
+    a.l[i] = lo + hi[i - 1];
+  }
+  a.l[0] &= F28_MASK;
+}
+// full (serial) carry propagation: limbs 0..12 < 2^28 exactly
+KZG_HD void f28_normalize(fp28& a) {
+  uint32_t c = 0;
+  KZG_UNROLL_FULL
+  for (int i = 0; i < F28_N - 1; i++) {
+    F28_ADDCHK(a.l[i], c);
+    const uint32_t t = a.l[i] + c;
+    a.l[i] = t & F28_MASK;
+    c = t >> F28_W;
+  }
+  F28_ADDCHK(a.l[F28_N - 1], c);
+  a.l[F28_N - 1] += c;
+}
+
+// ---- Montgomery products ------------------------------------------------------------------------
+// r = (a*b [+ c*d]) / 2^392 mod p, N-form.  Requires 14*(La*Lb [+ Lc*Ld]) + 14*2^56 < 2^64 for the limb
+// bounds L, and (Va*Vb [+ Vc*Vd]) < 2^11 for the value bounds V in units of p (so the result is < 2p).
+template <bool SQR, bool TWO>
+KZG_HD void f28_mul_core(fp28& r, const fp28& a, const fp28& b, const fp28& c, const fp28& d) {
+  uint32_t q[F28_N];
+  uint32_t a2[F28_N];
+  if (SQR) {
+    KZG_UNROLL_FULL
+    for (int i = 0; i < F28_N; i++) {
+      F28_ADDCHK(a.l[i], a.l[i]);
+      a2[i] = a.l[i] << 1;
+    }
+  }
+  F28_COL_INIT(A);
+  KZG_UNROLL_FULL
+  for (int k = 0; k < 2 * F28_N; k++) {
+    const int i0 = (k < F28_N) ? 0 : k - F28_N + 1;
+    const int i1 = (k < F28_N) ? k : F28_N - 1;
+    if (SQR) {
+      KZG_UNROLL_FULL
+      for (int i = i0; i <= i1; i++) {
+        const int j = k - i;
+        if (i < j) F28_MAC(A, a2[i], a.l[j]);
+        if (i == j) F28_MAC(A, a.l[i], a.l[i]);
+      }
+    } else {
+      KZG_UNROLL_FULL
+      for (int i = i0; i <= i1; i++) F28_MAC(A, a.l[i], b.l[k - i]);
+    }
+    if (TWO) {
+      KZG_UNROLL_FULL
+      for (int i = i0; i <= i1; i++) F28_MAC(A, c.l[i], d.l[k - i]);
+    }
+    if (k < F28_N) {
+      KZG_UNROLL_FULL
+      for (int i = 0; i < k; i++) F28_MAC(A, q[i], f28_p(k - i));
+      q[k] = (F28_LO(A) * (uint32_t)KZG_FP28_INV) & F28_MASK;
+      F28_MAC(A, q[k], f28_p(0));
+      F28_SHIFT(A);
+    } else {
+      KZG_UNROLL_FULL
+      for (int i = i0; i <= i1; i++) F28_MAC(A, q[i], f28_p(k - i));
+      if (k < 2 * F28_N - 1) {
+        r.l[k - F28_N] = F28_LO(A) & F28_MASK;  // r may alias an operand: limb k-14 of every operand was last read in column k-1
+        F28_SHIFT(A);
+      } else {
+        r.l[F28_N - 1] = F28_LO(A);  // value < 2p: the top limb is small, nothing above it
+      }
+    }
+  }
+}
+KZG_HD void f28_mul(fp28& r, const fp28& a, const fp28& b) { f28_mul_core<false, false>(r, a, b, a, b); }
+KZG_HD void f28_sqr(fp28& r, const fp28& a) { f28_mul_core<true, false>(r, a, a, a, a); }
+// r = (a*b + c*d) / 2^392: two products, ONE reduction
+KZG_HD void f28_mul2(fp28& r, const fp28& a, const fp28& b, const fp28& c, const fp28& d) { f28_mul_core<false, true>(r, a, b, c, d); }
+
+// ---- carry-free add / subtract ------------------------------------------------------------------
+KZG_HD void f28_add(fp28& r, const fp28& a, const fp28& b) {
+  KZG_UNROLL_FULL
+  for (int i = 0; i < F28_N; i++) {
+    F28_ADDCHK(a.l[i], b.l[i]);
+    r.l[i] = a.l[i] + b.l[i];
+  }
+}
+// r = a + KP - b limb-wise, KP a redundant multiple of p (see tools/gen_consts.py) that dominates b's limbs
+#define KZG_F28_SUB(name, KP)                                             \
+  KZG_HD void name(fp28& r, const fp28& a, const fp28& b) {               \
+    KZG_UNROLL_FULL                                                       \
+    for (int i = 0; i < F28_N; i++) {                                     \
+      F28_SUBCHK(a.l[i], KP(i), b.l[i]);                                  \
+      r.l[i] = a.l[i] + KP(i) - b.l[i];                                   \
+    }                                                                     \
+  }
+KZG_F28_SUB(f28_sub_4p, f28_4p_t1)    // b: N-form
+KZG_F28_SUB(f28_sub_16p, f28_16p_t1)  // b: limbs <= 2^28 + 16, value < 10p
+KZG_F28_SUB(f28_sub_8p3, f28_8p_t3)   // b: limbs <= 3 (2^28 - 1), value < 6p
+#undef KZG_F28_SUB
+// r = KP - b
+KZG_HD void f28_neg_2p(fp28& r, const fp28& b) {  // b canonical (< p, strictly normalised)
+  KZG_UNROLL_FULL
+  for (int i = 0; i < F28_N; i++) {
+    F28_SUBCHK(0u, f28_2p_t1(i), b.l[i]);
+    r.l[i] = f28_2p_t1(i) - b.l[i];
+  }
+}
+KZG_HD void f28_neg_4p(fp28& r, const fp28& b) {  // b N-form
+  KZG_UNROLL_FULL
+  for (int i = 0; i < F28_N; i++) {
+    F28_SUBCHK(0u, f28_4p_t1(i), b.l[i]);
+    r.l[i] = f28_4p_t1(i) - b.l[i];
+  }
+}
+
+KZG_HD fp28 f28_one() {
+  fp28 r;
+  KZG_UNROLL_FULL
+  for (int i = 0; i < F28_N; i++) r.l[i] = f28_one_limb(i);
+  return r;
+}
+
+// Cheap necessary condition for a == 0 (mod p) when 0 <= a < 2^11 p: a = k p with k < 2^11, and the low
+// 28 bits of a are exact whatever the carries, so k = a.l[0] * p^-1 mod 2^28 must be < 2^11.
+// False positives: 2^-17 of all inputs; the caller then runs f28_is_zero_exact.
+KZG_HD bool f28_maybe_zero(const fp28& a) { return ((a.l[0] * (uint32_t)KZG_FP28_PINV) & F28_MASK) < 2048u; }
+// exact: one Montgomery product by ONE brings a into N-form, where 0 (mod p) is exactly {0, p}
+KZG_HD bool f28_is_zero_exact(const fp28& a) {
+  fp28 t;
+  f28_mul(t, a, f28_one());
+  uint32_t z = 0, e = 0;
+  KZG_UNROLL_FULL
+  for (int i = 0; i < F28_N; i++) {
+    z |= t.l[i];
+    e |= t.l[i] ^ f28_p(i);
+  }
+  return z == 0 || e == 0;
+}
+
+// ---- 2^392-Montgomery <-> 2^384-Montgomery (field.cuh) ------------------------------------------------
+// x*2^392 (any bounded fp28 value) -> canonical x*2^384 in 12 x 32 limbs
+KZG_HD void f28_to_fp(fp_t& r, const fp28& a) {
+  fp28 k, t;
+  KZG_UNROLL_FULL
+  for (int i = 0; i < F28_N; i++) k.l[i] = f28_r384_limb(i);
+  f28_mul(t, a, k);  // a * 2^384 / 2^392 = x * 2^384, N-form (< 2p < 2^382)
+  f28_to_bn(r, t);
+  canonicalize<FpParams>(r);
+}
+// canonical x*2^384 -> canonical x*2^392 as 12 x 32 limbs (the table format read by k_msm_fixed28)
+KZG_HD void fp_to_r392(fp_t& r, const fp_t& a) {
+  fp_t k;
+  constexpr uint32_t t[12] = KZG_FP_R392_PLAIN;
+  KZG_UNROLL_FULL
+  for (int i = 0; i < 12; i++) k.v[i] = t[i];
+  fp_mul(r, a, k);
+}
+
+// ---- XYZZ accumulator in fp28 ---------------------------------------------------------------------
+// Invariant between additions:  x: limbs <= 2^28 + 16, value < 10p;  y, zz, zzz: N-form.
+struct g1_xyzz28 {
+  fp28 x, y, zz, zzz;
+  uint32_t inf;
+};
+
+KZG_HD void xyzz28_set_inf(g1_xyzz28& p) {
+  KZG_UNROLL_FULL
+  for (int i = 0; i < F28_N; i++) p.x.l[i] = p.y.l[i] = p.zz.l[i] = p.zzz.l[i] = 0;
+  p.inf = 1;
+}
+
+// p = 2 * (x, y), (x, y) finite; x canonical, y = +-y limbs < 2^29 value <= 2p   (mdbl-2008-s-1, a = 0)
+KZG_HD void xyzz28_mdbl(g1_xyzz28& p, const fp28& x, const fp28& y) {
+  if (f28_is_zero_exact(y)) {  // order-2 point: not on this curve's subgroup, handled for completeness
+    xyzz28_set_inf(p);
+    return;
+  }
+  fp28 u, v, w, s, m, t;
+  f28_add(u, y, y);  // limbs < 2^30, value <= 4p
+  f28_sqr(v, u);
+  f28_mul(w, u, v);
+  f28_mul(s, x, v);
+  f28_sqr(m, x);
+  f28_add(t, m, m);
+  f28_add(m, m, t);  // 3x^2: limbs < 3*2^28, value < 6p
+  fp28 x3;
+  f28_sqr(x3, m);
+  f28_add(t, s, s);  // limbs < 2^29, value < 4p
+  f28_sub_8p3(x3, x3, t);  // value < 10p, limbs < 5*2^28
+  f28_carry_pass(x3);
+  f28_sub_16p(t, s, x3);  // S - X3: limbs < 3*2^28, value < 18p
+  fp28 ny;
+  f28_neg_4p(ny, w);  // we need M*(S-X3) - W*y: second product enters with -W
+  f28_mul2(p.y, m, t, ny, y);
+  p.x = x3;
+  p.zz = v;
+  p.zzz = w;
+  p.inf = 0;
+}
+
+// p += (x2, y2) for a FINITE accumulator p and the generic case; x2 canonical; y2 either canonical or
+// 2p - canonical (limbs < 2^29, value <= 2p).  Returns false -- with p untouched -- when x2 * ZZ1 == X1 (mod p)
+// may hold (P + P or P + (-P): about 2^-17 of all calls are false alarms); the caller then runs
+// xyzz28_madd_complete.  The split keeps the operands of the rare doubling out of the hot path's live registers.
+// madd-2008-s with Y3 = (R (Q - X3) + (4p - Y1) PPP) / 2^392 as ONE reduction: 7 products + 2 squarings +
+// 1 double product, no carry chains anywhere.  Statement order keeps at most seven field elements live.
+KZG_HD bool xyzz28_madd_fast(g1_xyzz28& p, const fp28& x2, const fp28& y2) {
+  fp28 u2, r, pp, ppp;
+  f28_mul(u2, x2, p.zz);      // U2: 14 * 2^56
+  f28_mul(r, y2, p.zzz);      // S2: 14 * 2^57
+  f28_sub_16p(u2, u2, p.x);   // P = U2 - X1: limbs < 3*2^28, value < 18p
+  if (f28_maybe_zero(u2)) return false;
+  f28_sub_4p(r, r, p.y);      // R = S2 - Y1: limbs < 3*2^28, value < 6p
+  f28_sqr(pp, u2);            // PP: 14 * 9 * 2^56
+  f28_mul(ppp, u2, pp);       // PPP
+  f28_mul(p.zz, p.zz, pp);    // ZZ3
+  f28_mul(p.zzz, p.zzz, ppp); // ZZZ3
+  f28_mul(pp, p.x, pp);       // Q = X1 * PP (X1 and PP are dead from here)
+  f28_sqr(p.x, r);            // R^2
+  KZG_UNROLL_FULL
+  for (int i = 0; i < F28_N; i++) {
+    const uint32_t s = ppp.l[i] + 2u * pp.l[i];  // PPP + 2Q: limbs <= 3 (2^28 - 1), value < 6p
+    F28_SUBCHK(p.x.l[i], f28_8p_t3(i), s);
+    p.x.l[i] = p.x.l[i] + f28_8p_t3(i) - s;      // X3 = R^2 - PPP - 2Q: limbs < 5*2^28, value < 10p
+  }
+  f28_carry_pass(p.x);        // limbs <= 2^28 + 3
+  f28_sub_16p(pp, pp, p.x);   // Q - X3: limbs < 3*2^28, value < 18p
+  f28_neg_4p(p.y, p.y);       // 4p - Y1: limbs < 2^29, value <= 4p
+  f28_mul2(p.y, r, pp, p.y, ppp);  // Y3: 14 * (9 + 2) * 2^56 ; (6*18 + 4*2) p^2 / 2^392 < p/16
+  return true;
+}
+
+// Complete addition (identity, P + P, P + (-P), and the generic case): the out-of-line companion of
+// xyzz28_madd_fast.  Same operand conventions.
+KZG_HD_NOINLINE void xyzz28_madd_complete(g1_xyzz28& p, const fp28& x2, const fp28& y2) {
+  if (p.inf) {
+    const fp28 one = f28_one();
+    p.x = x2;
+    f28_mul(p.y, y2, one);  // brings a negated y (limbs < 2^29) into N-form
+    p.zz = one;
+    p.zzz = one;
+    p.inf = 0;
+    return;
+  }
+  if (xyzz28_madd_fast(p, x2, y2)) return;
+  fp28 u2, r;
+  f28_mul(u2, x2, p.zz);
+  f28_mul(r, y2, p.zzz);
+  f28_sub_16p(u2, u2, p.x);
+  f28_sub_4p(r, r, p.y);
+  if (f28_is_zero_exact(u2)) {
+    if (f28_is_zero_exact(r))
+      xyzz28_mdbl(p, x2, y2);
+    else
+      xyzz28_set_inf(p);
+    return;
+  }
+  // false alarm of the cheap test: the generic formulas apply
+  fp28 pp, ppp;
+  f28_sqr(pp, u2);
+  f28_mul(ppp, u2, pp);
+  f28_mul(p.zz, p.zz, pp);
+  f28_mul(p.zzz, p.zzz, ppp);
+  f28_mul(pp, p.x, pp);
+  f28_sqr(p.x, r);
+  KZG_UNROLL_FULL
+  for (int i = 0; i < F28_N; i++) {
+    const uint32_t s = ppp.l[i] + 2u * pp.l[i];
+    F28_SUBCHK(p.x.l[i], f28_8p_t3(i), s);
+    p.x.l[i] = p.x.l[i] + f28_8p_t3(i) - s;
+  }
+  f28_carry_pass(p.x);
+  f28_sub_16p(pp, pp, p.x);
+  f28_neg_4p(p.y, p.y);
+  f28_mul2(p.y, r, pp, p.y, ppp);
+}
+
+// accumulator -> the 12 x 32-limb XYZZ format of g1.cuh (2^384 Montgomery, canonical)
+KZG_HD void xyzz28_to_xyzz(g1_xyzz& r, const g1_xyzz28& p) {
+  if (p.inf) {
+    xyzz_set_inf(r);
+    return;
+  }
+  f28_to_fp(r.x, p.x);
+  f28_to_fp(r.y, p.y);
+  f28_to_fp(r.zz, p.zz);
+  f28_to_fp(r.zzz, p.zzz);
+}
+// table entry (canonical x*2^392, y*2^392 as 12 x 32 limbs) -> operands of xyzz28_madd
+KZG_HD void f28_load_entry(fp28& x, fp28& y, const fp_t& rx, const fp_t& ry, bool neg) {
+  f28_from_bn(x, rx);
+  fp28 t;
+  f28_from_bn(t, ry);
+  KZG_UNROLL_FULL
+  for (int i = 0; i < F28_N; i++) y.l[i] = neg ? (f28_2p_t1(i) - t.l[i]) : t.l[i];
+}
+}  // namespace kzg

@@ -22,7 +22,7 @@
 // sums go to HBM; k_msm_reduce combines them by a 6-level tree through LDS and
 // k_g1_compress emits the 48-byte encodings.
 #pragma once
-#include "g1.cuh"
+#include "fp28.cuh"
 
 namespace kzg {
 
@@ -182,6 +182,101 @@ static __global__ __launch_bounds__(64, OCC) void k_msm_fixed(const uint8_t* __r
   }
 }
 
+
+// The same walk with the accumulator in the carry-free radix-2^28 representation (fp28.cuh): 392 v_mad_u64_u32
+// and no carry instruction per Montgomery product, 9 reductions per mixed add.  The table must hold 2^392-Montgomery
+// coordinates (kzg_ctx::msm_radix28).  The generic add runs inline; the first add of a lane (identity accumulator)
+// and the ~2^-17 of adds whose cheap "P == +-Q?" test fires go through the out-of-line complete adder on a COPY of
+// the accumulator (taking the accumulator's own address would move it to scratch for the whole loop) and re-read the
+// table entry, so the hot path keeps neither the raw entry nor the doubling's operands alive.
+template <bool BE_BYTES>
+static __global__ __launch_bounds__(64, 2) void k_msm_fixed28(const uint8_t* __restrict__ scalars, uint32_t splits,
+                                                              const uint4* __restrict__ table, MsmGeom g,
+                                                              g1_xyzz* __restrict__ partials, int32_t* __restrict__ status) {
+  const int lane = threadIdx.x;
+  const uint64_t unit = blockIdx.x;
+  const uint64_t blob = unit / splits;
+  const uint32_t split = (uint32_t)(unit % splits);
+  const uint32_t pts_per_split = 4096u / splits;
+  const uint32_t per_lane = pts_per_split / 64u;
+  const uint32_t mask = (1u << g.c) - 1u;
+  const uint8_t* base = scalars + blob * (uint64_t)KZG_BYTES_PER_BLOB_;
+
+  g1_xyzz28 acc;
+  xyzz28_set_inf(acc);
+  bool bad = false;
+
+  uint32_t sc[8];
+  uint32_t carry = 0, j = g.W, k = 0, i = 0;
+  fp_t nx, ny;
+  bn_zero(nx);
+  bn_zero(ny);
+  bool nvalid = false, nneg = false;
+  uint64_t nidx = 0;
+  const uint32_t total = per_lane * g.W;
+
+#pragma unroll 1
+  for (uint32_t t = 0; t <= total; t++) {
+    fp28 cx, cy;
+    f28_load_entry(cx, cy, nx, ny, nneg);
+    const bool cvalid = nvalid, cneg = nneg;
+    const uint64_t cidx = nidx;
+    nvalid = false;
+    if (t < total) {
+      if (j == g.W) {  // next scalar
+        i = split * pts_per_split + k * 64u + (uint32_t)lane;
+        load_scalar<BE_BYTES>(sc, base + (uint64_t)i * 32u);
+        if (BE_BYTES) {
+          fr_t v;
+#pragma unroll
+          for (int q = 0; q < 8; q++) v.v[q] = sc[q];
+          if (!fr_is_canonical(v)) {
+            bad = true;
+#pragma unroll
+            for (int q = 0; q < 8; q++) sc[q] = 0;
+          }
+        }
+        carry = 0;
+        j = 0;
+        k++;
+      }
+      uint32_t u = (sc[0] & mask) + carry;
+#pragma unroll
+      for (int q = 0; q < 7; q++) sc[q] = (sc[q] >> g.c) | (sc[q + 1] << (32u - g.c));
+      sc[7] >>= g.c;
+      const bool neg = u > g.half;
+      const uint32_t d = neg ? ((1u << g.c) - u) : u;
+      carry = neg ? 1u : 0u;
+      if (d != 0) {
+        nidx = table_index(g, j, i, d);
+        load_affine96(nx, ny, table, nidx);
+        nvalid = true;
+        nneg = neg;
+      }
+      j++;
+    }
+    if (cvalid) {
+      bool done = false;
+      if (!acc.inf) done = xyzz28_madd_fast(acc, cx, cy);
+      if (!done) {
+        g1_xyzz28 tmp = acc;
+        fp_t rx, ry;
+        load_affine96(rx, ry, table, cidx);
+        fp28 sx, sy;  // separate objects: the call takes their address
+        f28_load_entry(sx, sy, rx, ry, cneg);
+        xyzz28_madd_complete(tmp, sx, sy);
+        acc = tmp;
+      }
+    }
+  }
+  g1_xyzz out;
+  xyzz28_to_xyzz(out, acc);  // back to canonical 2^384-Montgomery limbs for k_msm_reduce
+  partials[unit * 64 + lane] = out;
+  if (BE_BYTES) {
+    if (__any(bad) && lane == 0) atomicOr(&status[blob], KZG_ERR_BLOB_INVALID_FIELD_ELEMENT);
+  }
+}
+
 // One wave per item: sums the 64 * splits lane partials of k_msm_fixed (6-level tree
 // through LDS) into one XYZZ point per item.
 static __global__ __launch_bounds__(64) void k_msm_reduce(const g1_xyzz* __restrict__ partials, uint32_t splits, uint64_t n,
@@ -219,196 +314,3 @@ static __global__ __launch_bounds__(64) void k_g1_compress(const g1_xyzz* __rest
 
 #endif  // __HIPCC__
 }  // namespace kzg
-
-// ---------------------------------------------------------------------------------------------
-// Batch-affine variant of the fixed-base MSM (experimental, selected with KATETH_AMD_MSM_BATCH_AFFINE=1).
-//
-// A lane's table entries are taken in PAIRS and each pair is first added in affine coordinates,
-//   lambda = (y1 - y0)/(x1 - x0),  x3 = lambda^2 - x0 - x1,  y3 = lambda (x0 - x3) - y0,
-// with ONE field inversion per lane for all of its pairs (Montgomery's trick: suffix products of
-// the denominators d_k = x1 - x0 are streamed to an HBM scratch area in a backward pass, the lane
-// inverts their total once, and a forward pass peels off 1/d_k).  An affine pair-sum costs
-// 6 multiplies + 1/512 of an inversion and then enters the XYZZ accumulator with one mixed add
-// (10): 16.9 multiplies per two table entries instead of 20.
-// Digits use Booth recoding (digit j depends only on bits [cj-1, cj+c) of the scalar), which gives
-// the random access the backward pass needs; the signed-digit table is the same.
-// Pairs that are not "regular" (a zero digit, equal x: doubling or cancellation) bypass the batch
-// and go through the complete mixed add directly.
-// ---------------------------------------------------------------------------------------------
-#if defined(__HIPCC__)
-namespace kzg {
-
-// Booth digit j of a 256-bit scalar (8 limbs): returns |d| (0..2^(c-1)) and sign
-__device__ __forceinline__ uint32_t booth_digit(const uint32_t* sc, uint32_t j, uint32_t c, bool& neg) {
-  const int bit = (int)(c * j) - 1;  // lowest bit of the (c+1)-bit group
-  uint32_t v;
-  if (bit < 0) {
-    v = (sc[0] << 1);
-  } else {
-    const uint32_t wi = (uint32_t)bit >> 5, sh = (uint32_t)bit & 31u;
-    uint32_t w0 = 0, w1 = 0;
-#pragma unroll
-    for (uint32_t q = 0; q < 8; q++) {
-      w0 = (q == wi) ? sc[q] : w0;
-      w1 = (q == wi + 1) ? sc[q] : w1;
-    }
-    const uint64_t two = ((uint64_t)w1 << 32) | w0;
-    v = (uint32_t)(two >> sh);
-  }
-  v &= (2u << c) - 1u;
-  const uint32_t top = (v >> c) & 1u;
-  const uint32_t mag = (v + 1u) >> 1;  // raw + carry-in
-  neg = top != 0;
-  return neg ? ((1u << c) - mag) : mag;
-}
-
-template <bool BE_BYTES>
-__global__ __launch_bounds__(64, 2) void k_msm_fixed_ba(const uint8_t* __restrict__ scalars, uint32_t splits, const uint4* __restrict__ table,
-                                                        MsmGeom g, g1_xyzz* __restrict__ partials, int32_t* __restrict__ status,
-                                                        fp_t* __restrict__ scratch) {
-  const int lane = threadIdx.x;
-  const uint64_t unit = blockIdx.x;
-  const uint64_t blob = unit / splits;
-  const uint32_t split = (uint32_t)(unit % splits);
-  const uint32_t pts_per_split = 4096u / splits;
-  const uint32_t per_lane = pts_per_split / 64u;
-  const uint8_t* base = scalars + blob * (uint64_t)KZG_BYTES_PER_BLOB_;
-  const uint32_t T = per_lane * g.W;     // entries of this lane
-  const uint32_t NP = (T + 1) / 2;       // pairs (the last one may be a single)
-  fp_t* my = scratch + (unit * (uint64_t)(NP + 1)) * 64 + lane;  // suffix product of pair k at my[k*64]
-
-  bool bad = false;
-  uint32_t sc[8];
-  uint32_t cur_k = 0xffffffffu;
-  // entry t -> table index (or none); keeps the scalar of point t / W in registers
-  auto entry = [&](uint32_t t, bool& present, bool& neg) -> uint64_t {
-    const uint32_t k = t / g.W, j = t - k * g.W;
-    const uint32_t i = split * pts_per_split + k * 64u + (uint32_t)lane;
-    if (k != cur_k) {
-      load_scalar<BE_BYTES>(sc, base + (uint64_t)i * 32u);
-      if (BE_BYTES) {
-        fr_t v;
-#pragma unroll
-        for (int q = 0; q < 8; q++) v.v[q] = sc[q];
-        if (!fr_is_canonical(v)) {
-          bad = true;
-#pragma unroll
-          for (int q = 0; q < 8; q++) sc[q] = 0;
-        }
-      }
-      cur_k = k;
-    }
-    const uint32_t d = booth_digit(sc, j, g.c, neg);
-    present = d != 0;
-    return present ? table_index(g, j, i, d) : 0;
-  };
-  auto load_x = [&](fp_t& x, uint64_t idx) {
-    const uint4* p = table + idx * 6;
-    uint4 a0 = p[0], a1 = p[1], a2 = p[2];
-    x.v[0] = a0.x; x.v[1] = a0.y; x.v[2] = a0.z; x.v[3] = a0.w;
-    x.v[4] = a1.x; x.v[5] = a1.y; x.v[6] = a1.z; x.v[7] = a1.w;
-    x.v[8] = a2.x; x.v[9] = a2.y; x.v[10] = a2.z; x.v[11] = a2.w;
-  };
-
-  // ---- pass A (backward): suffix products of the regular pairs' denominators ----
-  // The pass is one multiply per gathered pair, so the gathers are issued two pairs ahead
-  // (x-coordinates only, 2 x 24 VGPRs) to keep their latency off the critical path.
-  fp_t suf = fp_one();
-  my[(uint64_t)NP * 64] = suf;
-  fp_t ax0[2], ax1[2];
-  bool aboth[2] = {false, false};
-  auto fetch_a = [&](int k, int slot) {
-    aboth[slot] = false;
-    if (k < 0) return;
-    const uint32_t t0 = 2u * (uint32_t)k, t1 = t0 + 1u;
-    bool p1 = false, n1 = false, p0, n0;
-    uint64_t i1 = 0;
-    if (t1 < T) i1 = entry(t1, p1, n1);
-    const uint64_t i0 = entry(t0, p0, n0);
-    if (p0 && p1) {
-      load_x(ax0[slot], i0);
-      load_x(ax1[slot], i1);
-      aboth[slot] = true;
-    }
-  };
-  fetch_a((int)NP - 1, 0);
-  fetch_a((int)NP - 2, 1);
-#pragma unroll 1
-  for (int k = (int)NP - 1; k >= 0; k -= 2) {
-    // slot 0 holds pair k, slot 1 pair k-1 (static slots: the loop body handles two pairs)
-    if (aboth[0]) {
-      fp_t d;
-      fp_sub(d, ax1[0], ax0[0]);
-      if (!bn_is_zero(d)) fp_mul(suf, suf, d);
-    }
-    my[(uint64_t)k * 64] = suf;
-    fetch_a(k - 2, 0);
-    if (k - 1 >= 0) {
-      if (aboth[1]) {
-        fp_t d;
-        fp_sub(d, ax1[1], ax0[1]);
-        if (!bn_is_zero(d)) fp_mul(suf, suf, d);
-      }
-      my[(uint64_t)(k - 1) * 64] = suf;
-      fetch_a(k - 3, 1);
-    }
-  }
-  // ---- one inversion per lane ----
-  fp_t inv;
-  {
-    fp_t tot = suf;
-    fp_inv(inv, tot);
-  }
-  // ---- pass B (forward): peel off 1/d_k, affine pair sums, accumulate ----
-  g1_xyzz acc;
-  xyzz_set_inf(acc);
-  cur_k = 0xffffffffu;
-#pragma unroll 1
-  for (uint32_t k = 0; k < NP; k++) {
-    // no register prefetch here: the forward pass is multiply-bound (17 multiplies per pair) and already at
-    // the 256-VGPR budget of two waves per SIMD -- a one-pair-ahead prefetch spilled (432 B scratch) and
-    // cost 10 %; the second wave of the SIMD covers the gather latency instead.
-    const uint32_t t0 = 2u * k, t1 = t0 + 1u;
-    bool p0, n0, p1 = false, n1 = false;
-    const uint64_t i0 = entry(t0, p0, n0);
-    uint64_t i1 = 0;
-    if (t1 < T) i1 = entry(t1, p1, n1);
-    fp_t x0, y0, x1, y1, nxt;
-    if (p0) load_affine96(x0, y0, table, i0);
-    if (p1) load_affine96(x1, y1, table, i1);
-    nxt = my[(uint64_t)(k + 1) * 64];
-    if (p0 && n0) fp_neg(y0, y0);
-    if (p1 && n1) fp_neg(y1, y1);
-    bool regular = false;
-    fp_t d;
-    if (p0 && p1) {
-      fp_sub(d, x1, x0);
-      regular = !bn_is_zero(d);
-    }
-    if (regular) {
-      fp_t id, lam, x3, y3, t;
-      fp_mul(id, inv, nxt);   // 1/d_k
-      fp_mul(inv, inv, d);    // inverse of the remaining suffix
-      fp_sub(t, y1, y0);
-      fp_mul(lam, t, id);
-      fp_sqr(x3, lam);
-      fp_sub(x3, x3, x0);
-      fp_sub(x3, x3, x1);
-      fp_sub(t, x0, x3);
-      fp_mul(y3, lam, t);
-      fp_sub(y3, y3, y0);
-      xyzz_madd_lazy(acc, x3, y3);
-    } else {
-      if (p0) xyzz_madd_lazy(acc, x0, y0);
-      if (p1) xyzz_madd_lazy(acc, x1, y1);
-    }
-  }
-  xyzz_canonicalize(acc);
-  partials[unit * 64 + lane] = acc;
-  if (BE_BYTES) {
-    if (__any(bad) && lane == 0) atomicOr(&status[blob], KZG_ERR_BLOB_INVALID_FIELD_ELEMENT);
-  }
-}
-
-}  // namespace kzg
-#endif

@@ -57,10 +57,13 @@ static __global__ __launch_bounds__(64) void k_table_chain(const uint4* __restri
   }
 }
 
-// thread: normalises KN consecutive XYZZ entries with one shared inversion
+// thread: normalises KN consecutive XYZZ entries with one shared inversion; r392 selects the Montgomery radix of the stored
+// coordinates (2^392 for the radix-2^28 MSM kernel, 2^384 otherwise)
+//
 // (Montgomery's trick on zz*zzz) and writes affine table entries.
 template <int KN>
-static __global__ __launch_bounds__(64) void k_table_normalize(const g1_xyzz* __restrict__ tmp, uint64_t count, uint4* __restrict__ table, uint64_t table_off) {
+static __global__ __launch_bounds__(64) void k_table_normalize(const g1_xyzz* __restrict__ tmp, uint64_t count, uint4* __restrict__ table, uint64_t table_off,
+                                                              bool r392) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t first = t * KN;
   if (first >= count) return;
@@ -99,6 +102,10 @@ static __global__ __launch_bounds__(64) void k_table_normalize(const g1_xyzz* __
       fp_mul(x, e.x, a);
       fp_mul(a, wi, e.zz);  // 1/zzz
       fp_mul(y, e.y, a);
+      if (r392) {  // table for k_msm_fixed28: coordinates times 2^392 instead of 2^384
+        fp_to_r392(x, x);
+        fp_to_r392(y, y);
+      }
       store_affine96(table, table_off + first + k, x, y);
     }
   }

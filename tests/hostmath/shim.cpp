@@ -4,7 +4,10 @@
 #include <stdint.h>
 #include <string.h>
 
-#include "../../kateth_amd/csrc/g1.cuh"
+#include <stdio.h>
+#include <stdlib.h>
+#define KZG_FP28_CHECK 1
+#include "../../kateth_amd/csrc/fp28.cuh"
 #include "../../kateth_amd/csrc/sha256.cuh"
 
 using namespace kzg;
@@ -222,5 +225,83 @@ extern "C" int32_t hm_g1_sum_lazy(uint8_t* out48, const uint8_t* pts48, int n) {
   }
   xyzz_canonicalize(acc);
   g1_compress_xyzz(out48, acc);
+  return 0;
+}
+
+// ---- radix-2^28 field / adder of the fixed-base MSM (kateth_amd/csrc/fp28.cuh) ----------------------
+static int g_fp28_violations = 0;
+extern "C" void kzg_fp28_check_failed(const char* what) {
+  g_fp28_violations++;
+  fprintf(stderr, "fp28 bound violated: %s\n", what);
+}
+extern "C" int32_t hm_f28_violations() { return g_fp28_violations; }
+
+static void f28_in(fp28& r, const uint8_t* a48) {  // plain value -> x * 2^392 mod p, 14 x 28
+  fp_t x;
+  load_le(x, a48);
+  to_mont<FpParams>(x, x);
+  fp_to_r392(x, x);
+  f28_from_bn(r, x);
+}
+static void f28_out(uint8_t* out48, const fp28& a) {
+  fp_t x;
+  f28_to_fp(x, a);
+  from_mont<FpParams>(x, x);
+  store_le(out48, x);
+}
+// op 0: a*b, 1: a^2, 2: a*b + c*d, 3: round trip, 4: a + 4p - b, 5: carry pass of (a + 16p - b),
+// 6: is_zero_exact(a + 4p - b) -> out[0]
+extern "C" void hm_f28_op(int op, uint8_t* out48, const uint8_t* a48, const uint8_t* b48, const uint8_t* c48, const uint8_t* d48) {
+  fp28 a, b, c, d, r;
+  f28_in(a, a48);
+  f28_in(b, b48);
+  f28_in(c, c48);
+  f28_in(d, d48);
+  switch (op) {
+    case 0: f28_mul(r, a, b); break;
+    case 1: f28_sqr(r, a); break;
+    case 2: f28_mul2(r, a, b, c, d); break;
+    case 3: r = a; break;
+    case 4: f28_sub_4p(r, a, b); break;
+    case 5:
+      f28_sub_16p(r, a, b);
+      f28_carry_pass(r);
+      break;
+    case 6: {
+      f28_sub_4p(r, a, b);
+      bool z = f28_maybe_zero(r) && f28_is_zero_exact(r);
+      memset(out48, 0, 48);
+      out48[0] = z ? 1 : 0;
+      return;
+    }
+    default: r = a;
+  }
+  f28_out(out48, r);
+}
+// sum of +-points through xyzz28_madd (the MSM hot-loop adder); signs[i] != 0 negates point i
+static int g_fp28_slow_calls = 0;
+extern "C" int32_t hm_f28_slow_calls() { return g_fp28_slow_calls; }
+extern "C" int32_t hm_g1_sum28(uint8_t* out48, const uint8_t* pts48, const uint8_t* signs, int n, int force_complete) {
+  g1_xyzz28 acc;
+  xyzz28_set_inf(acc);
+  for (int i = 0; i < n; i++) {
+    fp_t x, y;
+    bool inf;
+    int32_t st = g1_uncompress(x, y, inf, pts48 + 48 * i);
+    if (st) return st;
+    if (inf) continue;
+    fp_to_r392(x, x);
+    fp_to_r392(y, y);
+    fp28 x2, y2;
+    f28_load_entry(x2, y2, x, y, signs[i] != 0);
+    // the kernel's flow: hot path first, complete adder when it declines (or when the accumulator is the identity)
+    if (force_complete || acc.inf || !xyzz28_madd_fast(acc, x2, y2)) {
+      g_fp28_slow_calls++;
+      xyzz28_madd_complete(acc, x2, y2);
+    }
+  }
+  g1_xyzz r;
+  xyzz28_to_xyzz(r, acc);
+  g1_compress_xyzz(out48, r);
   return 0;
 }

@@ -498,13 +498,13 @@ def test_ragged_batch_sizes_agree_with_single_items(engine, torch_cuda):
     assert engine.verify_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr() + 48, n - 1) is False
 
 
-def test_batch_affine_msm_variant_is_bit_exact(golden, monkeypatch):
-    """the experimental batch-affine fixed-base MSM (KATETH_AMD_MSM_BATCH_AFFINE=1: Booth digits, pairs
-    pre-added in affine coordinates with one inversion per lane) must produce the same bytes"""
+def test_radix32_msm_kernel_is_bit_exact(golden, monkeypatch):
+    """KATETH_AMD_MSM_RADIX=32 selects the 12 x 32-bit-limb MSM kernel and the 2^384-Montgomery table; the default is the
+    radix-2^28 kernel (fp28.cuh).  Both must produce the same bytes (the rest of this file runs the default)."""
     import kateth_amd
 
-    monkeypatch.setenv("KATETH_AMD_MSM_BATCH_AFFINE", "1")
-    s = kateth_amd.Setup.load_json(TRUSTED_SETUP, window_bits=7)  # odd window count exercises the unpaired tail
+    monkeypatch.setenv("KATETH_AMD_MSM_RADIX", "32")
+    s = kateth_amd.Setup.load_json(TRUSTED_SETUP, window_bits=7)
     try:
         recs = golden["blobs"][:3]
         blobs = b"".join(synth_blob(r["index"]) for r in recs) + be32(1) * 4096 + bytes(131072) + be32(R - 1) * 4096

@@ -237,3 +237,69 @@ def test_lazy_madd_matches_canonical(hm):
     assert hm.hm_g1_sum_lazy(out, enc[1] + enc[2] + bls.g1_compress(bls.g1_neg(bls.g1_add(pts[1], pts[2]))), 3) == 0 and out.raw == bls.g1_compress(None)
     assert hm.hm_g1_sum_lazy(out, enc[3] + enc[4] + bls.g1_compress(bls.g1_add(pts[3], pts[4])), 3) == 0
     assert out.raw == bls.g1_compress(bls.g1_mul(bls.g1_add(pts[3], pts[4]), 2))
+
+
+# ---- radix-2^28 field of the fixed-base MSM hot loop (kateth_amd/csrc/fp28.cuh) -------------------
+def _f28(hm, op, a, b=0, c=0, d=0):
+    out = ctypes.create_string_buffer(48)
+    hm.hm_f28_op(op, out, *(int(v).to_bytes(48, "little") for v in (a, b, c, d)))
+    return out.raw
+
+
+def test_fp28_field_ops(hm):
+    """14 x 28-bit limb Montgomery arithmetic (radix 2^392) against Python integers; the CPU build re-computes every
+    column sum in 128 bits and checks every limb subtraction, so a violated bound fails the test"""
+    rnd = random.Random(28)
+    edge = [0, 1, 2, P - 1, P - 2, (P - 1) // 2, (1 << 380), (1 << 28) - 1, ((1 << 392) % P), P - ((1 << 392) % P)]
+    vals = edge + [rnd.randrange(P) for _ in range(60)]
+    for a in vals:
+        assert int.from_bytes(_f28(hm, 3, a), "little") == a
+        assert int.from_bytes(_f28(hm, 1, a), "little") == a * a % P
+    for _ in range(300):
+        a, b, c, d = (rnd.choice(vals) for _ in range(4))
+        assert int.from_bytes(_f28(hm, 0, a, b), "little") == a * b % P
+        assert int.from_bytes(_f28(hm, 2, a, b, c, d), "little") == (a * b + c * d) % P
+        assert int.from_bytes(_f28(hm, 4, a, b), "little") == (a - b) % P
+        assert int.from_bytes(_f28(hm, 5, a, b), "little") == (a - b) % P
+        assert _f28(hm, 6, a, b)[0] == (1 if a == b else 0)
+    for a in vals:
+        assert _f28(hm, 6, a, a)[0] == 1
+    assert hm.hm_f28_violations() == 0
+
+
+def test_fp28_madd_complete(hm):
+    """the hot-loop adder in the 2^28 representation: long random signed sums, P + P, P - P, leading/trailing cancellation"""
+    rnd = random.Random(29)
+    g = bls.G1_GEN
+    pts = [bls.g1_mul(g, rnd.randrange(1, R)) for _ in range(48)]
+    enc = [bls.g1_compress(p) for p in pts]
+    out = ctypes.create_string_buffer(48)
+
+    def run(idx, signs, force=0):
+        assert hm.hm_g1_sum28(out, b"".join(enc[i] for i in idx), bytes(signs), len(idx), force) == 0
+        want = None
+        for i, s in zip(idx, signs):
+            want = bls.g1_add(want, bls.g1_neg(pts[i]) if s else pts[i])
+        assert out.raw == bls.g1_compress(want), (idx, signs)
+
+    run(list(range(48)), [rnd.randrange(2) for _ in range(48)])
+    assert hm.hm_f28_slow_calls() == 1  # only the first add (identity accumulator) left the hot path
+    run(list(range(48)), [rnd.randrange(2) for _ in range(48)], force=1)  # generic case through the complete adder
+    run([0, 0], [0, 0])  # P + P (first add after the identity)
+    run([0, 0], [1, 1])  # (-P) + (-P)
+    run([0, 0], [0, 1])  # P - P
+    run([0, 0, 1], [0, 1, 0])  # identity again, then a point
+    run([1, 2, 3, 3], [0, 0, 0, 0])
+    run([1, 2, 1, 2], [0, 0, 1, 1])  # cancels through a non-trivial accumulator
+    # accumulator equals the next entry with a non-trivial ZZ: (a + b) then + (a + b) as an affine point
+    ab = bls.g1_add(pts[4], pts[5])
+    assert hm.hm_g1_sum28(out, enc[4] + enc[5] + bls.g1_compress(ab), bytes([0, 0, 0]), 3, 0) == 0
+    assert out.raw == bls.g1_compress(bls.g1_mul(ab, 2))
+    assert hm.hm_g1_sum28(out, enc[4] + enc[5] + bls.g1_compress(ab), bytes([0, 0, 1]), 3, 0) == 0
+    assert out.raw == bls.g1_compress(None)
+    assert hm.hm_g1_sum28(out, enc[4] + enc[5] + bls.g1_compress(ab) + enc[6], bytes([1, 1, 1, 0]), 4, 0) == 0
+    assert out.raw == bls.g1_compress(bls.g1_add(bls.g1_neg(bls.g1_mul(ab, 2)), pts[6]))
+    for _ in range(6):
+        n = rnd.randrange(1, 30)
+        run([rnd.randrange(48) for _ in range(n)], [rnd.randrange(2) for _ in range(n)])
+    assert hm.hm_f28_violations() == 0
