@@ -88,13 +88,24 @@ struct f28_col {
 // ---- representation changes ---------------------------------------------------------------------
 // 12 x 32-bit limbs (value < 2^384) -> 14 x 28-bit limbs, strictly normalised
 KZG_HD void f28_from_bn(fp28& r, const fp_t& a) {
+  // 32-bit funnel shifts only: a 64-bit (hi:lo) >> s makes hipcc spill the source limbs to scratch and re-read them
+  // as unaligned 64-bit loads
   KZG_UNROLL_FULL
   for (int i = 0; i < F28_N; i++) {
     const int bit = F28_W * i, w = bit >> 5, s = bit & 31;
     const uint32_t lo = a.v[w];
-    const uint32_t hi = (w + 1 < 12) ? a.v[w + 1] : 0u;
-    const uint64_t two = ((uint64_t)hi << 32) | lo;
-    r.l[i] = (uint32_t)(two >> s) & F28_MASK;
+    uint32_t v;
+    if (s + F28_W <= 32) {
+      v = lo >> s;
+    } else {
+      const uint32_t hi = (w + 1 < 12) ? a.v[w + 1] : 0u;
+#if defined(__HIP_DEVICE_COMPILE__)
+      v = __builtin_amdgcn_alignbit(hi, lo, s);
+#else
+      v = (lo >> s) | (hi << (32 - s));
+#endif
+    }
+    r.l[i] = v & F28_MASK;
   }
 }
 // strictly normalised limbs (all < 2^28) and value < 2^384 -> 12 x 32-bit limbs
