@@ -8,7 +8,7 @@ GPU); every rank commits its own 4096 blobs (weak scaling, blobs are
 independent) and the 48-byte commitments are all-gathered with RCCL.
 
 Prints ONE JSON line on rank 0 (contract in the task description) carrying
-`roofline` (dominant kernel k_msm_fixed, HIP-event timed inside the library on
+`roofline` (dominant kernel k_msm_fixed28, HIP-event timed inside the library on
 the stream it runs on) and `cpu_baseline` (the C port of the reference's CPU
 algorithm, oracle/cport, timed on the host cores on a bounded sample).
 Secondary workloads (`compute_blob_kzg_proof`, `verify_blob_kzg_proof_batch`)
@@ -61,9 +61,10 @@ def cpu_baseline(sample_blobs, setup_path, gpu_out48):
 
 
 def pmc_traffic(n, window_bits):
-    """HBM bytes per k_msm_fixed launch from the committed rocprofv3 PMC passes
+    """HBM bytes per MSM-kernel launch from the committed rocprofv3 PMC passes
     (profiles/r01/pmc_traffic.json; separate --pmc FETCH_SIZE / WRITE_SIZE runs of this
-    same command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).
+    same command, calibrated against the kernel's known gather bytes as MI355X_MICROARCH.md
+    prescribes: factor 1.0 for this access pattern, see the note in that file).
     bench.py cannot run the profiler on itself, so this is the profiled value for the
     same (batch, window) configuration, or null when none has been recorded."""
     path = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")
@@ -252,9 +253,10 @@ def main():
         },
     }
     if rank == 0:
-        # measured integer-ALU ceiling: dependent Fp Montgomery multiplies (the lazy-reduction multiply of the
-        # hot loop), 8 waves/SIMD, whole chip.  The kernel also does ~7 add/sub per 10 multiplies, so
-        # valu_frac < 1 even at full VALU occupancy.
+        # measured integer-ALU ceiling: dependent Fp Montgomery multiplies with the multiply of the MSM kernel in
+        # use (radix-2^28 limbs by default), 8 waves/SIMD, whole chip.  A mixed add is 10 products (2 of them
+        # squarings, 2 sharing one reduction) plus ~900 other VALU instructions, so valu_frac is a utilisation
+        # estimate, not an exact instruction ratio; DESIGN.md section 5 gives the instruction counts.
         lanes = 256 * 4 * 64 * 8
         setup.microbench_fp_mul(lanes, 200)
         prof["fp_mul_peak_per_s"] = lanes * 2000 / (setup.microbench_fp_mul(lanes, 2000) * 1e-3)
@@ -263,7 +265,7 @@ def main():
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else None
         adds_per_blob = prof["adds_per_blob"]
         result["roofline"] = {
-            "kernel": "k_msm_fixed",
+            "kernel": "k_msm_fixed" if os.environ.get("KATETH_AMD_MSM_RADIX") == "32" else "k_msm_fixed28",
             "bound": "hbm",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,

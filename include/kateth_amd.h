@@ -166,7 +166,9 @@ int32_t kzg_synth_blobs_dev(const kzg_ctx* ctx, uint64_t seed, uint64_t first_in
 /*
  * Device micro-benchmarks (measurement support for bench.py's roofline object):
  * runs `iters` dependent Fp Montgomery multiplications per lane on `lanes`
- * lanes and returns the elapsed milliseconds measured with HIP events.
+ * lanes -- with the multiply of the fixed-base MSM kernel the context uses
+ * (radix-2^28 limbs by default) -- and returns the elapsed milliseconds
+ * measured with HIP events.
  */
 int32_t kzg_microbench_fp_mul(const kzg_ctx* ctx, uint64_t lanes, uint64_t iters, float* ms);
 

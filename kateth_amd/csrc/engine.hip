@@ -376,6 +376,28 @@ __global__ __launch_bounds__(256) void k_microbench_fp_mul(uint32_t* out, uint64
   out[t] = x;
 }
 
+// the same chain with the multiply of the radix-2^28 MSM kernel (fp28.cuh)
+__global__ __launch_bounds__(256) void k_microbench_fp28_mul(uint32_t* out, uint64_t iters) {
+  fp28 a, b;
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll
+  for (int q = 0; q < F28_N; q++) {
+    a.l[q] = f28_one_limb(q) ^ (t & 0xffu);
+    b.l[q] = f28_r384_limb(q);
+  }
+#pragma unroll 1
+  for (uint64_t it = 0; it < iters; it++) {
+    fp28 r;
+    f28_mul(r, a, b);
+    a = b;
+    b = r;
+  }
+  uint32_t x = 0;
+#pragma unroll
+  for (int q = 0; q < F28_N; q++) x ^= b.l[q];
+  out[t] = x;
+}
+
 extern "C" int32_t kzg_microbench_fp_mul(const kzg_ctx* ctx, uint64_t lanes, uint64_t iters, float* ms) {
   if (!ctx || !ms || lanes == 0) return fail(KZG_FAIL_ARGUMENT, "null argument");
   HIP_TRY(hipSetDevice(ctx->device));
@@ -385,9 +407,10 @@ extern "C" int32_t kzg_microbench_fp_mul(const kzg_ctx* ctx, uint64_t lanes, uin
   hipEvent_t e0, e1;
   HIP_TRY(hipEventCreate(&e0));
   HIP_TRY(hipEventCreate(&e1));
-  hipLaunchKernelGGL(k_microbench_fp_mul, dim3((unsigned)(lanes / 256)), dim3(256), 0, nullptr, d_out, (uint64_t)16);
+  auto kern = ctx->msm_radix28 ? k_microbench_fp28_mul : k_microbench_fp_mul;  // the multiply the MSM kernel in use is built on
+  hipLaunchKernelGGL(kern, dim3((unsigned)(lanes / 256)), dim3(256), 0, nullptr, d_out, (uint64_t)16);
   HIP_TRY(hipEventRecord(e0, nullptr));
-  hipLaunchKernelGGL(k_microbench_fp_mul, dim3((unsigned)(lanes / 256)), dim3(256), 0, nullptr, d_out, iters);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(lanes / 256)), dim3(256), 0, nullptr, d_out, iters);
   HIP_TRY(hipEventRecord(e1, nullptr));
   HIP_TRY(hipEventSynchronize(e1));
   HIP_TRY(hipEventElapsedTime(ms, e0, e1));
