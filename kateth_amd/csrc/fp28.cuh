@@ -151,7 +151,7 @@ KZG_HD void f28_normalize(fp28& a) {
 // r = (a*b [+ c*d]) / 2^392 mod p, N-form.  Requires 14*(La*Lb [+ Lc*Ld]) + 14*2^56 < 2^64 for the limb
 // bounds L, and (Va*Vb [+ Vc*Vd]) < 2^11 for the value bounds V in units of p (so the result is < 2p).
 template <bool SQR, bool TWO>
-KZG_HD void f28_mul_core(fp28& r, const fp28& a, const fp28& b, const fp28& c, const fp28& d) {
+KZG_HD void f28_mul_core_c(fp28& r, const fp28& a, const fp28& b, const fp28& c, const fp28& d) {
   uint32_t q[F28_N];
   uint32_t a2[F28_N];
   if (SQR) {
@@ -199,6 +199,96 @@ KZG_HD void f28_mul_core(fp28& r, const fp28& a, const fp28& b, const fp28& c, c
     }
   }
 }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// Device version: every column is issued as explicit v_mad_u64_u32 chains (mac_asm.cuh) that START from the carry of
+// the previous column.  Left to itself hipcc starts each column from zero and adds the carry with an extra
+// v_lshl_add_u64 (26 per product, 5 % of the hot loop).  Same arithmetic as f28_mul_core_c, which the CPU tests run.
+// Columns are template instances so that every operand list has a compile-time length.
+template <bool SQR, bool TWO, int K>
+KZG_HD void f28_column(uint64_t& A, uint32_t* q, fp28& r, const fp28& a, const uint32_t* a2, const fp28& b, const fp28& c, const fp28& d) {
+  constexpr int i0 = (K < F28_N) ? 0 : K - F28_N + 1;
+  constexpr int i1 = (K < F28_N) ? K : F28_N - 1;
+  constexpr int cnt = i1 - i0 + 1;
+  if constexpr (SQR) {
+    // pairs i < j with i + j = K:  i = i0 .. (K-1)/2 ;  diagonal when K is even
+    constexpr int last_pair = (K - 1) / 2;
+    constexpr int npairs = (K >= 1 && last_pair >= i0) ? last_pair - i0 + 1 : 0;
+    constexpr int diag = (K % 2 == 0) ? 1 : 0;
+    uint32_t xs[npairs + diag], ys[npairs + diag];
+    KZG_UNROLL_FULL
+    for (int t = 0; t < npairs; t++) {
+      xs[t] = a2[i0 + t];
+      ys[t] = a.l[K - i0 - t];
+    }
+    if constexpr (diag) {
+      xs[npairs] = a.l[K / 2];
+      ys[npairs] = a.l[K / 2];
+    }
+    mad28_chain<npairs + diag, false>::run(A, xs, ys);
+  } else {
+    uint32_t xs[cnt], ys[cnt];
+    KZG_UNROLL_FULL
+    for (int t = 0; t < cnt; t++) {
+      xs[t] = a.l[i0 + t];
+      ys[t] = b.l[K - i0 - t];
+    }
+    mad28_chain<cnt, false>::run(A, xs, ys);
+  }
+  if constexpr (TWO) {
+    uint32_t xs[cnt], ys[cnt];
+    KZG_UNROLL_FULL
+    for (int t = 0; t < cnt; t++) {
+      xs[t] = c.l[i0 + t];
+      ys[t] = d.l[K - i0 - t];
+    }
+    mad28_chain<cnt, false>::run(A, xs, ys);
+  }
+  if constexpr (K < F28_N) {
+    if constexpr (K > 0) {
+      uint32_t qs[K], ps[K];
+      KZG_UNROLL_FULL
+      for (int t = 0; t < K; t++) {
+        qs[t] = q[t];
+        ps[t] = f28_p(K - t);
+      }
+      mad28_chain<K, true>::run(A, qs, ps);
+    }
+    q[K] = ((uint32_t)A * (uint32_t)KZG_FP28_INV) & F28_MASK;
+    const uint32_t p0 = f28_p(0);
+    mad28_chain<1, true>::run(A, &q[K], &p0);
+    A >>= F28_W;
+  } else {
+    uint32_t qs[cnt], ps[cnt];
+    KZG_UNROLL_FULL
+    for (int t = 0; t < cnt; t++) {
+      qs[t] = q[i0 + t];
+      ps[t] = f28_p(K - i0 - t);
+    }
+    mad28_chain<cnt, true>::run(A, qs, ps);
+    r.l[K - F28_N] = (uint32_t)A & F28_MASK;  // r may alias an operand: limb K-14 of every operand was last read in column K-1
+    A >>= F28_W;
+  }
+  if constexpr (K + 1 < 2 * F28_N - 1) f28_column<SQR, TWO, K + 1>(A, q, r, a, a2, b, c, d);
+}
+template <bool SQR, bool TWO>
+KZG_HD void f28_mul_core(fp28& r, const fp28& a, const fp28& b, const fp28& c, const fp28& d) {
+  uint32_t q[F28_N];
+  uint32_t a2[F28_N];
+  if (SQR) {
+    KZG_UNROLL_FULL
+    for (int i = 0; i < F28_N; i++) a2[i] = a.l[i] << 1;
+  }
+  uint64_t A = 0;
+  f28_column<SQR, TWO, 0>(A, q, r, a, a2, b, c, d);
+  r.l[F28_N - 1] = (uint32_t)A;  // column 27 holds only the carry; value < 2p: the top limb is small
+}
+#else
+template <bool SQR, bool TWO>
+KZG_HD void f28_mul_core(fp28& r, const fp28& a, const fp28& b, const fp28& c, const fp28& d) {
+  f28_mul_core_c<SQR, TWO>(r, a, b, c, d);
+}
+#endif
 KZG_HD void f28_mul(fp28& r, const fp28& a, const fp28& b) { f28_mul_core<false, false>(r, a, b, a, b); }
 KZG_HD void f28_sqr(fp28& r, const fp28& a) { f28_mul_core<true, false>(r, a, a, a, a); }
 // r = (a*b + c*d) / 2^392: two products, ONE reduction
