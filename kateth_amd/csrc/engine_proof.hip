@@ -57,13 +57,12 @@ static int32_t proof_dev_locked(const kzg_ctx* ctx, const uint8_t* d_blobs, cons
   g1_xyzz* partials = reinterpret_cast<g1_xyzz*>(ws + o_part);
   g1_xyzz* sums = reinterpret_cast<g1_xyzz*>(ws + o_sum);
   hipStream_t side = overlap ? ctx->side_stream : st;
-  std::vector<hipEvent_t> ev_prep(nchunks, nullptr), ev_done(nchunks, nullptr);
+  std::vector<hipEvent_t> ev_prep(nchunks, nullptr), ev_done(nchunks, nullptr), ev_fork(nchunks, nullptr), ev_join(nchunks, nullptr);
   hipEvent_t ev_start = nullptr;
   auto cleanup = [&]() {
-    for (auto e : ev_prep)
-      if (e) (void)hipEventDestroy(e);
-    for (auto e : ev_done)
-      if (e) (void)hipEventDestroy(e);
+    for (auto* v : {&ev_prep, &ev_done, &ev_fork, &ev_join})
+      for (auto e : *v)
+        if (e) (void)hipEventDestroy(e);
     if (ev_start) (void)hipEventDestroy(ev_start);
   };
   HIP_TRY(hipMemsetAsync(d_status, 0, n * sizeof(int32_t), st));
@@ -72,7 +71,9 @@ static int32_t proof_dev_locked(const kzg_ctx* ctx, const uint8_t* d_blobs, cons
   (void)hipStreamWaitEvent(side, ev_start, 0);
   for (uint64_t k = 0; k < nchunks && rc == 0; k++) {
     if (hipEventCreateWithFlags(&ev_prep[k], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ev_done[k], hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&ev_done[k], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ev_fork[k], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ev_join[k], hipEventDisableTiming) != hipSuccess) {
       rc = fail(KZG_FAIL_HIP, "event create failed");
       break;
     }
@@ -91,9 +92,18 @@ static int32_t proof_dev_locked(const kzg_ctx* ctx, const uint8_t* d_blobs, cons
     (void)hipMemsetAsync(cstat, 0, m * sizeof(int32_t), side);
     if (d_commitments48) {
       const uint8_t* com = d_commitments48 + base * 48;
-      hipLaunchKernelGGL(k_g1_decompress, dim3(blocks_for(m, 64)), dim3(64), 0, side, com, m, cstat, (const uint8_t*)nullptr, (uint64_t)0,
+      // the commitment check (one lane per point: ~2.6 ms of latency for any chunk size) runs beside the SHA-256
+      // challenge (one lane per blob: ~5.6 ms) on a second stream; both are far too small to compete for CUs
+      hipStream_t dec = overlap ? side : ctx->side_stream;
+      if (dec != side) {
+        (void)hipEventRecord(ev_fork[k], side);
+        (void)hipStreamWaitEvent(dec, ev_fork[k], 0);
+      }
+      hipLaunchKernelGGL(k_g1_decompress, dim3(blocks_for(m, 64)), dim3(64), 0, dec, com, m, cstat, (const uint8_t*)nullptr, (uint64_t)0,
                          (int32_t*)nullptr, (uint4*)nullptr, (uint8_t*)nullptr);
+      if (dec != side) (void)hipEventRecord(ev_join[k], dec);
       hipLaunchKernelGGL(k_challenge, dim3(blocks_for(m, 64)), dim3(64), 0, side, blobs, com, m, z);
+      if (dec != side) (void)hipStreamWaitEvent(side, ev_join[k], 0);
     } else {
       hipLaunchKernelGGL(k_fr_parse, dim3(blocks_for(m, 64)), dim3(64), 0, side, d_z32 + base * 32, m, z, cstat);
     }

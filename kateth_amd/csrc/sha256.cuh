@@ -26,6 +26,23 @@ KZG_HD uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
 #endif
 }
 
+// Ch and Maj as single v_bitop3_b32 instructions (result bit = table[(a << 2) | (b << 1) | c]); hipcc
+// otherwise builds Maj from an and, a xor and one bitop3
+KZG_HD uint32_t sha_ch(uint32_t e, uint32_t f, uint32_t g) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_bitop3_b32(e, f, g, 0xCA);
+#else
+  return (e & f) ^ (~e & g);
+#endif
+}
+KZG_HD uint32_t sha_maj(uint32_t a, uint32_t b, uint32_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_bitop3_b32(a, b, c, 0xE8);
+#else
+  return (a & b) ^ (a & c) ^ (b & c);
+#endif
+}
+
 KZG_HD void sha256_init(sha256_state& s) {
   s.h[0] = 0x6a09e667u;
   s.h[1] = 0xbb67ae85u;
@@ -70,10 +87,10 @@ KZG_HD void sha256_block(sha256_state& s, const uint32_t* win) {
       w[i & 15] = wi;
     }
     uint32_t S1 = xor3(rotr32(e, 6), rotr32(e, 11), rotr32(e, 25));
-    uint32_t ch = (e & f) ^ (~e & g);
+    uint32_t ch = sha_ch(e, f, g);
     uint32_t t1 = h + S1 + ch + sha256_k(i) + wi;
     uint32_t S0 = xor3(rotr32(a, 2), rotr32(a, 13), rotr32(a, 22));
-    uint32_t mj = (a & b) ^ (a & c) ^ (b & c);
+    uint32_t mj = sha_maj(a, b, c);
     uint32_t t2 = S0 + mj;
     h = g;
     g = f;
