@@ -125,8 +125,7 @@ extern "C" void kzg_ctx_destroy(kzg_ctx* ctx) {
   if (ctx->d_table) (void)hipFree(ctx->d_table);
   if (ctx->d_bases_brp) (void)hipFree(ctx->d_bases_brp);
   if (ctx->d_roots_brp) (void)hipFree(ctx->d_roots_brp);
-  if (ctx->d_roots_r2) (void)hipFree(ctx->d_roots_r2);
-  if (ctx->d_roots_sq) (void)hipFree(ctx->d_roots_sq);
+  if (ctx->d_eval_tab) (void)hipFree(ctx->d_eval_tab);
   if (ctx->d_gen_affine) (void)hipFree(ctx->d_gen_affine);
   delete ctx->pairing;
   if (ctx->ws) (void)hipFree(ctx->ws);
@@ -139,20 +138,6 @@ extern "C" void kzg_ctx_destroy(kzg_ctx* ctx) {
   delete ctx;
 }
 
-__global__ __launch_bounds__(64) void k_setup_roots_r2(const fr_t* __restrict__ roots, fr_t* __restrict__ out) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= 4096) return;
-  fr_t r;
-  to_mont<FrParams>(r, roots[t]);
-  out[t] = r;
-}
-__global__ __launch_bounds__(64) void k_setup_roots_sq(const fr_t* __restrict__ roots, fr_t* __restrict__ out) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= 2048) return;
-  fr_t r;
-  fr_sqr(r, roots[2 * t]);
-  out[t] = r;
-}
 
 static int32_t ctx_build(kzg_ctx* ctx, const uint8_t* g1_lagrange, const uint8_t* g2_monomial) {
   const MsmGeom g = ctx->geom;
@@ -213,10 +198,8 @@ static int32_t ctx_build(kzg_ctx* ctx, const uint8_t* g1_lagrange, const uint8_t
   // ---- roots of unity -------------------------------------------------------
   HIP_TRY(hipMalloc(&ctx->d_roots_brp, 4096 * sizeof(fr_t)));
   hipLaunchKernelGGL(k_setup_roots, dim3(64), dim3(64), 0, st, ctx->d_roots_brp);
-  HIP_TRY(hipMalloc(&ctx->d_roots_r2, 4096 * sizeof(fr_t)));
-  hipLaunchKernelGGL(k_setup_roots_r2, dim3(64), dim3(64), 0, st, ctx->d_roots_brp, ctx->d_roots_r2);
-  HIP_TRY(hipMalloc(&ctx->d_roots_sq, 2048 * sizeof(fr_t)));
-  hipLaunchKernelGGL(k_setup_roots_sq, dim3(32), dim3(64), 0, st, ctx->d_roots_brp, ctx->d_roots_sq);
+  HIP_TRY(hipMalloc(&ctx->d_eval_tab, (size_t)2048 * EVAL_TAB_DWORDS * sizeof(uint32_t)));
+  hipLaunchKernelGGL(k_setup_eval_tab, dim3(32), dim3(64), 0, st, ctx->d_roots_brp, ctx->d_eval_tab);
   HIP_TRY(hipGetLastError());
   // ---- fixed-base table -----------------------------------------------------
   const uint64_t entries = table_entries(g);

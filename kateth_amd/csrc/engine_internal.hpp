@@ -34,8 +34,7 @@ struct kzg_ctx {
   uint4* d_table = nullptr;      // fixed-base table, table_entries(geom) * 96 B
   uint4* d_bases_brp = nullptr;  // 4096 affine Lagrange points, BRP order
   fr_t* d_roots_brp = nullptr;   // 4096 roots of unity, Montgomery, BRP order
-  fr_t* d_roots_r2 = nullptr;    // the same roots times R^2 (see k_eval_frac)
-  fr_t* d_roots_sq = nullptr;    // 2048 squares w_{2k}^2 (Montgomery): pair denominators z^2 - w^2
+  uint32_t* d_eval_tab = nullptr;  // 2048 x {w R, w R^2, w^2 R} in radix-2^29 limbs (k_eval_frac, verify_kernels.cuh)
   uint4* d_gen_affine = nullptr; // G1 generator, affine Montgomery (96 B)
   host::pairing_ctx* pairing = nullptr;  // host: Frobenius constants + Miller lines of G2 and [tau]_2
   uint64_t table_bytes = 0;

@@ -16,6 +16,7 @@
 // (src/bls.rs:416-437) together with field.cuh.
 #pragma once
 #include "g1.cuh"
+#include "rdx_mont.cuh"
 
 namespace kzg {
 
@@ -23,9 +24,16 @@ constexpr int F28_N = 14;
 constexpr int F28_W = 28;
 constexpr uint32_t F28_MASK = (1u << F28_W) - 1u;
 
-struct fp28 {
-  uint32_t l[F28_N];
+struct Fp28P {
+  static constexpr int N = F28_N;
+  static constexpr int W = F28_W;
+  static constexpr uint32_t INV = KZG_FP28_INV;
+  KZG_HD static constexpr uint32_t mod(int i) {
+    constexpr uint32_t t[N] = KZG_FP28_MOD;
+    return t[i];
+  }
 };
+using fp28 = rdx_t<Fp28P>;
 
 #define KZG_F28_TABLE(fn, MACRO)                 \
   KZG_HD constexpr uint32_t fn(int i) {          \
@@ -41,84 +49,14 @@ KZG_F28_TABLE(f28_16p_t1, KZG_FP28_16P_T1)
 KZG_F28_TABLE(f28_8p_t3, KZG_FP28_8P_T3)
 #undef KZG_F28_TABLE
 
-#if !defined(__HIP_DEVICE_COMPILE__) && defined(KZG_FP28_CHECK)
-// CPU test build: every column sum is also formed in 128 bits and every limb subtraction is
-// checked, so a violated bound aborts the test instead of silently wrapping.
-extern "C" void kzg_fp28_check_failed(const char* what);
-struct f28_col {
-  unsigned __int128 wide;
-  uint64_t v;
-};
-#define F28_COL_INIT(A) \
-  f28_col A { 0, 0 }
-#define F28_MAC(A, x, y)                                            \
-  do {                                                              \
-    (A).wide += (unsigned __int128)(uint32_t)(x) * (uint32_t)(y);   \
-    (A).v += (uint64_t)(uint32_t)(x) * (uint32_t)(y);               \
-    if ((A).wide >> 64) kzg_fp28_check_failed("column overflow");   \
-  } while (0)
-#define F28_LO(A) ((uint32_t)(A).v)
-#define F28_SHIFT(A)      \
-  do {                    \
-    (A).v >>= F28_W;      \
-    (A).wide = (A).v;     \
-  } while (0)
-#define F28_SUBCHK(a, m, b)                                                              \
-  do {                                                                                   \
-    if ((uint64_t)(a) + (uint64_t)(m) < (uint64_t)(b)) kzg_fp28_check_failed("limb underflow"); \
-    if ((uint64_t)(a) + (uint64_t)(m) - (uint64_t)(b) >> 32) kzg_fp28_check_failed("limb overflow"); \
-  } while (0)
-#define F28_ADDCHK(a, b)                                                          \
-  do {                                                                            \
-    if (((uint64_t)(a) + (uint64_t)(b)) >> 32) kzg_fp28_check_failed("limb overflow"); \
-  } while (0)
-#else
-#define F28_COL_INIT(A) uint64_t A = 0
-#define F28_MAC(A, x, y) (A) += (uint64_t)(uint32_t)(x) * (uint32_t)(y)
-#define F28_LO(A) ((uint32_t)(A))
-#define F28_SHIFT(A) (A) >>= F28_W
-#define F28_SUBCHK(a, m, b) \
-  do {                      \
-  } while (0)
-#define F28_ADDCHK(a, b) \
-  do {                   \
-  } while (0)
-#endif
+// the bound-check hooks of rdx_mont.cuh under their fp28 names
+#define F28_SUBCHK RDX_SUBCHK
+#define F28_ADDCHK RDX_ADDCHK
 
-// ---- representation changes ---------------------------------------------------------------------
-// 12 x 32-bit limbs (value < 2^384) -> 14 x 28-bit limbs, strictly normalised
-KZG_HD void f28_from_bn(fp28& r, const fp_t& a) {
-  // 32-bit funnel shifts only: a 64-bit (hi:lo) >> s makes hipcc spill the source limbs to scratch and re-read them
-  // as unaligned 64-bit loads
-  KZG_UNROLL_FULL
-  for (int i = 0; i < F28_N; i++) {
-    const int bit = F28_W * i, w = bit >> 5, s = bit & 31;
-    const uint32_t lo = a.v[w];
-    uint32_t v;
-    if (s + F28_W <= 32) {
-      v = lo >> s;
-    } else {
-      const uint32_t hi = (w + 1 < 12) ? a.v[w + 1] : 0u;
-#if defined(__HIP_DEVICE_COMPILE__)
-      v = __builtin_amdgcn_alignbit(hi, lo, s);
-#else
-      v = (lo >> s) | (hi << (32 - s));
-#endif
-    }
-    r.l[i] = v & F28_MASK;
-  }
-}
-// strictly normalised limbs (all < 2^28) and value < 2^384 -> 12 x 32-bit limbs
-KZG_HD void f28_to_bn(fp_t& r, const fp28& a) {
-  KZG_UNROLL_FULL
-  for (int w = 0; w < 12; w++) {
-    const int bit = 32 * w, i = bit / F28_W, s = bit % F28_W;
-    uint64_t v = (uint64_t)a.l[i] >> s;
-    if (i + 1 < F28_N) v |= (uint64_t)a.l[i + 1] << (F28_W - s);
-    if (i + 2 < F28_N && 2 * F28_W - s < 32) v |= (uint64_t)a.l[i + 2] << (2 * F28_W - s);
-    r.v[w] = (uint32_t)v;
-  }
-}
+// ---- representation changes (rdx_mont.cuh) -----------------------------------------------------------
+// 12 x 32-bit limbs (value < 2^384) -> 14 x 28-bit limbs, strictly normalised, and back
+KZG_HD void f28_from_bn(fp28& r, const fp_t& a) { rdx_from_bn<Fp28P, 12>(r, a); }
+KZG_HD void f28_to_bn(fp_t& r, const fp28& a) { rdx_to_bn<Fp28P, 12>(r, a); }
 
 // one carry pass, all limbs at once (no serial chain): limbs 0..12 end up <= 2^28 - 1 + (max limb >> 28)
 KZG_HD void f28_carry_pass(fp28& a) {
@@ -147,152 +85,13 @@ KZG_HD void f28_normalize(fp28& a) {
   a.l[F28_N - 1] += c;
 }
 
-// ---- Montgomery products ------------------------------------------------------------------------
+// ---- Montgomery products (rdx_mont.cuh) -----------------------------------------------------------
 // r = (a*b [+ c*d]) / 2^392 mod p, N-form.  Requires 14*(La*Lb [+ Lc*Ld]) + 14*2^56 < 2^64 for the limb
 // bounds L, and (Va*Vb [+ Vc*Vd]) < 2^11 for the value bounds V in units of p (so the result is < 2p).
-template <bool SQR, bool TWO>
-KZG_HD void f28_mul_core_c(fp28& r, const fp28& a, const fp28& b, const fp28& c, const fp28& d) {
-  uint32_t q[F28_N];
-  uint32_t a2[F28_N];
-  if (SQR) {
-    KZG_UNROLL_FULL
-    for (int i = 0; i < F28_N; i++) {
-      F28_ADDCHK(a.l[i], a.l[i]);
-      a2[i] = a.l[i] << 1;
-    }
-  }
-  F28_COL_INIT(A);
-  KZG_UNROLL_FULL
-  for (int k = 0; k < 2 * F28_N; k++) {
-    const int i0 = (k < F28_N) ? 0 : k - F28_N + 1;
-    const int i1 = (k < F28_N) ? k : F28_N - 1;
-    if (SQR) {
-      KZG_UNROLL_FULL
-      for (int i = i0; i <= i1; i++) {
-        const int j = k - i;
-        if (i < j) F28_MAC(A, a2[i], a.l[j]);
-        if (i == j) F28_MAC(A, a.l[i], a.l[i]);
-      }
-    } else {
-      KZG_UNROLL_FULL
-      for (int i = i0; i <= i1; i++) F28_MAC(A, a.l[i], b.l[k - i]);
-    }
-    if (TWO) {
-      KZG_UNROLL_FULL
-      for (int i = i0; i <= i1; i++) F28_MAC(A, c.l[i], d.l[k - i]);
-    }
-    if (k < F28_N) {
-      KZG_UNROLL_FULL
-      for (int i = 0; i < k; i++) F28_MAC(A, q[i], f28_p(k - i));
-      q[k] = (F28_LO(A) * (uint32_t)KZG_FP28_INV) & F28_MASK;
-      F28_MAC(A, q[k], f28_p(0));
-      F28_SHIFT(A);
-    } else {
-      KZG_UNROLL_FULL
-      for (int i = i0; i <= i1; i++) F28_MAC(A, q[i], f28_p(k - i));
-      if (k < 2 * F28_N - 1) {
-        r.l[k - F28_N] = F28_LO(A) & F28_MASK;  // r may alias an operand: limb k-14 of every operand was last read in column k-1
-        F28_SHIFT(A);
-      } else {
-        r.l[F28_N - 1] = F28_LO(A);  // value < 2p: the top limb is small, nothing above it
-      }
-    }
-  }
-}
-
-#if defined(__HIP_DEVICE_COMPILE__)
-// Device version: every column is issued as explicit v_mad_u64_u32 chains (mac_asm.cuh) that START from the carry of
-// the previous column.  Left to itself hipcc starts each column from zero and adds the carry with an extra
-// v_lshl_add_u64 (26 per product, 5 % of the hot loop).  Same arithmetic as f28_mul_core_c, which the CPU tests run.
-// Columns are template instances so that every operand list has a compile-time length.
-template <bool SQR, bool TWO, int K>
-KZG_HD void f28_column(uint64_t& A, uint32_t* q, fp28& r, const fp28& a, const uint32_t* a2, const fp28& b, const fp28& c, const fp28& d) {
-  constexpr int i0 = (K < F28_N) ? 0 : K - F28_N + 1;
-  constexpr int i1 = (K < F28_N) ? K : F28_N - 1;
-  constexpr int cnt = i1 - i0 + 1;
-  if constexpr (SQR) {
-    // pairs i < j with i + j = K:  i = i0 .. (K-1)/2 ;  diagonal when K is even
-    constexpr int last_pair = (K - 1) / 2;
-    constexpr int npairs = (K >= 1 && last_pair >= i0) ? last_pair - i0 + 1 : 0;
-    constexpr int diag = (K % 2 == 0) ? 1 : 0;
-    uint32_t xs[npairs + diag], ys[npairs + diag];
-    KZG_UNROLL_FULL
-    for (int t = 0; t < npairs; t++) {
-      xs[t] = a2[i0 + t];
-      ys[t] = a.l[K - i0 - t];
-    }
-    if constexpr (diag) {
-      xs[npairs] = a.l[K / 2];
-      ys[npairs] = a.l[K / 2];
-    }
-    mad28_chain<npairs + diag, false>::run(A, xs, ys);
-  } else {
-    uint32_t xs[cnt], ys[cnt];
-    KZG_UNROLL_FULL
-    for (int t = 0; t < cnt; t++) {
-      xs[t] = a.l[i0 + t];
-      ys[t] = b.l[K - i0 - t];
-    }
-    mad28_chain<cnt, false>::run(A, xs, ys);
-  }
-  if constexpr (TWO) {
-    uint32_t xs[cnt], ys[cnt];
-    KZG_UNROLL_FULL
-    for (int t = 0; t < cnt; t++) {
-      xs[t] = c.l[i0 + t];
-      ys[t] = d.l[K - i0 - t];
-    }
-    mad28_chain<cnt, false>::run(A, xs, ys);
-  }
-  if constexpr (K < F28_N) {
-    if constexpr (K > 0) {
-      uint32_t qs[K], ps[K];
-      KZG_UNROLL_FULL
-      for (int t = 0; t < K; t++) {
-        qs[t] = q[t];
-        ps[t] = f28_p(K - t);
-      }
-      mad28_chain<K, true>::run(A, qs, ps);
-    }
-    q[K] = ((uint32_t)A * (uint32_t)KZG_FP28_INV) & F28_MASK;
-    const uint32_t p0 = f28_p(0);
-    mad28_chain<1, true>::run(A, &q[K], &p0);
-    A >>= F28_W;
-  } else {
-    uint32_t qs[cnt], ps[cnt];
-    KZG_UNROLL_FULL
-    for (int t = 0; t < cnt; t++) {
-      qs[t] = q[i0 + t];
-      ps[t] = f28_p(K - i0 - t);
-    }
-    mad28_chain<cnt, true>::run(A, qs, ps);
-    r.l[K - F28_N] = (uint32_t)A & F28_MASK;  // r may alias an operand: limb K-14 of every operand was last read in column K-1
-    A >>= F28_W;
-  }
-  if constexpr (K + 1 < 2 * F28_N - 1) f28_column<SQR, TWO, K + 1>(A, q, r, a, a2, b, c, d);
-}
-template <bool SQR, bool TWO>
-KZG_HD void f28_mul_core(fp28& r, const fp28& a, const fp28& b, const fp28& c, const fp28& d) {
-  uint32_t q[F28_N];
-  uint32_t a2[F28_N];
-  if (SQR) {
-    KZG_UNROLL_FULL
-    for (int i = 0; i < F28_N; i++) a2[i] = a.l[i] << 1;
-  }
-  uint64_t A = 0;
-  f28_column<SQR, TWO, 0>(A, q, r, a, a2, b, c, d);
-  r.l[F28_N - 1] = (uint32_t)A;  // column 27 holds only the carry; value < 2p: the top limb is small
-}
-#else
-template <bool SQR, bool TWO>
-KZG_HD void f28_mul_core(fp28& r, const fp28& a, const fp28& b, const fp28& c, const fp28& d) {
-  f28_mul_core_c<SQR, TWO>(r, a, b, c, d);
-}
-#endif
-KZG_HD void f28_mul(fp28& r, const fp28& a, const fp28& b) { f28_mul_core<false, false>(r, a, b, a, b); }
-KZG_HD void f28_sqr(fp28& r, const fp28& a) { f28_mul_core<true, false>(r, a, a, a, a); }
+KZG_HD void f28_mul(fp28& r, const fp28& a, const fp28& b) { rdx_mul_core<Fp28P, false, false>(r, a, b, a, b); }
+KZG_HD void f28_sqr(fp28& r, const fp28& a) { rdx_mul_core<Fp28P, true, false>(r, a, a, a, a); }
 // r = (a*b + c*d) / 2^392: two products, ONE reduction
-KZG_HD void f28_mul2(fp28& r, const fp28& a, const fp28& b, const fp28& c, const fp28& d) { f28_mul_core<false, true>(r, a, b, c, d); }
+KZG_HD void f28_mul2(fp28& r, const fp28& a, const fp28& b, const fp28& c, const fp28& d) { rdx_mul_core<Fp28P, false, true>(r, a, b, c, d); }
 
 // ---- carry-free add / subtract ------------------------------------------------------------------
 KZG_HD void f28_add(fp28& r, const fp28& a, const fp28& b) {

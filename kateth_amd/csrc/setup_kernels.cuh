@@ -1,6 +1,7 @@
 // Context-creation kernels: what Setup::load_json does after parsing
 // (src/kzg/setup.rs:52-81) plus the fixed-base table build of msm_fixed.cuh.
 #pragma once
+#include "fr29.cuh"
 #include "msm_fixed.cuh"
 
 namespace kzg {
@@ -109,6 +110,38 @@ static __global__ __launch_bounds__(64) void k_table_normalize(const g1_xyzz* __
       store_affine96(table, table_off + first + k, x, y);
     }
   }
+}
+
+// one thread per pair: builds eval_tab from the Montgomery (radix 2^256) roots
+static __global__ __launch_bounds__(64) void k_setup_eval_tab(const fr_t* __restrict__ roots_brp, uint32_t* __restrict__ eval_tab) {
+  const uint32_t pr = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pr >= 2048) return;
+  const fr_t w = roots_brp[2 * pr];
+  fr_t c261, c522, t;
+  {
+    const uint32_t a[8] = KZG_FR_R261_PLAIN, b[8] = KZG_FR_R522_PLAIN;
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      c261.v[q] = a[q];
+      c522.v[q] = b[q];
+    }
+  }
+  fr29 o;
+  uint32_t* out = eval_tab + (uint64_t)pr * EVAL_TAB_DWORDS;
+  fr_mul(t, w, c261);  // (w 2^256)(2^261) / 2^256 = w 2^261
+  f29_from_bn(o, t);
+#pragma unroll
+  for (int q = 0; q < F29_N; q++) out[q] = o.l[q];
+  fr_mul(t, w, c522);
+  f29_from_bn(o, t);
+#pragma unroll
+  for (int q = 0; q < F29_N; q++) out[9 + q] = o.l[q];
+  fr_sqr(t, w);
+  fr_mul(t, t, c261);
+  f29_from_bn(o, t);
+#pragma unroll
+  for (int q = 0; q < F29_N; q++) out[18 + q] = o.l[q];
+  out[27] = 0;
 }
 
 // roots_of_unity_brp (src/math.rs:16-29 + BRP, src/kzg/setup.rs:74-75), Montgomery form.

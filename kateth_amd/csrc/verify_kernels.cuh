@@ -2,6 +2,7 @@
 // src/kzg/setup.rs:223-275 and Setup::verify_proof_batch, :115-161).
 #pragma once
 #include "blob_kernels.cuh"
+#include "fr29.cuh"
 #include "msm_fixed.cuh"
 
 namespace kzg {
@@ -20,32 +21,39 @@ namespace kzg {
 // Because prod_i (z - w_i) = z^4096 - 1, the merged denominator cancels the
 // barycentric factor and y = N / 4096: the whole evaluation needs no inversion.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ fr_t shfl_down_fr(const fr_t& a, int delta) {
-  fr_t r;
+// The arithmetic runs in the carry-free radix-2^29 representation of Fr (fr29.cuh, Montgomery radix R = 2^261).
+// Bit-reversed order puts w and -w next to each other (roots_brp[2k+1] = -roots_brp[2k]), so a PAIR of elements
+// contributes
+//   e0 w/(z - w) - e1 w/(z + w) = w [ (e0 - e1) z + (e0 + e1) w ] / (z^2 - w^2)
+// and per pair the kernel does 6 products with only 4 reductions:
+//   u  = ((e0 - e1) * zR + (e0 + e1) * wR) / R           plain, one reduction for two products
+//   a  = (u * wR^2) / R = (u w) R                         Montgomery
+//   N' = (N * d + a * D) / R,  D' = (D * d) / R           d = z^2 R - w^2 R (a limb-wise subtraction)
+// eval_tab[pr] = { w R, w R^2, w^2 R } as 3 x 9 limbs (28 dwords with padding), w = roots_brp[2 pr].
+__device__ __forceinline__ fr29 shfl_down_fr29(const fr29& a, int delta) {
+  fr29 r;
 #pragma unroll
-  for (int q = 0; q < 8; q++) r.v[q] = __shfl_down(a.v[q], delta, 64);
+  for (int q = 0; q < F29_N; q++) r.l[q] = __shfl_down(a.l[q], delta, 64);
   return r;
 }
-
 static __global__ __launch_bounds__(64) void k_eval_frac(const uint8_t* __restrict__ blobs, const fr_t* __restrict__ z_plain,
-                                                         const fr_t* __restrict__ roots_brp, const fr_t* __restrict__ roots_r2,
-                                                         const fr_t* __restrict__ roots_sq, fr_t* __restrict__ y_plain,
-                                                         int32_t* __restrict__ status) {
-  // Bit-reversed order puts w and -w next to each other (roots_brp[2k+1] = -roots_brp[2k]), so a
-  // PAIR of elements contributes
-  //   e0 w/(z - w) - e1 w/(z + w) = w [ (e0 - e1) z + (e0 + e1) w ] / (z^2 - w^2)
-  // : 3 multiplies for the numerator (the denominator is a subtraction from the precomputed
-  // w^2 table) + 3 for the fraction update = 3 Fr multiplies per element instead of 4.
-  // Montgomery bookkeeping: e0, e1 are plain; mont_mul(plain, X*R) = plain*X (plain), and
-  // mont_mul(plain, X*R^2) = plain*X*R (Montgomery).
+                                                         const fr_t* __restrict__ roots_brp, const uint32_t* __restrict__ eval_tab,
+                                                         fr_t* __restrict__ y_plain, int32_t* __restrict__ status) {
   const int lane = threadIdx.x;
   const uint64_t b = blockIdx.x;
   const uint8_t* blob = blobs + b * 131072ull;
-  fr_t z, z2;
-  to_mont<FrParams>(z, z_plain[b]);
-  fr_sqr(z2, z);
-  fr_t N, D = fr_one(), e_dom;
-  bn_zero(N);
+  fr29 z, z2;
+  {
+    fr29 zp;
+    f29_from_bn(zp, z_plain[b]);
+    f29_to_mont(z, zp);  // N-form
+    f29_sqr(z2, z);
+  }
+  // lane fraction N/D: both N-form between steps
+  fr29 N, D = f29_const_one();
+  KZG_UNROLL_FULL
+  for (int q = 0; q < F29_N; q++) N.l[q] = 0;
+  fr_t e_dom;
   bn_zero(e_dom);
   bool bad = false;
   int dom = -1;
@@ -68,42 +76,51 @@ static __global__ __launch_bounds__(64) void k_eval_frac(const uint8_t* __restri
       bad = true;
       bn_zero(e1);
     }
-    const fr_t w = roots_brp[2 * pr];
-    fr_t d;
-    fr_sub(d, z2, roots_sq[pr]);  // z^2 - w^2
-    if (bn_is_zero(d)) {          // z == w or z == -w: the evaluation is that element (poly.rs:14-18)
-      fr_t t;
-      fr_sub(t, z, w);
-      if (bn_is_zero(t)) {
-        dom = 2 * pr;
-        e_dom = e0;
-      } else {
-        dom = 2 * pr + 1;
-        e_dom = e1;
+    fr29 w, wr2, wsq;
+    {
+      const uint4* t = reinterpret_cast<const uint4*>(eval_tab + (uint64_t)pr * EVAL_TAB_DWORDS);
+      const uint4 t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3], t4 = t[4], t5 = t[5], t6 = t[6];
+      const uint32_t f[28] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w, t2.x, t2.y, t2.z, t2.w, t3.x, t3.y,
+                              t3.z, t3.w, t4.x, t4.y, t4.z, t4.w, t5.x, t5.y, t5.z, t5.w, t6.x, t6.y, t6.z, t6.w};
+#pragma unroll
+      for (int q = 0; q < F29_N; q++) {
+        w.l[q] = f[q];
+        wr2.l[q] = f[9 + q];
+        wsq.l[q] = f[18 + q];
       }
-      continue;
     }
-    fr_t sm, df, u, v, a, t;
-    fr_add(sm, e0, e1);
-    fr_sub(df, e0, e1);
-    fr_mul(u, df, z);  // plain (e0 - e1) z
-    fr_mul(v, sm, w);  // plain (e0 + e1) w
-    fr_add(u, u, v);
-    fr_mul(a, u, roots_r2[2 * pr]);  // Montgomery  w [ ... ]
-    fr_mul(t, a, D);
-    fr_mul(N, N, d);
-    fr_add(N, N, t);
-    fr_mul(D, D, d);
+    fr29 d;
+    f29_sub_2r(d, z2, wsq);  // z^2 - w^2: limbs < 3*2^29, value < 4r
+    if (f29_maybe_zero(d)) {
+      if (f29_is_zero_exact(d)) {  // z == w or z == -w: the evaluation is that element (poly.rs:14-18)
+        fr29 t;
+        f29_sub_2r(t, z, w);
+        if (f29_is_zero_exact(t)) {
+          dom = 2 * pr;
+          e_dom = e0;
+        } else {
+          dom = 2 * pr + 1;
+          e_dom = e1;
+        }
+        continue;
+      }
+    }
+    fr29 x0, x1, sm, df, u, a;
+    f29_from_bn(x0, e0);
+    f29_from_bn(x1, e1);
+    f29_add(sm, x0, x1);      // limbs < 2^30, value < 2r
+    f29_sub_2r(df, x0, x1);   // limbs < 3*2^29, value < 3r
+    f29_mul2(u, df, z, sm, w);  // 9*(3 + 2)*2^58 + 9*2^58 = 54*2^58 < 2^64;  plain (e0-e1) z + (e0+e1) w
+    f29_mul(a, u, wr2);
+    f29_mul2(N, N, d, a, D);  // 9*(3 + 1)*2^58 + 9*2^58
+    f29_mul(D, D, d);
   }
   // merge lane fractions: (N1/D1) + (N2/D2) = (N1 D2 + N2 D1) / (D1 D2)
 #pragma unroll 1
   for (int delta = 32; delta >= 1; delta >>= 1) {
-    fr_t N2 = shfl_down_fr(N, delta), D2 = shfl_down_fr(D, delta);
-    fr_t t1, t2;
-    fr_mul(t1, N, D2);
-    fr_mul(t2, N2, D);
-    fr_add(N, t1, t2);
-    fr_mul(D, D, D2);
+    const fr29 N2 = shfl_down_fr29(N, delta), D2 = shfl_down_fr29(D, delta);
+    f29_mul2(N, N, D2, N2, D);
+    f29_mul(D, D, D2);
   }
   int dom_any = dom;
 #pragma unroll
@@ -119,14 +136,11 @@ static __global__ __launch_bounds__(64) void k_eval_frac(const uint8_t* __restri
 #pragma unroll
     for (int q = 0; q < 8; q++) y.v[q] = __shfl(e_dom.v[q], owner, 64);  // already plain
   } else {
-    fr_t f;
-    {
-      const uint32_t c4096[8] = KZG_FR_INV4096_MONT;
-#pragma unroll
-      for (int q = 0; q < 8; q++) f.v[q] = c4096[q];
-    }
-    fr_mul(y, N, f);
-    from_mont<FrParams>(y, y);
+    fr29 f, t;
+    KZG_UNROLL_FULL
+    for (int q = 0; q < F29_N; q++) f.l[q] = f29_inv4096_limb(q);
+    f29_mul(t, N, f);  // (N R)(1/4096) / R: plain
+    f29_to_canonical_bn(y, t);
   }
   if (lane == 0) y_plain[b] = y;
   if (__any(bad) && lane == 0) atomicOr(&status[b], KZG_ERR_BLOB_INVALID_FIELD_ELEMENT);

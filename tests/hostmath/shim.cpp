@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #define KZG_FP28_CHECK 1
 #include "../../kateth_amd/csrc/fp28.cuh"
+#include "../../kateth_amd/csrc/fr29.cuh"
 #include "../../kateth_amd/csrc/sha256.cuh"
 
 using namespace kzg;
@@ -304,4 +305,60 @@ extern "C" int32_t hm_g1_sum28(uint8_t* out48, const uint8_t* pts48, const uint8
   xyzz28_to_xyzz(r, acc);
   g1_compress_xyzz(out48, r);
   return 0;
+}
+
+// ---- radix-2^29 Fr of the verification's evaluation kernel (kateth_amd/csrc/fr29.cuh) ---------------
+static void f29_in(fr29& r, const uint8_t* a32, bool mont) {  // plain value -> 9 x 29 limbs (optionally x 2^261)
+  fr_t x;
+  load_le(x, a32);
+  f29_from_bn(r, x);
+  if (mont) f29_to_mont(r, r);
+}
+// op 0: a*b (Montgomery), 1: a^2, 2: a*b + c*d, 3: round trip, 4: plain a + 2r - b then reduced through a product,
+// 5: is_zero(a + 2r - b) -> out[0], 6: the pair update of k_eval_frac (see tests)
+extern "C" void hm_f29_op(int op, uint8_t* out32, const uint8_t* a32, const uint8_t* b32, const uint8_t* c32, const uint8_t* d32) {
+  fr29 a, b, c, d, r;
+  fr_t o;
+  if (op == 3) {
+    f29_in(a, a32, false);
+    f29_to_bn(o, a);
+    store_le(out32, o);
+    return;
+  }
+  if (op == 4 || op == 5) {
+    f29_in(a, a32, true);
+    f29_in(b, b32, false);
+    fr29 bm;
+    f29_to_mont(bm, b);
+    fr_t bc;
+    f29_to_canonical_bn(bc, bm);  // canonical Montgomery b
+    f29_from_bn(bm, bc);
+    f29_sub_2r(r, a, bm);
+    if (op == 5) {
+      memset(out32, 0, 32);
+      out32[0] = (f29_maybe_zero(r) && f29_is_zero_exact(r)) ? 1 : 0;
+      return;
+    }
+    fr29 one;
+    for (int i = 0; i < F29_N; i++) one.l[i] = i == 0 ? 1u : 0u;
+    f29_mul(r, r, one);  // out of Montgomery form
+    f29_to_canonical_bn(o, r);
+    store_le(out32, o);
+    return;
+  }
+  f29_in(a, a32, true);
+  f29_in(b, b32, true);
+  f29_in(c, c32, true);
+  f29_in(d, d32, true);
+  switch (op) {
+    case 0: f29_mul(r, a, b); break;
+    case 1: f29_sqr(r, a); break;
+    case 2: f29_mul2(r, a, b, c, d); break;
+    default: r = a;
+  }
+  fr29 one;
+  for (int i = 0; i < F29_N; i++) one.l[i] = i == 0 ? 1u : 0u;
+  f29_mul(r, r, one);
+  f29_to_canonical_bn(o, r);
+  store_le(out32, o);
 }

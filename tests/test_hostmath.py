@@ -303,3 +303,29 @@ def test_fp28_madd_complete(hm):
         n = rnd.randrange(1, 30)
         run([rnd.randrange(48) for _ in range(n)], [rnd.randrange(2) for _ in range(n)])
     assert hm.hm_f28_violations() == 0
+
+
+def _f29(hm, op, a, b=0, c=0, d=0):
+    out = ctypes.create_string_buffer(32)
+    hm.hm_f29_op(op, out, *(int(v).to_bytes(32, "little") for v in (a, b, c, d)))
+    return out.raw
+
+
+def test_fr29_field_ops(hm):
+    """9 x 29-bit limb Montgomery arithmetic for Fr (radix 2^261) against Python integers, with the 128-bit column and
+    limb-subtraction checks of the CPU build armed"""
+    rnd = random.Random(2929)
+    edge = [0, 1, 2, R - 1, R - 2, (R - 1) // 2, 1 << 254, (1 << 29) - 1, (1 << 261) % R, R - ((1 << 261) % R), 4096, pow(4096, -1, R)]
+    vals = edge + [rnd.randrange(R) for _ in range(60)]
+    for a in vals:
+        assert int.from_bytes(_f29(hm, 3, a), "little") == a
+        assert int.from_bytes(_f29(hm, 1, a), "little") == a * a % R
+    for _ in range(300):
+        a, b, c, d = (rnd.choice(vals) for _ in range(4))
+        assert int.from_bytes(_f29(hm, 0, a, b), "little") == a * b % R
+        assert int.from_bytes(_f29(hm, 2, a, b, c, d), "little") == (a * b + c * d) % R
+        assert int.from_bytes(_f29(hm, 4, a, b), "little") == (a - b) % R
+        assert _f29(hm, 5, a, b)[0] == (1 if a == b else 0)
+    for a in vals:
+        assert _f29(hm, 5, a, a)[0] == 1
+    assert hm.hm_f28_violations() == 0
