@@ -2,7 +2,7 @@
 // challenge (K4), barycentric evaluation (K5), quotient polynomial (K6),
 // point decompression (K7).  See each kernel for the reference lines it replaces.
 #pragma once
-#include "g1.cuh"
+#include "g1_decode28.cuh"
 #include "sha256.cuh"
 
 namespace kzg {
@@ -86,7 +86,7 @@ static __global__ __launch_bounds__(64) void k_g1_decompress(const uint8_t* __re
   }
   fp_t x, y;
   bool is_inf = false;
-  int32_t st = g1_decompress(x, y, is_inf, buf);
+  int32_t st = g1_decompress28(x, y, is_inf, buf);  // radix-2^28 field path (g1_decode28.cuh)
   (second ? status_b : status_a)[i] = st;
   if (affine != nullptr) {
     if (st != 0 || is_inf) {

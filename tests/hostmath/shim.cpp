@@ -9,6 +9,7 @@
 #define KZG_FP28_CHECK 1
 #include "../../kateth_amd/csrc/fp28.cuh"
 #include "../../kateth_amd/csrc/fr29.cuh"
+#include "../../kateth_amd/csrc/g1_decode28.cuh"
 #include "../../kateth_amd/csrc/sha256.cuh"
 
 using namespace kzg;
@@ -361,4 +362,22 @@ extern "C" void hm_f29_op(int op, uint8_t* out32, const uint8_t* a32, const uint
   f29_mul(r, r, one);
   f29_to_canonical_bn(o, r);
   store_le(out32, o);
+}
+
+// ---- point decoding in the radix-2^28 representation (kateth_amd/csrc/g1_decode28.cuh) ------------------
+// returns g1_decompress28's status in the low byte and g1_decompress's (the 12 x 32-bit-limb reference path) in the
+// next byte; out48 = re-encoding of what the radix-2^28 path decoded; bit 16 set if the two paths' (x, y) differ
+extern "C" int32_t hm_g1_decompress28(uint8_t* out48, const uint8_t* in48) {
+  fp_t x, y, x0, y0;
+  bool inf = false, inf0 = false;
+  const int32_t st = g1_decompress28(x, y, inf, in48);
+  const int32_t st0 = g1_decompress(x0, y0, inf0, in48);
+  int32_t diff = 0;
+  if (st == 0 && st0 == 0) {
+    if (inf != inf0 || !bn_eq(x, x0) || !bn_eq(y, y0)) diff = 1 << 16;
+    g1_compress_affine(out48, x, y, inf);
+  } else {
+    memset(out48, 0, 48);
+  }
+  return (st & 0xff) | ((st0 & 0xff) << 8) | diff;
 }

@@ -329,3 +329,58 @@ def test_fr29_field_ops(hm):
     for a in vals:
         assert _f29(hm, 5, a, a)[0] == 1
     assert hm.hm_f28_violations() == 0
+
+
+def test_g1_decompress_radix28_matches_reference_path(hm):
+    """g1_decompress28 (square root, sign choice and subgroup test in the radix-2^28 field) against g1_decompress
+    (12 x 32-bit limbs) and the oracle: same status codes, same decoded coordinates, on members, non-members of every
+    kind, both signs, infinity and malformed encodings; the CPU build's 128-bit bound checks stay armed"""
+    rnd = random.Random(2828)
+    out = ctypes.create_string_buffer(48)
+
+    def both(enc):
+        rc = hm.hm_g1_decompress28(out, enc)
+        assert rc >> 16 == 0, "decoded coordinates differ"
+        assert rc & 0xFF == (rc >> 8) & 0xFF, "status codes differ: %x" % rc
+        return rc & 0xFF
+
+    for k in (1, 2, 3, R - 1, R - 2) + tuple(rnd.randrange(R) for _ in range(12)):
+        pt = bls.g1_mul(bls.G1_GEN, k)
+        for q in (pt, bls.g1_neg(pt)):
+            enc = bls.g1_compress(q)
+            assert both(enc) == 0 and out.raw == enc
+    assert both(bls.g1_compress(None)) == 0 and out.raw == bls.g1_compress(None)
+    gen = bls.g1_compress(bls.G1_GEN)
+    assert both(bytes([gen[0] & 0x7F]) + gen[1:]) == 3
+    assert both(bytes([0x9A]) + bytes([0xFF] * 47)) == 3
+    assert both(bytes([0xE0]) + bytes(47)) == 3
+    assert both(bytes([0xC0]) + bytes(46) + b"\x01") == 3
+    pb = P.to_bytes(48, "big")
+    assert both(bytes([0x80 | pb[0]]) + pb[1:]) == 3  # x == p is not canonical
+    # x with no y; points on the curve outside the subgroup (several, both signs); member + cofactor component
+    found_nc = found_ns = 0
+    x = 1
+    last_ns = None
+    while found_nc < 4 or found_ns < 6:
+        y = bls._fp_sqrt(x**3 + 4)
+        if y is None:
+            if found_nc < 4:
+                assert both(bytes([0x80]) + x.to_bytes(48, "big")[1:]) == 4
+                found_nc += 1
+        elif not bls.g1_in_subgroup((x, y)):
+            if found_ns < 6:
+                assert both(bls.g1_compress((x, y))) == 5
+                assert both(bls.g1_compress((x, P - y))) == 5
+                found_ns += 1
+                last_ns = (x, y)
+        x += 1
+    t = bls.g1_mul_unreduced(last_ns, R)  # lands in the cofactor part
+    if t is not None:
+        assert both(bls.g1_compress(bls.g1_add(bls.g1_mul(bls.G1_GEN, 777), t))) == 5
+        assert both(bls.g1_compress(t)) == 5
+        # small-order points: multiply further by cofactor factors until the order is tiny
+        for f in (3, 11, 11 * 3, 10177, 859267):
+            s = bls.g1_mul_unreduced(t, f)
+            if s is not None:
+                assert both(bls.g1_compress(s)) == 5
+    assert hm.hm_f28_violations() == 0
