@@ -144,6 +144,7 @@ struct MsmVarJob {
   uint8_t* buf = nullptr;
   bool owns_buf = false;
   std::vector<g1_xyzz> win;
+  const g1_xyzz* d_win = nullptr;
   hipStream_t st = nullptr;
   bool active = false;
 };
@@ -182,7 +183,9 @@ static int32_t msm_var_launch(MsmVarJob& job, const uint4* d_points, const uint8
   hipLaunchKernelGGL(k_var_fold, dim3(blocks_for((uint64_t)nb * K, 64)), dim3(64), 0, st, bpart, nb, K, bsum);
   hipLaunchKernelGGL(k_var_windows, dim3(g.W), dim3(64), 0, st, bsum, g, winsum);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(job.win.data(), winsum, (size_t)g.W * sizeof(g1_xyzz), hipMemcpyDeviceToHost, st));
+  // the window sums are read back in msm_var_finish: a device-to-host copy into pageable memory blocks the host
+  // until the stream has drained, which would keep a second job from being enqueued beside this one
+  job.d_win = winsum;
   return 0;
 }
 
@@ -190,7 +193,9 @@ static int32_t msm_var_finish(MsmVarJob& job, g1_xyzz& result) {
   xyzz_set_inf(result);
   if (!job.active) return 0;
   int32_t rc = 0;
-  if (hipStreamSynchronize(job.st) != hipSuccess) rc = fail(KZG_FAIL_HIP, "variable-base MSM synchronize failed");
+  if (hipMemcpyAsync(job.win.data(), job.d_win, (size_t)job.g.W * sizeof(g1_xyzz), hipMemcpyDeviceToHost, job.st) != hipSuccess ||
+      hipStreamSynchronize(job.st) != hipSuccess)
+    rc = fail(KZG_FAIL_HIP, "variable-base MSM read-back failed");
   if (rc == 0) host_horner(result, job.win, job.g);
   if (job.owns_buf) (void)hipFree(job.buf);
   job.buf = nullptr;

@@ -9,8 +9,8 @@ def main(path, detail=()):
     s = open(path).read()
     for name in re.findall(r"^(_Z\w+):", s, flags=re.M):
         a = s.index("\n" + name + ":")
-        b = s.find("s_endpgm", a)
-        body = s[a:b]
+        b = s.find(".Lfunc_end", a)  # closes kernels and device functions alike
+        body = s[a:b if b > 0 else len(s)]
         ins = []
         for l in body.split("\n"):
             t = l.strip()
