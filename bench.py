@@ -277,7 +277,7 @@ def main():
             "algorithmic_bytes_per_blob": ALG_BYTES_COMMIT,
             "note": "integer-ALU bound, not HBM bound: see valu_* fields and DESIGN.md section 5",
             "table_gather_bytes_per_blob": adds_per_blob * 96,
-            "valu_fp_mul_per_s": (adds_per_blob * 10 * n / (k_ms * 1e-3)) if k_ms > 0 else None,
+            "valu_fp_mul_per_s": (adds_per_blob * 10 * n / (k_ms * 1e-3)) if k_ms > 0 else None,  # 10 products per mixed add
             "valu_fp_mul_peak_per_s": prof.get("fp_mul_peak_per_s"),
         }
         if result["roofline"]["valu_fp_mul_peak_per_s"]:
