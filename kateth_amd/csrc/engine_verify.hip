@@ -305,6 +305,7 @@ extern "C" int32_t kzg_verify_phase1_dev(const kzg_ctx* ctx, const void* d_blobs
         (void)hipEventRecord(ev_fork, st);
         (void)hipStreamWaitEvent(side, ev_fork, 0);
       }
+      if (!small && getenv("KATETH_AMD_VERIFY_SERIAL")) side = st;  // measurement aid: decode and evaluate back to back on one stream
       hipLaunchKernelGGL(k_g1_decompress, dim3(blocks_for(2 * n, 64)), dim3(64), 0, side, prf, n, stat + 2 * n, com, n, stat + n, s->aff, s->inf);
       (void)hipEventRecord(ev_join, side);
       hipLaunchKernelGGL(k_eval_frac, dim3((unsigned)n), dim3(64), 0, st, blobs, s->z, ctx->d_roots_brp, ctx->d_eval_tab, s->y, stat);

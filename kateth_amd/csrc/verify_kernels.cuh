@@ -57,17 +57,32 @@ static __global__ __launch_bounds__(64) void k_eval_frac(const uint8_t* __restri
   bn_zero(e_dom);
   bool bad = false;
   int dom = -1;
+  // the blob elements come from HBM (each byte is read exactly once): the next pair is in flight while this one is
+  // processed; the table entry is L2-resident and loaded where it is used
+  uint4 nb0, nb1, nb2, nb3;
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(blob + (uint64_t)lane * 64u);
+    nb0 = src[0];
+    nb1 = src[1];
+    nb2 = src[2];
+    nb3 = src[3];
+  }
 #pragma unroll 1
   for (int k = 0; k < 32; k++) {
     const int pr = k * 64 + lane;  // pair index: elements 2*pr, 2*pr + 1 (64 contiguous bytes)
-    uint32_t sc[8];
-    fr_t e0, e1;
-    load_scalar_be_(sc, blob + (uint64_t)pr * 64u);
-#pragma unroll
-    for (int q = 0; q < 8; q++) e0.v[q] = sc[q];
-    load_scalar_be_(sc, blob + (uint64_t)pr * 64u + 32u);
-#pragma unroll
-    for (int q = 0; q < 8; q++) e1.v[q] = sc[q];
+    const uint4 b0 = nb0, b1 = nb1, b2 = nb2, b3 = nb3;
+    if (k + 1 < 32) {
+      const uint4* src = reinterpret_cast<const uint4*>(blob + (uint64_t)(pr + 64) * 64u);
+      nb0 = src[0];
+      nb1 = src[1];
+      nb2 = src[2];
+      nb3 = src[3];
+    }
+    fr_t e0, e1;  // 32 big-endian bytes -> 8 little-endian limbs
+    e0.v[7] = __builtin_bswap32(b0.x); e0.v[6] = __builtin_bswap32(b0.y); e0.v[5] = __builtin_bswap32(b0.z); e0.v[4] = __builtin_bswap32(b0.w);
+    e0.v[3] = __builtin_bswap32(b1.x); e0.v[2] = __builtin_bswap32(b1.y); e0.v[1] = __builtin_bswap32(b1.z); e0.v[0] = __builtin_bswap32(b1.w);
+    e1.v[7] = __builtin_bswap32(b2.x); e1.v[6] = __builtin_bswap32(b2.y); e1.v[5] = __builtin_bswap32(b2.z); e1.v[4] = __builtin_bswap32(b2.w);
+    e1.v[3] = __builtin_bswap32(b3.x); e1.v[2] = __builtin_bswap32(b3.y); e1.v[1] = __builtin_bswap32(b3.z); e1.v[0] = __builtin_bswap32(b3.w);
     if (!fr_is_canonical(e0)) {
       bad = true;
       bn_zero(e0);
