@@ -176,7 +176,10 @@ int32_t kzg_microbench_fp_mul(const kzg_ctx* ctx, uint64_t lanes, uint64_t iters
  * On-device self-test of the hand-scheduled multiply: every lane multiplies
  * `iters` pseudo-random operand pairs with the inline-asm v_mad_u64_u32 chains
  * and with a plain-C multiply the compiler schedules (hazard wait states and
- * all); *mismatches counts disagreements (Fp and Fr).  Expected: 0.
+ * all); *mismatches counts disagreements (Fp and Fr).  The same operands also go
+ * through the carry-free radix-2^28 (Fp) and radix-2^29 (Fr) multipliers of the
+ * hot loops (product, squaring, two products with one reduction) and must agree
+ * with the 32-bit-limb result.  Expected: 0.
  */
 int32_t kzg_selftest_field_mul(const kzg_ctx* ctx, uint64_t lanes, uint64_t iters, uint64_t* mismatches);
 

@@ -430,6 +430,85 @@ __device__ __forceinline__ uint32_t selftest_one(uint64_t& rng) {
   return bn_eq(r1, r2) ? 0u : 1u;
 }
 
+// The carry-free radix-2^28 / 2^29 multipliers of the hot loops (explicit v_mad_u64_u32 chains, fp28.cuh / fr29.cuh)
+// against the 32-bit-limb multiplier on the same operands: a*b*2^-392 is brought to a*b*2^-384 with one more
+// product by 2^400 (Fr: 2^-261 -> 2^-256 by 2^266), then the canonical limbs must be equal.  Covers f28_mul, f28_sqr,
+// f28_mul2 (as a*b + b*a = 2ab), f29_mul, f29_sqr, f29_mul2.
+__device__ __forceinline__ void selftest_operand(uint64_t& rng, uint32_t* v, int n, uint32_t top_mask) {
+  for (int q = 0; q < n; q++) {
+    rng ^= rng << 13;
+    rng ^= rng >> 7;
+    rng ^= rng << 17;
+    v[q] = (uint32_t)(rng >> 16);
+  }
+  v[n - 1] &= top_mask;
+}
+__device__ __noinline__ uint32_t selftest_radix(uint64_t& rng) {
+  uint32_t bad = 0;
+  {
+    fp_t a, b, want, want2, got;
+    selftest_operand(rng, a.v, 12, 0x0fffffffu);  // < 2^380 < p
+    selftest_operand(rng, b.v, 12, 0x0fffffffu);
+    if ((rng & 7) == 0) b = a;
+    mont_mul<FpParams>(want, a, b);
+    add_mod<FpParams>(want2, want, want);
+    fp28 A, B, k, x;
+    f28_from_bn(A, a);
+    f28_from_bn(B, b);
+    {
+      const uint32_t t[F28_N] = KZG_FP28_R400;
+#pragma unroll
+      for (int q = 0; q < F28_N; q++) k.l[q] = t[q];
+    }
+    f28_mul(x, A, B);
+    f28_mul(x, x, k);
+    f28_to_bn(got, x);
+    canonicalize<FpParams>(got);
+    bad += bn_eq(got, want) ? 0u : 1u;
+    f28_mul2(x, A, B, B, A);
+    f28_mul(x, x, k);
+    f28_to_bn(got, x);
+    canonicalize<FpParams>(got);
+    bad += bn_eq(got, want2) ? 0u : 1u;
+    mont_mul<FpParams>(want, a, a);
+    f28_sqr(x, A);
+    f28_mul(x, x, k);
+    f28_to_bn(got, x);
+    canonicalize<FpParams>(got);
+    bad += bn_eq(got, want) ? 0u : 1u;
+  }
+  {
+    fr_t a, b, want, want2, got;
+    selftest_operand(rng, a.v, 8, 0x3fffffffu);  // < 2^254 < r
+    selftest_operand(rng, b.v, 8, 0x3fffffffu);
+    if ((rng & 7) == 0) b = a;
+    mont_mul<FrParams>(want, a, b);
+    add_mod<FrParams>(want2, want, want);
+    fr29 A, B, k, x;
+    f29_from_bn(A, a);
+    f29_from_bn(B, b);
+    {
+      const uint32_t t[F29_N] = KZG_FR29_R266;
+#pragma unroll
+      for (int q = 0; q < F29_N; q++) k.l[q] = t[q];
+    }
+    f29_mul(x, A, B);
+    f29_mul(x, x, k);
+    f29_to_canonical_bn(got, x);
+    bad += bn_eq(got, want) ? 0u : 1u;
+    f29_mul2(x, A, B, B, A);
+    f29_mul(x, x, k);
+    f29_to_canonical_bn(got, x);
+    bad += bn_eq(got, want2) ? 0u : 1u;
+    mont_mul<FrParams>(want, a, a);
+    f29_sqr(x, A);
+    f29_mul(x, x, k);
+    f29_to_canonical_bn(got, x);
+    bad += bn_eq(got, want) ? 0u : 1u;
+  }
+  return bad;
+}
+
 __global__ __launch_bounds__(64) void k_selftest_field_mul(uint64_t iters, unsigned long long* mismatches) {
   uint64_t rng = 0x9E3779B97F4A7C15ull * (blockIdx.x * 64ull + threadIdx.x + 1);
   uint32_t bad = 0;
@@ -437,6 +516,7 @@ __global__ __launch_bounds__(64) void k_selftest_field_mul(uint64_t iters, unsig
   for (uint64_t it = 0; it < iters; it++) {
     bad += selftest_one<FpParams>(rng);
     bad += selftest_one<FrParams>(rng);
+    bad += selftest_radix(rng);
   }
   if (bad) atomicAdd(mismatches, (unsigned long long)bad);
 }

@@ -21,8 +21,6 @@ KZG_F28_TABLE(f28_b_limb, KZG_FP28_B)
 KZG_F28_TABLE(f28_beta_limb, KZG_FP28_BETA)
 #undef KZG_F28_TABLE
 
-// a == 0 (mod p) for 0 <= a < 2^11 p
-KZG_HD bool f28_is_zero(const fp28& a) { return f28_maybe_zero(a) && f28_is_zero_exact(a); }
 
 // r = a^((p+1)/4): the square root of a when a is a square.  a: N-form.  Result N-form.
 KZG_HD_NOINLINE void f28_sqrt_candidate(fp28& r, const fp28& a) {
@@ -51,78 +49,6 @@ KZG_HD_NOINLINE void f28_sqrt_candidate(fp28& r, const fp28& a) {
     }
   }
   r = acc;
-}
-
-// p = 2 p   (dbl-2008-s-1, a = 0) on an accumulator that satisfies the invariant of g1_xyzz28
-// (x: limbs <= 2^28 + 16, value < 10p; y, zz, zzz: N-form); the invariant holds again afterwards.
-KZG_HD_NOINLINE void xyzz28_dbl(g1_xyzz28& p) {
-  if (p.inf) return;
-  if (f28_is_zero(p.y)) {  // a point of order two
-    xyzz28_set_inf(p);
-    return;
-  }
-  fp28 u, v, w, s, m, t;
-  f28_add(u, p.y, p.y);     // limbs < 2^29, value < 4p
-  f28_sqr(v, u);            // 14 * 2^58
-  f28_mul(w, u, v);
-  f28_mul(s, p.x, v);
-  f28_sqr(m, p.x);
-  f28_add(t, m, m);
-  f28_add(m, m, t);         // 3 X^2: limbs < 3*2^28, value < 6p
-  fp28 x3;
-  f28_sqr(x3, m);           // 14 * 9 * 2^56
-  f28_add(t, s, s);         // limbs < 2^29, value < 4p
-  f28_sub_8p3(x3, x3, t);   // X3 = M^2 - 2S: limbs < 5*2^28, value < 10p
-  f28_carry_pass(x3);
-  f28_sub_16p(t, s, x3);    // S - X3: limbs < 3*2^28, value < 18p
-  fp28 nw;
-  f28_neg_4p(nw, w);        // limbs < 2^29, value <= 4p
-  f28_mul2(p.y, m, t, nw, p.y);  // Y3 = M (S - X3) - W Y1: 14 * (9 + 2) * 2^56
-  p.x = x3;
-  f28_mul(p.zz, p.zz, v);
-  f28_mul(p.zzz, p.zzz, w);
-}
-
-// p += q, both XYZZ accumulators under the invariant; complete   (add-2008-s)
-KZG_HD_NOINLINE void xyzz28_add_complete(g1_xyzz28& p, const g1_xyzz28& q) {
-  if (q.inf) return;
-  if (p.inf) {
-    p = q;
-    return;
-  }
-  fp28 u1, u2, s1, s2, pp, ppp;
-  f28_mul(u1, p.x, q.zz);
-  f28_mul(u2, q.x, p.zz);
-  f28_mul(s1, p.y, q.zzz);
-  f28_mul(s2, q.y, p.zzz);
-  f28_sub_4p(u2, u2, u1);  // P: limbs < 3*2^28, value < 6p
-  f28_sub_4p(s2, s2, s1);  // R
-  if (f28_is_zero(u2)) {
-    if (f28_is_zero(s2))
-      xyzz28_dbl(p);
-    else
-      xyzz28_set_inf(p);
-    return;
-  }
-  f28_sqr(pp, u2);
-  f28_mul(ppp, u2, pp);
-  f28_mul(p.zz, p.zz, q.zz);
-  f28_mul(p.zz, p.zz, pp);
-  f28_mul(p.zzz, p.zzz, q.zzz);
-  f28_mul(p.zzz, p.zzz, ppp);
-  f28_mul(pp, u1, pp);     // Q = U1 PP
-  f28_sqr(p.x, s2);        // R^2
-  KZG_UNROLL_FULL
-  for (int i = 0; i < F28_N; i++) {
-    const uint32_t s = ppp.l[i] + 2u * pp.l[i];
-    F28_SUBCHK(p.x.l[i], f28_8p_t3(i), s);
-    p.x.l[i] = p.x.l[i] + f28_8p_t3(i) - s;  // X3 = R^2 - PPP - 2Q
-  }
-  f28_carry_pass(p.x);
-  f28_sub_16p(pp, pp, p.x);  // Q - X3
-  fp28 ns1;
-  f28_neg_4p(ns1, s1);
-  f28_mul2(p.y, s2, pp, ns1, ppp);  // Y3 = R (Q - X3) - S1 PPP
 }
 
 // out = [|z|] base, |z| = 0xd201000000010000 (the BLS12-381 parameter); base finite or infinity
