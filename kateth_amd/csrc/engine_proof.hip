@@ -22,13 +22,14 @@ __global__ __launch_bounds__(256) void k_fr_store_be(const fr_t* __restrict__ pl
 static int32_t proof_dev_locked(const kzg_ctx* ctx, const uint8_t* d_blobs, const uint8_t* d_commitments48, const uint8_t* d_z32, uint64_t n,
                                 uint8_t* d_out48, uint8_t* d_y32, int32_t* d_status, hipStream_t st) {
   if (n == 0) return 0;
-  // Chunks of up to 4,096 blobs (bounds the quotient scratch at 128 KiB per blob).  The
-  // per-blob preparation (commitment check, SHA-256 challenge, evaluation + quotient) is
-  // latency-bound -- ~15 ms per chunk whatever its size -- so few large chunks win: measured at
-  // n = 4096 (c = 12): one serial chunk 84.4 ms; two overlapped 2,048-chunks 90.4 ms; four
-  // overlapped 1,024-chunks 112 ms (profiles/r01/proof_pipeline_variants.txt).  The two-stream
-  // pipeline stays available for multi-chunk batches (KATETH_AMD_PROOF_OVERLAP=1).
-  uint64_t chunk_max = 4096;
+  // Chunks of up to 16,384 blobs (quotient scratch: 128 KiB per blob = 2 GiB per chunk).  The per-chunk preparation
+  // starts with ~6 ms of pure latency (one SHA-256 stream per blob, 2,050 sequential blocks) during which the GPU is
+  // almost idle, and it cannot be hidden behind the previous chunk's MSM: that launch keeps every wave slot filled
+  // with its own queued waves until it ends (a second stream, also at the highest stream priority, only got going
+  // when the MSM finished).  So FEW, LARGE chunks win -- measured at n = 16,384, c = 12: 4 x 4,096 serial 244 ms,
+  // 4 x 4,096 on two streams 242 ms, 2 x 8,192 224 ms, 8 x 2,048 279 ms (profiles/r01/proof_pipeline_variants.txt).
+  // The two-stream pipeline stays selectable (KATETH_AMD_PROOF_OVERLAP=1, KATETH_AMD_PROOF_CHUNK).
+  uint64_t chunk_max = 16384;
   bool overlap = false;
   if (const char* e = getenv("KATETH_AMD_PROOF_CHUNK")) chunk_max = (uint64_t)atoll(e) > 0 ? (uint64_t)atoll(e) : chunk_max;
   if (const char* e = getenv("KATETH_AMD_PROOF_OVERLAP")) overlap = atoi(e) != 0;

@@ -19,7 +19,8 @@ d_p = torch.empty(n * 48, dtype=torch.uint8, device="cuda")
 d_st = torch.empty(n, dtype=torch.int32, device="cuda")
 s.synth_blobs_dev(0x4844, 0, n, d_blobs.data_ptr())
 s.blob_to_commitment_batch_dev(d_blobs.data_ptr(), n, d_c.data_ptr(), d_st.data_ptr())
-for tag, env in (("chunk1024_overlap", ("1024", "1")), ("chunk2048_overlap", ("2048", "1")), ("chunk4096_serial", ("4096", "0")), ("chunk1024_serial", ("1024", "0")), ("chunk512_overlap", ("512", "1"))):
+VARIANTS = (("chunk4096_serial", ("4096", "0")), ("chunk4096_overlap", ("4096", "1")), ("chunk2048_overlap", ("2048", "1")), ("chunk1024_overlap", ("1024", "1")), ("chunk8192_overlap", ("8192", "1")))
+for tag, env in VARIANTS:
     os.environ["KATETH_AMD_PROOF_CHUNK"], os.environ["KATETH_AMD_PROOF_OVERLAP"] = env
     s.compute_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), n, d_p.data_ptr(), d_st.data_ptr())
     torch.cuda.synchronize()
