@@ -268,7 +268,7 @@ static int32_t commit_dev_locked(const kzg_ctx* ctx, const void* d_blobs, uint64
   const uint64_t chunk_max = 16384;  // bounds the lane-partial scratch (12 KiB per blob)
   const uint64_t cn = n < chunk_max ? n : chunk_max;
   const uint32_t splits = choose_splits(ctx, cn);
-  const size_t partial_bytes = (size_t)cn * splits * 64 * sizeof(g1_xyzz);
+  const size_t partial_bytes = (size_t)cn * splits * 65 * sizeof(g1_xyzz);  // 64 lane sums + 1 unit sum per (blob, split)
   const size_t need = partial_bytes + (size_t)cn * sizeof(g1_xyzz);
   int32_t rc = ws_reserve(ctx, need);
   if (rc) return rc;

@@ -78,7 +78,11 @@ static int32_t msm_pipeline(const kzg_ctx* ctx, const uint8_t* d_scalars, uint64
                        partials, d_status);
   HIP_TRY(hipGetLastError());
   if (pe1) HIP_TRY(hipEventRecord(pe1, st));
-  hipLaunchKernelGGL(k_msm_reduce, dim3((unsigned)n), dim3(64), 0, st, partials, splits, n, sums);
+  // two tree stages: the 64 lane sums of every (blob, split) unit, then the units of a blob -- 6 + log2(splits) levels of
+  // latency instead of the splits + 5 a sequential walk over the splits costs (a single blob uses 64 splits)
+  g1_xyzz* unit_sums = (splits == 1) ? sums : partials + (size_t)n * splits * 64;
+  hipLaunchKernelGGL(k_msm_reduce, dim3((unsigned)(n * splits)), dim3(64), 0, st, partials, n * splits, unit_sums);
+  if (splits > 1) hipLaunchKernelGGL(k_msm_reduce_splits, dim3((unsigned)n), dim3(64), 0, st, unit_sums, splits, n, sums);
   hipLaunchKernelGGL(k_g1_compress, dim3(blocks_for(n, 64)), dim3(64), 0, st, sums, n, d_status, d_out48);
   HIP_TRY(hipGetLastError());
   return 0;

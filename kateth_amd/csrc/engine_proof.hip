@@ -50,7 +50,7 @@ static int32_t proof_dev_locked(const kzg_ctx* ctx, const uint8_t* d_blobs, cons
     o_cs[sl] = take(cn * sizeof(int32_t));
     o_q[sl] = take(cn * 4096 * sizeof(fr_t));
   }
-  const size_t o_part = take(cn * splits * 64 * sizeof(g1_xyzz));
+  const size_t o_part = take(cn * splits * 65 * sizeof(g1_xyzz));  // 64 lane sums + 1 unit sum per (blob, split)
   const size_t o_sum = take(cn * sizeof(g1_xyzz));
   int32_t rc = ws_reserve(ctx, off);
   if (rc) return rc;

@@ -19,25 +19,24 @@ namespace kzg {
 KZG_F28_TABLE(f28_r2_limb, KZG_FP28_R2)
 KZG_F28_TABLE(f28_b_limb, KZG_FP28_B)
 KZG_F28_TABLE(f28_beta_limb, KZG_FP28_BETA)
+KZG_F28_TABLE(f28_r400_limb, KZG_FP28_R400)
 #undef KZG_F28_TABLE
 
 
-// r = a^((p+1)/4): the square root of a when a is a square.  a: N-form.  Result N-form.
-KZG_HD_NOINLINE void f28_sqrt_candidate(fp28& r, const fp28& a) {
-  // odd powers a, a^3, a^5, a^7
+// r = a^e for a fixed exponent given as a width-3 sliding-window schedule (tools/gen_consts.py): `first` is the
+// leading digit's index, then (squarings, digit index | 255) pairs; digit index d stands for a^(2d+1).
+// a: N-form.  Result N-form.
+KZG_HD void f28_pow_sched(fp28& r, const fp28& a, const uint8_t* sched, int len, int first) {
   fp28 t1 = a, t3, t5, t7, a2;
   f28_sqr(a2, a);
   f28_mul(t3, a2, a);
   f28_mul(t5, t3, a2);
   f28_mul(t7, t5, a2);
-  const uint8_t sched[2 * KZG_FP_SQRT_SCHED_LEN] = KZG_FP_SQRT_SCHED;
   fp28 acc;
-  {
-    constexpr int f = KZG_FP_SQRT_FIRST_DIGIT_INDEX;
-    acc = f == 0 ? t1 : (f == 1 ? t3 : (f == 2 ? t5 : t7));
-  }
+  KZG_UNROLL_FULL
+  for (int i = 0; i < F28_N; i++) acc.l[i] = first == 0 ? t1.l[i] : (first == 1 ? t3.l[i] : (first == 2 ? t5.l[i] : t7.l[i]));
 #pragma unroll 1
-  for (int s = 0; s < KZG_FP_SQRT_SCHED_LEN; s++) {
+  for (int s = 0; s < len; s++) {
     const int nsq = sched[2 * s], idx = sched[2 * s + 1];
 #pragma unroll 1
     for (int q = 0; q < nsq; q++) f28_sqr(acc, acc);
@@ -49,6 +48,57 @@ KZG_HD_NOINLINE void f28_sqrt_candidate(fp28& r, const fp28& a) {
     }
   }
   r = acc;
+}
+// a^((p+1)/4): the square root of a when a is a square (378 squarings + 105 products)
+KZG_HD_NOINLINE void f28_sqrt_candidate(fp28& r, const fp28& a) {
+  const uint8_t sched[2 * KZG_FP_SQRT_SCHED_LEN] = KZG_FP_SQRT_SCHED;
+  f28_pow_sched(r, a, sched, KZG_FP_SQRT_SCHED_LEN, KZG_FP_SQRT_FIRST_DIGIT_INDEX);
+}
+// a^(p-2) = 1/a (0 -> 0)
+KZG_HD_NOINLINE void f28_inv(fp28& r, const fp28& a) {
+  const uint8_t sched[2 * KZG_FP_INV_SCHED_LEN] = KZG_FP_INV_SCHED;
+  f28_pow_sched(r, a, sched, KZG_FP_INV_SCHED_LEN, KZG_FP_INV_FIRST_DIGIT_INDEX);
+}
+
+// blst_p1_compress (src/bls.rs:499) of an XYZZ point given in the 12 x 32-bit-limb format (canonical 2^384-Montgomery):
+// same bytes as g1_compress_xyzz (g1.cuh); the inversion and the five products around it run in the radix-2^28 field.
+KZG_HD_NOINLINE void g1_compress_xyzz28(uint8_t* out48, const g1_xyzz& p) {
+  if (xyzz_is_inf(p)) {
+    out48[0] = 0xC0;
+    for (int i = 1; i < 48; i++) out48[i] = 0;
+    return;
+  }
+  fp28 k, X, Y, ZZ, ZZZ, t, ti, a;
+  KZG_UNROLL_FULL
+  for (int i = 0; i < F28_N; i++) k.l[i] = f28_r400_limb(i);
+  // v * 2^384 read as an integer, times 2^400 / 2^392  ->  v * 2^392
+  f28_from_bn(X, p.x);
+  f28_mul(X, X, k);
+  f28_from_bn(Y, p.y);
+  f28_mul(Y, Y, k);
+  f28_from_bn(ZZ, p.zz);
+  f28_mul(ZZ, ZZ, k);
+  f28_from_bn(ZZZ, p.zzz);
+  f28_mul(ZZZ, ZZZ, k);
+  f28_mul(t, ZZ, ZZZ);
+  f28_inv(ti, t);
+  f28_mul(a, ti, ZZZ);  // 1 / ZZ
+  f28_mul(X, X, a);
+  f28_mul(a, ti, ZZ);   // 1 / ZZZ
+  f28_mul(Y, Y, a);
+  fp28 one_plain;
+  KZG_UNROLL_FULL
+  for (int i = 0; i < F28_N; i++) one_plain.l[i] = i == 0 ? 1u : 0u;
+  f28_mul(X, X, one_plain);  // plain, N-form
+  f28_mul(Y, Y, one_plain);
+  fp_t xp, yp;
+  f28_to_bn(xp, X);
+  canonicalize<FpParams>(xp);
+  f28_to_bn(yp, Y);
+  canonicalize<FpParams>(yp);
+  fp_to_be_bytes_plain(out48, xp);
+  out48[0] |= 0x80;
+  if (fp_is_lex_larger_plain(yp)) out48[0] |= 0x20;
 }
 
 // out = [|z|] base, |z| = 0xd201000000010000 (the BLS12-381 parameter); base finite or infinity

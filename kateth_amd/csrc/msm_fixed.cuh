@@ -22,7 +22,7 @@
 // sums go to HBM; k_msm_reduce combines them by a 6-level tree through LDS and
 // k_g1_compress emits the 48-byte encodings.
 #pragma once
-#include "fp28.cuh"
+#include "g1_decode28.cuh"
 
 namespace kzg {
 
@@ -277,19 +277,26 @@ static __global__ __launch_bounds__(64, 2) void k_msm_fixed28(const uint8_t* __r
   }
 }
 
-// One wave per item: sums the 64 * splits lane partials of k_msm_fixed (6-level tree
-// through LDS) into one XYZZ point per item.
-static __global__ __launch_bounds__(64) void k_msm_reduce(const g1_xyzz* __restrict__ partials, uint32_t splits, uint64_t n,
-                                                   g1_xyzz* __restrict__ sums) {
+// One wave per (blob, split) unit: sums the unit's 64 lane partials (6-level tree through LDS).
+static __global__ __launch_bounds__(64) void k_msm_reduce(const g1_xyzz* __restrict__ partials, uint64_t units, g1_xyzz* __restrict__ unit_sums) {
+  __shared__ g1_xyzz lds[32];
+  const int lane = threadIdx.x;
+  const uint64_t u = blockIdx.x;
+  if (u >= units) return;
+  g1_xyzz acc = partials[u * 64 + lane];
+  wave_reduce_xyzz(acc, lds, lane);
+  if (lane == 0) unit_sums[u] = acc;
+}
+// One wave per blob: sums the blob's `splits` (<= 64) unit sums.
+static __global__ __launch_bounds__(64) void k_msm_reduce_splits(const g1_xyzz* __restrict__ unit_sums, uint32_t splits, uint64_t n,
+                                                                 g1_xyzz* __restrict__ sums) {
   __shared__ g1_xyzz lds[32];
   const int lane = threadIdx.x;
   const uint64_t b = blockIdx.x;
   if (b >= n) return;
-  g1_xyzz acc = partials[(b * splits) * 64 + lane];
-  for (uint32_t s = 1; s < splits; s++) {
-    g1_xyzz t = partials[(b * splits + s) * 64 + lane];
-    xyzz_add(acc, t);
-  }
+  g1_xyzz acc;
+  xyzz_set_inf(acc);
+  if ((uint32_t)lane < splits) acc = unit_sums[b * splits + lane];
   wave_reduce_xyzz(acc, lds, lane);
   if (lane == 0) sums[b] = acc;
 }
@@ -306,7 +313,7 @@ static __global__ __launch_bounds__(64) void k_g1_compress(const g1_xyzz* __rest
     for (int q = 0; q < 48; q++) tmp[q] = 0;
   } else {
     g1_xyzz acc = sums[b];
-    g1_compress_xyzz(tmp, acc);
+    g1_compress_xyzz28(tmp, acc);  // inversion in the radix-2^28 field (g1_decode28.cuh)
   }
   for (int q = 0; q < 12; q++)
     o[q] = (uint32_t)tmp[4 * q] | ((uint32_t)tmp[4 * q + 1] << 8) | ((uint32_t)tmp[4 * q + 2] << 16) | ((uint32_t)tmp[4 * q + 3] << 24);

@@ -381,3 +381,20 @@ extern "C" int32_t hm_g1_decompress28(uint8_t* out48, const uint8_t* in48) {
   }
   return (st & 0xff) | ((st0 & 0xff) << 8) | diff;
 }
+
+// compress(sum of points) through g1_compress_xyzz28 (radix-2^28 inversion) and through g1_compress_xyzz; returns 1 if the
+// two encodings are identical, out48 = the radix-2^28 one
+extern "C" int32_t hm_g1_sum_compress28(uint8_t* out48, const uint8_t* pts48, int n) {
+  g1_xyzz acc;
+  xyzz_set_inf(acc);
+  for (int i = 0; i < n; i++) {
+    fp_t x, y;
+    bool inf;
+    if (g1_uncompress(x, y, inf, pts48 + 48 * i) != 0) return -1;
+    if (!inf) xyzz_madd(acc, x, y);
+  }
+  uint8_t ref[48];
+  g1_compress_xyzz(ref, acc);
+  g1_compress_xyzz28(out48, acc);
+  return memcmp(ref, out48, 48) == 0 ? 1 : 0;
+}

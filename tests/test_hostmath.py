@@ -384,3 +384,22 @@ def test_g1_decompress_radix28_matches_reference_path(hm):
             if s is not None:
                 assert both(bls.g1_compress(s)) == 5
     assert hm.hm_f28_violations() == 0
+
+
+def test_g1_compress_radix28_matches_reference_path(hm):
+    """g1_compress_xyzz28 (inversion by a sliding-window power in the radix-2^28 field) gives the bytes of
+    g1_compress_xyzz and of the oracle, on sums with non-trivial ZZ, on both y signs and on infinity"""
+    rnd = random.Random(4848)
+    out = ctypes.create_string_buffer(48)
+    pts = [bls.g1_mul(bls.G1_GEN, rnd.randrange(1, R)) for _ in range(12)]
+    enc = [bls.g1_compress(p) for p in pts]
+    for k in range(1, 12):
+        assert hm.hm_g1_sum_compress28(out, b"".join(enc[:k]), k) == 1
+        want = None
+        for p in pts[:k]:
+            want = bls.g1_add(want, p)
+        assert out.raw == bls.g1_compress(want)
+        neg = bls.g1_compress(bls.g1_neg(want))
+        assert hm.hm_g1_sum_compress28(out, neg, 1) == 1 and out.raw == neg
+    assert hm.hm_g1_sum_compress28(out, enc[0] + bls.g1_compress(bls.g1_neg(pts[0])), 2) == 1 and out.raw == bls.g1_compress(None)
+    assert hm.hm_f28_violations() == 0
