@@ -498,6 +498,38 @@ def test_ragged_batch_sizes_agree_with_single_items(engine, torch_cuda):
     assert engine.verify_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr() + 48, n - 1) is False
 
 
+def test_proof_chunking_and_two_stream_pipeline_are_bit_exact(engine, torch_cuda, monkeypatch):
+    """the proof path walks large batches in chunks (default 16,384 blobs, so ordinary test batches are one chunk);
+    forcing tiny chunks -- serial and with the two-stream pipeline, ragged last chunk included -- must give the same
+    proofs, statuses and invalid-item positions as one chunk"""
+    torch = torch_cuda
+    n = 37
+    d_blobs = torch.empty(n * 131072, dtype=torch.uint8, device="cuda")
+    engine.synth_blobs_dev(0xC0FFEE, 7, n, d_blobs.data_ptr())
+    d_blobs[5 * 131072: 5 * 131072 + 32] = 0xFF  # blob 5: first element not canonical
+    d_c = torch.empty(n * 48, dtype=torch.uint8, device="cuda")
+    d_st = torch.empty(n, dtype=torch.int32, device="cuda")
+    engine.blob_to_commitment_batch_dev(d_blobs.data_ptr(), n, d_c.data_ptr(), d_st.data_ptr())
+    torch.cuda.synchronize()
+    d_c[5 * 48: 6 * 48] = d_c[0:48]  # give the bad blob a decodable commitment
+    d_c[11 * 48] = 0x00  # commitment 11: compression bit cleared
+    want_p = torch.empty(n * 48, dtype=torch.uint8, device="cuda")
+    want_st = torch.empty(n, dtype=torch.int32, device="cuda")
+    engine.compute_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), n, want_p.data_ptr(), want_st.data_ptr())
+    torch.cuda.synchronize()
+    st = want_st.cpu().tolist()
+    assert st[5] == 2 and st[11] == 3 and sum(1 for v in st if v) == 2
+    for chunk, overlap in (("8", "0"), ("8", "1"), ("5", "1"), ("16", "0")):
+        monkeypatch.setenv("KATETH_AMD_PROOF_CHUNK", chunk)
+        monkeypatch.setenv("KATETH_AMD_PROOF_OVERLAP", overlap)
+        got_p = torch.zeros(n * 48, dtype=torch.uint8, device="cuda")
+        got_st = torch.full((n,), -7, dtype=torch.int32, device="cuda")
+        engine.compute_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), n, got_p.data_ptr(), got_st.data_ptr())
+        torch.cuda.synchronize()
+        assert got_st.cpu().tolist() == st, (chunk, overlap)
+        assert got_p.cpu().numpy().tobytes() == want_p.cpu().numpy().tobytes(), (chunk, overlap)
+
+
 def test_radix32_msm_kernel_is_bit_exact(golden, monkeypatch):
     """KATETH_AMD_MSM_RADIX=32 selects the 12 x 32-bit-limb MSM kernel and the 2^384-Montgomery table; the default is the
     radix-2^28 kernel (fp28.cuh).  Both must produce the same bytes (the rest of this file runs the default)."""
