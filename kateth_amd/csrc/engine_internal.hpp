@@ -62,6 +62,28 @@ uint32_t choose_splits(const kzg_ctx* ctx, uint64_t n);
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static inline unsigned blocks_for(uint64_t n, unsigned per) { return (unsigned)((n + per - 1) / per); }
 
+// Fiat-Shamir challenges of n blobs: up to one workgroup pair per SIMD the two-wave kernel (shorter critical path per
+// SHA-256 block); beyond that the chip is full and the one-lane-per-blob kernel does less total work.
+static inline void launch_challenge(const kzg_ctx* ctx, hipStream_t st, const uint8_t* blobs, const uint8_t* commitments48, uint64_t n, fr_t* z) {
+  if (n == 0) return;
+  const uint64_t split_max = (uint64_t)ctx->num_cus * 4 * 64 / 2;  // 2 waves per 64 blobs, one wave per SIMD: 32,768 on 256 CUs
+  if (n <= split_max)
+    hipLaunchKernelGGL(k_challenge_split, dim3(blocks_for(n, 64)), dim3(128), 0, st, blobs, commitments48, n, z);
+  else
+    hipLaunchKernelGGL(k_challenge, dim3(blocks_for(n, 64)), dim3(64), 0, st, blobs, commitments48, n, z);
+}
+
+// Small batches: challenges of n blobs and decoding of n_a + n_b points in one launch (k_challenge_and_decode).
+constexpr uint64_t KZG_FUSED_PREP_MAX = 8192;
+static inline void launch_challenge_and_decode(hipStream_t st, const uint8_t* blobs, const uint8_t* commitments48, uint64_t n, fr_t* z,
+                                               const uint8_t* in_a, uint64_t n_a, int32_t* status_a, const uint8_t* in_b, uint64_t n_b,
+                                               int32_t* status_b, uint4* affine, uint8_t* inf) {
+  const uint32_t sha_wgs = (uint32_t)blocks_for(n, 64);
+  const uint32_t dec_wgs = (uint32_t)blocks_for(n_a + n_b, 128);
+  hipLaunchKernelGGL(k_challenge_and_decode, dim3(sha_wgs + dec_wgs), dim3(128), 0, st, blobs, commitments48, n, z, sha_wgs, in_a, n_a, status_a, in_b,
+                     n_b, status_b, affine, inf);
+}
+
 // launches the fixed-base MSM + reduce + compress over `n` scalar vectors already on device
 template <bool BE_BYTES>
 static int32_t msm_pipeline(const kzg_ctx* ctx, const uint8_t* d_scalars, uint64_t n, uint8_t* d_out48, int32_t* d_status, g1_xyzz* partials,

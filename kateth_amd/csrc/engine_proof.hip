@@ -93,18 +93,24 @@ static int32_t proof_dev_locked(const kzg_ctx* ctx, const uint8_t* d_blobs, cons
     (void)hipMemsetAsync(cstat, 0, m * sizeof(int32_t), side);
     if (d_commitments48) {
       const uint8_t* com = d_commitments48 + base * 48;
-      // the commitment check (one lane per point: ~2.6 ms of latency for any chunk size) runs beside the SHA-256
-      // challenge (one lane per blob: ~5.6 ms) on a second stream; both are far too small to compete for CUs
-      hipStream_t dec = overlap ? side : ctx->side_stream;
-      if (dec != side) {
-        (void)hipEventRecord(ev_fork[k], side);
-        (void)hipStreamWaitEvent(dec, ev_fork[k], 0);
+      if (m <= KZG_FUSED_PREP_MAX) {
+        // commitment check and SHA-256 challenge in one launch: both are long per-lane dependency chains and must not share SIMDs
+        launch_challenge_and_decode(side, blobs, com, m, z, com, m, cstat, (const uint8_t*)nullptr, (uint64_t)0, (int32_t*)nullptr, (uint4*)nullptr,
+                                    (uint8_t*)nullptr);
+      } else {
+        // the commitment check (one lane per point: ~2.6 ms of latency for any chunk size) runs beside the SHA-256
+        // challenge (one lane per blob: ~5.6 ms) on a second stream; both are far too small to compete for CUs
+        hipStream_t dec = overlap ? side : ctx->side_stream;
+        if (dec != side) {
+          (void)hipEventRecord(ev_fork[k], side);
+          (void)hipStreamWaitEvent(dec, ev_fork[k], 0);
+        }
+        hipLaunchKernelGGL(k_g1_decompress, dim3(blocks_for(m, 64)), dim3(64), 0, dec, com, m, cstat, (const uint8_t*)nullptr, (uint64_t)0,
+                           (int32_t*)nullptr, (uint4*)nullptr, (uint8_t*)nullptr);
+        if (dec != side) (void)hipEventRecord(ev_join[k], dec);
+        launch_challenge(ctx, side, blobs, com, m, z);
+        if (dec != side) (void)hipStreamWaitEvent(side, ev_join[k], 0);
       }
-      hipLaunchKernelGGL(k_g1_decompress, dim3(blocks_for(m, 64)), dim3(64), 0, dec, com, m, cstat, (const uint8_t*)nullptr, (uint64_t)0,
-                         (int32_t*)nullptr, (uint4*)nullptr, (uint8_t*)nullptr);
-      if (dec != side) (void)hipEventRecord(ev_join[k], dec);
-      hipLaunchKernelGGL(k_challenge, dim3(blocks_for(m, 64)), dim3(64), 0, side, blobs, com, m, z);
-      if (dec != side) (void)hipStreamWaitEvent(side, ev_join[k], 0);
     } else {
       hipLaunchKernelGGL(k_fr_parse, dim3(blocks_for(m, 64)), dim3(64), 0, side, d_z32 + base * 32, m, z, cstat);
     }

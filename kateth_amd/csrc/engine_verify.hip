@@ -293,21 +293,20 @@ extern "C" int32_t kzg_verify_phase1_dev(const kzg_ctx* ctx, const void* d_blobs
         break;
       }
       hipStream_t side = ctx->side_stream;
-      // Small batches (both kernels together far below one wave per SIMD) are latency-bound instead: there the
-      // decoding starts at once, beside the challenge (a single blob: 12.4 -> 9.9 ms).
-      const bool small = n <= 8192;
+      // Small batches (everything together below one wave per SIMD) are latency-bound instead: there hashing and
+      // decoding are ONE launch whose workgroups the dispatcher deals over different CUs (single blob: 12.4 -> 6.2 ms
+      // together with the two-wave SHA-256).
+      const bool small = n <= KZG_FUSED_PREP_MAX;
       if (small) {
+        launch_challenge_and_decode(st, blobs, com, n, s->z, prf, n, stat + 2 * n, com, n, stat + n, s->aff, s->inf);
+        (void)hipEventRecord(ev_join, st);
+      } else {
+        launch_challenge(ctx, st, blobs, com, n, s->z);
         (void)hipEventRecord(ev_fork, st);
         (void)hipStreamWaitEvent(side, ev_fork, 0);
+        hipLaunchKernelGGL(k_g1_decompress, dim3(blocks_for(2 * n, 64)), dim3(64), 0, side, prf, n, stat + 2 * n, com, n, stat + n, s->aff, s->inf);
+        (void)hipEventRecord(ev_join, side);
       }
-      hipLaunchKernelGGL(k_challenge, dim3(blocks_for(n, 64)), dim3(64), 0, st, blobs, com, n, s->z);
-      if (!small) {
-        (void)hipEventRecord(ev_fork, st);
-        (void)hipStreamWaitEvent(side, ev_fork, 0);
-      }
-      if (!small && getenv("KATETH_AMD_VERIFY_SERIAL")) side = st;  // measurement aid: decode and evaluate back to back on one stream
-      hipLaunchKernelGGL(k_g1_decompress, dim3(blocks_for(2 * n, 64)), dim3(64), 0, side, prf, n, stat + 2 * n, com, n, stat + n, s->aff, s->inf);
-      (void)hipEventRecord(ev_join, side);
       hipLaunchKernelGGL(k_eval_frac, dim3((unsigned)n), dim3(64), 0, st, blobs, s->z, ctx->d_roots_brp, ctx->d_eval_tab, s->y, stat);
       (void)hipStreamWaitEvent(st, ev_join, 0);
       (void)hipEventDestroy(ev_fork);
