@@ -15,6 +15,7 @@
 // with it except for the once-per-call pairing (pairing.hpp).
 #pragma once
 #include <stdint.h>
+#include <string.h>
 
 #include "consts.cuh"
 
@@ -191,13 +192,29 @@ KZG_HD uint32_t bn_add(bn<N>& r, const bn<N>& a, const bn<N>& b) {
   for (int i = 0; i < N; i++) r.v[i] = __builtin_addc(a.v[i], b.v[i], c, &c);
   return c;
 #else
-  uint64_t c = 0;
-  for (int i = 0; i < N; i++) {
-    c += (uint64_t)a.v[i] + b.v[i];
-    r.v[i] = (uint32_t)c;
-    c >>= 32;
+  if constexpr (N % 2 == 0) {  // host: the same little-endian bytes viewed as N/2 64-bit limbs
+    constexpr int M = N / 2;
+    uint64_t A[M], B[M], R[M];
+    memcpy(A, a.v, 4 * N);
+    memcpy(B, b.v, 4 * N);
+    unsigned __int128 c = 0;
+#pragma GCC unroll 8
+    for (int i = 0; i < M; i++) {
+      c += (unsigned __int128)A[i] + B[i];
+      R[i] = (uint64_t)c;
+      c >>= 64;
+    }
+    memcpy(r.v, R, 4 * N);
+    return (uint32_t)c;
+  } else {
+    uint64_t c = 0;
+    for (int i = 0; i < N; i++) {
+      c += (uint64_t)a.v[i] + b.v[i];
+      r.v[i] = (uint32_t)c;
+      c >>= 32;
+    }
+    return (uint32_t)c;
   }
-  return (uint32_t)c;
 #endif
 }
 
@@ -210,13 +227,29 @@ KZG_HD uint32_t bn_sub(bn<N>& r, const bn<N>& a, const bn<N>& b) {
   for (int i = 0; i < N; i++) r.v[i] = __builtin_subc(a.v[i], b.v[i], c, &c);
   return c;
 #else
-  int64_t c = 0;
-  for (int i = 0; i < N; i++) {
-    c += (int64_t)a.v[i] - (int64_t)b.v[i];
-    r.v[i] = (uint32_t)c;
-    c >>= 32;
+  if constexpr (N % 2 == 0) {
+    constexpr int M = N / 2;
+    uint64_t A[M], B[M], R[M];
+    memcpy(A, a.v, 4 * N);
+    memcpy(B, b.v, 4 * N);
+    uint64_t borrow = 0;
+#pragma GCC unroll 8
+    for (int i = 0; i < M; i++) {
+      const unsigned __int128 t = (unsigned __int128)A[i] - B[i] - borrow;
+      R[i] = (uint64_t)t;
+      borrow = (uint64_t)(t >> 64) & 1u;
+    }
+    memcpy(r.v, R, 4 * N);
+    return (uint32_t)borrow;
+  } else {
+    int64_t c = 0;
+    for (int i = 0; i < N; i++) {
+      c += (int64_t)a.v[i] - (int64_t)b.v[i];
+      r.v[i] = (uint32_t)c;
+      c >>= 32;
+    }
+    return (uint32_t)(c & 1);
   }
-  return (uint32_t)(c & 1);
 #endif
 }
 
@@ -256,20 +289,81 @@ KZG_HD void reduce_once(bn<F::N>& r, const bn<F::N>& t, uint32_t carry) {
 // ---------------------------------------------------------------------------
 // modular add / sub / neg / double on fully reduced values
 // ---------------------------------------------------------------------------
+#if !defined(__HIP_DEVICE_COMPILE__)
+// host versions in 64-bit limbs (the once-per-call pairing does ~3 additions per multiplication)
+template <class F>
+inline void add_mod_host64(bn<F::N>& r, const bn<F::N>& a, const bn<F::N>& b) {
+  constexpr int M = F::N / 2;
+  typedef unsigned __int128 u128;
+  uint64_t A[M], B[M], T[M], D[M];
+  memcpy(A, a.v, 8 * M);
+  memcpy(B, b.v, 8 * M);
+  u128 c = 0;
+  uint64_t borrow = 0;
+#pragma GCC unroll 8
+  for (int i = 0; i < M; i++) {
+    c += (u128)A[i] + B[i];
+    T[i] = (uint64_t)c;
+    c >>= 64;
+    const uint64_t p = (uint64_t)F::mod(2 * i) | ((uint64_t)F::mod(2 * i + 1) << 32);
+    const u128 u = (u128)T[i] - p - borrow;
+    D[i] = (uint64_t)u;
+    borrow = (uint64_t)(u >> 64) & 1u;
+  }
+  const uint64_t mask = ((uint64_t)c != 0 || borrow == 0) ? ~0ull : 0ull;  // take T - p
+#pragma GCC unroll 8
+  for (int i = 0; i < M; i++) T[i] = (D[i] & mask) | (T[i] & ~mask);
+  memcpy(r.v, T, 8 * M);
+}
+template <class F>
+inline void sub_mod_host64(bn<F::N>& r, const bn<F::N>& a, const bn<F::N>& b) {
+  constexpr int M = F::N / 2;
+  typedef unsigned __int128 u128;
+  uint64_t A[M], B[M], T[M];
+  memcpy(A, a.v, 8 * M);
+  memcpy(B, b.v, 8 * M);
+  uint64_t borrow = 0;
+#pragma GCC unroll 8
+  for (int i = 0; i < M; i++) {
+    const u128 u = (u128)A[i] - B[i] - borrow;
+    T[i] = (uint64_t)u;
+    borrow = (uint64_t)(u >> 64) & 1u;
+  }
+  const uint64_t mask = borrow ? ~0ull : 0ull;  // add p back
+  u128 c = 0;
+#pragma GCC unroll 8
+  for (int i = 0; i < M; i++) {
+    const uint64_t p = ((uint64_t)F::mod(2 * i) | ((uint64_t)F::mod(2 * i + 1) << 32)) & mask;
+    c += (u128)T[i] + p;
+    T[i] = (uint64_t)c;
+    c >>= 64;
+  }
+  memcpy(r.v, T, 8 * M);
+}
+#endif
+
 template <class F>
 KZG_HD void add_mod(bn<F::N>& r, const bn<F::N>& a, const bn<F::N>& b) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+  add_mod_host64<F>(r, a, b);
+#else
   bn<F::N> t;
   uint32_t c = bn_add(t, a, b);
   reduce_once<F>(r, t, c);
+#endif
 }
 
 template <class F>
 KZG_HD void sub_mod(bn<F::N>& r, const bn<F::N>& a, const bn<F::N>& b) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+  sub_mod_host64<F>(r, a, b);
+#else
   bn<F::N> t, u;
   uint32_t borrow = bn_sub(t, a, b);
   bn_add(u, t, modulus<F>());
 #pragma unroll
   for (int i = 0; i < F::N; i++) r.v[i] = borrow ? u.v[i] : t.v[i];
+#endif
 }
 
 template <class F>
@@ -299,14 +393,16 @@ inline void mont_mul_host64(bn<F::N>& r, const bn<F::N>& a, const bn<F::N>& b) {
   constexpr int M = F::N / 2;
   typedef unsigned __int128 u128;
   uint64_t A[M], B[M], P[M], t[M + 2];
-  for (int i = 0; i < M; i++) {
-    A[i] = (uint64_t)a.v[2 * i] | ((uint64_t)a.v[2 * i + 1] << 32);
-    B[i] = (uint64_t)b.v[2 * i] | ((uint64_t)b.v[2 * i + 1] << 32);
-    P[i] = (uint64_t)F::mod(2 * i) | ((uint64_t)F::mod(2 * i + 1) << 32);
-  }
+  memcpy(A, a.v, 8 * M);
+  memcpy(B, b.v, 8 * M);
+#pragma GCC unroll 8
+  for (int i = 0; i < M; i++) P[i] = (uint64_t)F::mod(2 * i) | ((uint64_t)F::mod(2 * i + 1) << 32);
+#pragma GCC unroll 8
   for (int i = 0; i < M + 2; i++) t[i] = 0;
+#pragma GCC unroll 8
   for (int i = 0; i < M; i++) {
     uint64_t c = 0;
+#pragma GCC unroll 8
     for (int j = 0; j < M; j++) {
       u128 s = (u128)A[j] * B[i] + t[j] + c;
       t[j] = (uint64_t)s;
@@ -318,6 +414,7 @@ inline void mont_mul_host64(bn<F::N>& r, const bn<F::N>& a, const bn<F::N>& b) {
     uint64_t m = t[0] * F::INV64;
     s = (u128)m * P[0] + t[0];
     c = (uint64_t)(s >> 64);
+#pragma GCC unroll 8
     for (int j = 1; j < M; j++) {
       s = (u128)m * P[j] + t[j] + c;
       t[j - 1] = (uint64_t)s;
@@ -327,15 +424,20 @@ inline void mont_mul_host64(bn<F::N>& r, const bn<F::N>& a, const bn<F::N>& b) {
     t[M - 1] = (uint64_t)s;
     t[M] = t[M + 1] + (uint64_t)(s >> 64);
   }
-  bn<F::N> tt;
-  for (int i = 0; i < M; i++) {
-    tt.v[2 * i] = (uint32_t)t[i];
-    tt.v[2 * i + 1] = (uint32_t)(t[i] >> 32);
+  if (LAZY) {
+    memcpy(r.v, t, 8 * M);  // inputs < 2p and 4p < radix  =>  result < 2p, no final subtraction
+  } else {
+    // conditional subtraction of the modulus in 64-bit limbs
+    uint64_t d[M], borrow = 0;
+#pragma GCC unroll 8
+    for (int i = 0; i < M; i++) {
+      const u128 u = (u128)t[i] - P[i] - borrow;
+      d[i] = (uint64_t)u;
+      borrow = (uint64_t)(u >> 64) & 1u;
+    }
+    const bool use_d = (t[M] != 0) || (borrow == 0);
+    memcpy(r.v, use_d ? d : t, 8 * M);
   }
-  if (LAZY)
-    r = tt;  // inputs < 2p and 4p < radix  =>  result < 2p, no final subtraction
-  else
-    reduce_once<F>(r, tt, (uint32_t)t[M]);
 }
 #endif
 
