@@ -186,9 +186,53 @@ inline bool f12_eq(const fp12& a, const fp12& b) {
 }
 // multiply by the sparse line value  l = l0 + l2*w^2 + l3*w^3  (w^2 = v, w^3 = v*w):
 // as an Fp12 element: c0 = (l0, l2, 0), c1 = (0, l3, 0)
-inline fp12 f12_mul_by_line(const fp12& f, const fp2& l0, const fp2& l2, const fp2& l3) {
-  fp12 l{fp6{l0, l2, f2_zero()}, fp6{f2_zero(), l3, f2_zero()}};
-  return f12_mul(f, l);
+// Sparse products (13 Fp2 multiplications instead of 18, three of them by an Fp scalar): a * (c0 + c1 v) in Fp6 ...
+inline fp6 f6_mul_by_01(const fp6& a, const fp2& c0, const fp2& c1) {
+  const fp2 aa = f2_mul(a.c0, c0), bb = f2_mul(a.c1, c1);
+  const fp2 t1 = f2_add(f2_mul_xi(f2_mul(a.c2, c1)), aa);
+  const fp2 t2 = f2_sub(f2_sub(f2_mul(f2_add(c0, c1), f2_add(a.c0, a.c1)), aa), bb);
+  const fp2 t3 = f2_add(f2_mul(a.c2, c0), bb);
+  return fp6{t1, t2, t3};
+}
+// ... and a * (s v) with s in Fp
+inline fp6 f6_mul_by_1_fp(const fp6& a, const fp_t& s) { return fp6{f2_mul_xi(f2_mul_fp(a.c2, s)), f2_mul_fp(a.c0, s), f2_mul_fp(a.c1, s)}; }
+// f * (l0 + l2 v + y v w), y in Fp: the line value with the G1 point's y as its w^3 coefficient
+inline fp12 f12_mul_by_line(const fp12& f, const fp2& l0, const fp2& l2, const fp_t& y) {
+  const fp6 aa = f6_mul_by_01(f.c0, l0, l2);
+  const fp6 bb = f6_mul_by_1_fp(f.c1, y);
+  fp2 o = l2;
+  fp_add(o.c0, o.c0, y);  // l2 + y (y has no u part)
+  const fp6 c1 = f6_sub(f6_sub(f6_mul_by_01(f6_add(f.c1, f.c0), l0, o), aa), bb);
+  const fp6 c0 = f6_add(f6_mul_by_v(bb), aa);
+  return fp12{c0, c1};
+}
+// Squaring in the cyclotomic subgroup (Granger-Scott): valid for unitary f with f^(p^4 - p^2 + 1) = 1, i.e. anything
+// after the easy part of the final exponentiation.  9 Fp2 squarings instead of the 12 Fp2 products of f12_sqr.
+inline void f4_sqr(fp2& c0, fp2& c1, const fp2& a, const fp2& b) {
+  const fp2 t0 = f2_sqr(a), t1 = f2_sqr(b);
+  c0 = f2_add(f2_mul_xi(t1), t0);
+  c1 = f2_sub(f2_sub(f2_sqr(f2_add(a, b)), t0), t1);
+}
+inline fp12 f12_cyclotomic_sqr(const fp12& f) {
+  fp2 z0 = f.c0.c0, z4 = f.c0.c1, z3 = f.c0.c2, z2 = f.c1.c0, z1 = f.c1.c1, z5 = f.c1.c2;
+  fp2 t0, t1, t2, t3;
+  f4_sqr(t0, t1, z0, z1);
+  z0 = f2_sub(t0, z0);
+  z0 = f2_add(f2_dbl(z0), t0);
+  z1 = f2_add(t1, z1);
+  z1 = f2_add(f2_dbl(z1), t1);
+  f4_sqr(t0, t1, z2, z3);
+  f4_sqr(t2, t3, z4, z5);
+  z4 = f2_sub(t0, z4);
+  z4 = f2_add(f2_dbl(z4), t0);
+  z5 = f2_add(t1, z5);
+  z5 = f2_add(f2_dbl(z5), t1);
+  t0 = f2_mul_xi(t3);
+  z2 = f2_add(t0, z2);
+  z2 = f2_add(f2_dbl(z2), t0);
+  z3 = f2_sub(t2, z3);
+  z3 = f2_add(f2_dbl(z3), t2);
+  return fp12{fp6{z0, z4, z3}, fp6{z2, z1, z5}};
 }
 
 // ---- Frobenius ---------------------------------------------------------------
@@ -414,14 +458,14 @@ inline fp12 multi_miller(const g1_host_affine* ps, const miller_lines* const* ls
       if (ps[j].inf || ls[j]->q_is_inf) continue;
       size_t k = idx[j]++;
       fp2 l2 = f2_neg(f2_mul_fp(ls[j]->lambda[k], ps[j].x));
-      f = f12_mul_by_line(f, ls[j]->mu[k], l2, fp2{ps[j].y, fp_zero()});
+      f = f12_mul_by_line(f, ls[j]->mu[k], l2, ps[j].y);
     }
     if ((BLS_X_ABS >> bit) & 1) {
       for (int j = 0; j < npairs; j++) {
         if (ps[j].inf || ls[j]->q_is_inf) continue;
         size_t k = idx[j]++;
         fp2 l2 = f2_neg(f2_mul_fp(ls[j]->lambda[k], ps[j].x));
-        f = f12_mul_by_line(f, ls[j]->mu[k], l2, fp2{ps[j].y, fp_zero()});
+        f = f12_mul_by_line(f, ls[j]->mu[k], l2, ps[j].y);
       }
     }
   }
@@ -429,10 +473,10 @@ inline fp12 multi_miller(const g1_host_affine* ps, const miller_lines* const* ls
 }
 
 // ---- final exponentiation ------------------------------------------------------
-inline fp12 f12_pow_x(const fp12& a) {  // a^|z|
+inline fp12 f12_pow_x(const fp12& a) {  // a^|z|, a in the cyclotomic subgroup
   fp12 r = a;
   for (int bit = 62; bit >= 0; bit--) {
-    r = f12_sqr(r);
+    r = f12_cyclotomic_sqr(r);
     if ((BLS_X_ABS >> bit) & 1) r = f12_mul(r, a);
   }
   return r;
