@@ -307,7 +307,12 @@ extern "C" int32_t kzg_verify_phase1_dev(const kzg_ctx* ctx, const void* d_blobs
         hipLaunchKernelGGL(k_g1_decompress, dim3(blocks_for(2 * n, 64)), dim3(64), 0, side, prf, n, stat + 2 * n, com, n, stat + n, s->aff, s->inf);
         (void)hipEventRecord(ev_join, side);
       }
-      hipLaunchKernelGGL(k_eval_frac, dim3((unsigned)n), dim3(64), 0, st, blobs, s->z, ctx->d_roots_brp, ctx->d_eval_tab, s->y, stat);
+      bool wide_groups = n < 4096;
+      if (const char* e = getenv("KATETH_AMD_EVAL_GROUP")) wide_groups = atoi(e) != 16;  // tests force either shape
+      if (!wide_groups)  // chip full: 16 lanes per blob (four blobs per wave), shorter merge tree
+        hipLaunchKernelGGL(k_eval_frac<16>, dim3(blocks_for(n, 4)), dim3(64), 0, st, blobs, s->z, ctx->d_roots_brp, ctx->d_eval_tab, s->y, stat, n);
+      else  // latency first: the whole wave on one blob
+        hipLaunchKernelGGL(k_eval_frac<64>, dim3((unsigned)n), dim3(64), 0, st, blobs, s->z, ctx->d_roots_brp, ctx->d_eval_tab, s->y, stat, n);
       (void)hipStreamWaitEvent(st, ev_join, 0);
       (void)hipEventDestroy(ev_fork);
       (void)hipEventDestroy(ev_join);

@@ -30,17 +30,26 @@ namespace kzg {
 //   a  = (u * wR^2) / R = (u w) R                         Montgomery
 //   N' = (N * d + a * D) / R,  D' = (D * d) / R           d = z^2 R - w^2 R (a limb-wise subtraction)
 // eval_tab[pr] = { w R, w R^2, w^2 R } as 3 x 9 limbs (28 dwords with padding), w = roots_brp[2 pr].
+template <int G>
 __device__ __forceinline__ fr29 shfl_down_fr29(const fr29& a, int delta) {
   fr29 r;
 #pragma unroll
-  for (int q = 0; q < F29_N; q++) r.l[q] = __shfl_down(a.l[q], delta, 64);
+  for (int q = 0; q < F29_N; q++) r.l[q] = __shfl_down(a.l[q], delta, G);
   return r;
 }
+// G lanes work on one blob (64 / G blobs per wave).  G = 64 has the shortest latency (32 pairs per lane); G = 16 does
+// 128 pairs per lane and a 4-level merge instead of 32 pairs and a 6-level one -- the merge is 11 % of a wave's work
+// at G = 64, 2 % at G = 16 -- and is used when the batch fills the chip.
+template <int G>
 static __global__ __launch_bounds__(64) void k_eval_frac(const uint8_t* __restrict__ blobs, const fr_t* __restrict__ z_plain,
                                                          const fr_t* __restrict__ roots_brp, const uint32_t* __restrict__ eval_tab,
-                                                         fr_t* __restrict__ y_plain, int32_t* __restrict__ status) {
-  const int lane = threadIdx.x;
-  const uint64_t b = blockIdx.x;
+                                                         fr_t* __restrict__ y_plain, int32_t* __restrict__ status, uint64_t n) {
+  constexpr int PER_LANE = 2048 / G;  // pairs per lane
+  const int lane = threadIdx.x % G;   // position inside the blob's group
+  const int group = threadIdx.x / G;
+  uint64_t b = (uint64_t)blockIdx.x * (64 / G) + group;
+  const bool live = b < n;
+  if (!live) b = n - 1;  // idle groups shadow the last blob (they take part in the shuffles, never store)
   const uint8_t* blob = blobs + b * 131072ull;
   fr29 z, z2;
   {
@@ -61,18 +70,18 @@ static __global__ __launch_bounds__(64) void k_eval_frac(const uint8_t* __restri
   // processed; the table entry is L2-resident and loaded where it is used
   uint4 nb0, nb1, nb2, nb3;
   {
-    const uint4* src = reinterpret_cast<const uint4*>(blob + (uint64_t)lane * 64u);
+    const uint4* src = reinterpret_cast<const uint4*>(blob + (uint64_t)lane * 64u);  // pair `lane` of the blob
     nb0 = src[0];
     nb1 = src[1];
     nb2 = src[2];
     nb3 = src[3];
   }
 #pragma unroll 1
-  for (int k = 0; k < 32; k++) {
-    const int pr = k * 64 + lane;  // pair index: elements 2*pr, 2*pr + 1 (64 contiguous bytes)
+  for (int k = 0; k < PER_LANE; k++) {
+    const int pr = k * G + lane;  // pair index: elements 2*pr, 2*pr + 1 (64 contiguous bytes)
     const uint4 b0 = nb0, b1 = nb1, b2 = nb2, b3 = nb3;
-    if (k + 1 < 32) {
-      const uint4* src = reinterpret_cast<const uint4*>(blob + (uint64_t)(pr + 64) * 64u);
+    if (k + 1 < PER_LANE) {
+      const uint4* src = reinterpret_cast<const uint4*>(blob + (uint64_t)(pr + G) * 64u);
       nb0 = src[0];
       nb1 = src[1];
       nb2 = src[2];
@@ -132,24 +141,24 @@ static __global__ __launch_bounds__(64) void k_eval_frac(const uint8_t* __restri
   }
   // merge lane fractions: (N1/D1) + (N2/D2) = (N1 D2 + N2 D1) / (D1 D2)
 #pragma unroll 1
-  for (int delta = 32; delta >= 1; delta >>= 1) {
-    const fr29 N2 = shfl_down_fr29(N, delta), D2 = shfl_down_fr29(D, delta);
+  for (int delta = G / 2; delta >= 1; delta >>= 1) {
+    const fr29 N2 = shfl_down_fr29<G>(N, delta), D2 = shfl_down_fr29<G>(D, delta);
     f29_mul2(N, N, D2, N2, D);
     f29_mul(D, D, D2);
   }
   int dom_any = dom;
 #pragma unroll
-  for (int delta = 32; delta >= 1; delta >>= 1) {
-    const int o = __shfl_xor(dom_any, delta, 64);
+  for (int delta = G / 2; delta >= 1; delta >>= 1) {
+    const int o = __shfl_xor(dom_any, delta, G);
     dom_any = o > dom_any ? o : dom_any;
   }
   // The merged denominator is prod_k (z^2 - w_k^2) = z^4096 - 1 exactly, so
   //   y = (N / D) * (z^4096 - 1) / 4096 = N / 4096          -- no inversion at all.
   fr_t y;
   if (dom_any >= 0) {
-    const int owner = (dom_any >> 1) & 63;  // pair index pr = k*64 + lane
+    const int owner = (dom_any >> 1) % G;  // pair index pr = k*G + lane
 #pragma unroll
-    for (int q = 0; q < 8; q++) y.v[q] = __shfl(e_dom.v[q], owner, 64);  // already plain
+    for (int q = 0; q < 8; q++) y.v[q] = __shfl(e_dom.v[q], owner, G);  // already plain
   } else {
     fr29 f, t;
     KZG_UNROLL_FULL
@@ -157,8 +166,12 @@ static __global__ __launch_bounds__(64) void k_eval_frac(const uint8_t* __restri
     f29_mul(t, N, f);  // (N R)(1/4096) / R: plain
     f29_to_canonical_bn(y, t);
   }
-  if (lane == 0) y_plain[b] = y;
-  if (__any(bad) && lane == 0) atomicOr(&status[b], KZG_ERR_BLOB_INVALID_FIELD_ELEMENT);
+  const unsigned long long bad_lanes = __ballot(bad);
+  const unsigned long long group_mask = (G == 64) ? ~0ull : (((1ull << (G % 64)) - 1ull) << (group * G));
+  if (live && lane == 0) {
+    y_plain[b] = y;
+    if (bad_lanes & group_mask) atomicOr(&status[b], KZG_ERR_BLOB_INVALID_FIELD_ELEMENT);
+  }
 }
 
 // ---------------------------------------------------------------------------

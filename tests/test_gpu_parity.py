@@ -530,6 +530,39 @@ def test_proof_chunking_and_two_stream_pipeline_are_bit_exact(engine, torch_cuda
         assert got_p.cpu().numpy().tobytes() == want_p.cpu().numpy().tobytes(), (chunk, overlap)
 
 
+def test_evaluation_kernel_group_shapes_agree(engine, golden, torch_cuda, monkeypatch):
+    """batch verification evaluates each blob with 64 lanes (small batches) or 16 lanes (four blobs per wave, batches that
+    fill the chip); both shapes must accept the same valid ragged batches, reject the same corrupted ones and report the
+    same invalid blob"""
+    import kateth_amd
+
+    torch = torch_cuda
+    n = 131  # not a multiple of 4: the last wave of the 16-lane shape has idle groups
+    d_blobs = torch.empty(n * 131072, dtype=torch.uint8, device="cuda")
+    engine.synth_blobs_dev(0xE7A1, 3, n, d_blobs.data_ptr())
+    d_c = torch.empty(n * 48, dtype=torch.uint8, device="cuda")
+    d_p = torch.empty(n * 48, dtype=torch.uint8, device="cuda")
+    d_st = torch.empty(n, dtype=torch.int32, device="cuda")
+    engine.blob_to_commitment_batch_dev(d_blobs.data_ptr(), n, d_c.data_ptr(), d_st.data_ptr())
+    engine.compute_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), n, d_p.data_ptr(), d_st.data_ptr())
+    torch.cuda.synchronize()
+    assert int(d_st.abs().sum()) == 0
+    bad_blobs = d_blobs.clone()
+    bad_blobs[129 * 131072 + 64 * 7: 129 * 131072 + 64 * 7 + 32] = 0xFF  # element 14 of blob 129 is not canonical
+    flipped = d_blobs.clone()
+    flipped[77 * 131072 + 31] ^= 1  # a valid but different blob 77
+    for group in ("16", "64"):
+        monkeypatch.setenv("KATETH_AMD_EVAL_GROUP", group)
+        for m in (1, 2, 3, 4, 5, 67, n):
+            assert engine.verify_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), m) is True, (group, m)
+        assert engine.verify_blob_proof_batch_dev(flipped.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n) is False
+        assert engine.verify_blob_proof_batch_dev(flipped.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), 77) is True
+        with pytest.raises(kateth_amd.KzgError) as err:
+            engine.verify_blob_proof_batch_dev(bad_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n)
+        assert isinstance(err.value.inner, kateth_amd.BlobError) and err.value.inner.kind == "InvalidFieldElement"
+        assert engine.verify_blob_proof_batch_dev(bad_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), 129) is True  # the bad blob is item 129
+
+
 def test_radix32_msm_kernel_is_bit_exact(golden, monkeypatch):
     """KATETH_AMD_MSM_RADIX=32 selects the 12 x 32-bit-limb MSM kernel and the 2^384-Montgomery table; the default is the
     radix-2^28 kernel (fp28.cuh).  Both must produce the same bytes (the rest of this file runs the default)."""
