@@ -241,7 +241,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "u32 limbs (381-bit Fp / 255-bit Fr Montgomery integer arithmetic)",
+        "dtype": "u32 limbs (381-bit Fp / 255-bit Fr Montgomery integer arithmetic; 28/29-bit radix in the hot loops)",
         "data": "synthetic: element(b,i)=SHA-256(seed||b||i) mod r, generated on device, resident in HBM",
         "config": {
             "workload": "blob_to_kzg_commitment batch=%d blobs per GPU (BASELINE configs[1])" % n,
