@@ -64,7 +64,7 @@ static __global__ __launch_bounds__(256) void k_synth_blobs(uint64_t seed, uint6
 // ---------------------------------------------------------------------------
 // K7: P1::decompress (src/bls.rs:505-531) for n points, one thread per point.
 // status[i] = 0 / KZG_ERR_EC_*.  If `affine` != null the decoded point is stored
-// (Montgomery x,y; infinity -> all-zero entry and inf[i] = 1).
+// (canonical 2^392-Montgomery x,y -- the operand format of k_var_buckets; infinity -> all-zero entry and inf[i] = 1).
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void g1_decompress_item(uint64_t t, const uint8_t* __restrict__ in_a, uint64_t n_a, int32_t* __restrict__ status_a,
                                                    const uint8_t* __restrict__ in_b, uint64_t n_b, int32_t* __restrict__ status_b,
@@ -85,7 +85,7 @@ __device__ __forceinline__ void g1_decompress_item(uint64_t t, const uint8_t* __
   }
   fp_t x, y;
   bool is_inf = false;
-  int32_t st = g1_decompress28(x, y, is_inf, buf);  // radix-2^28 field path (g1_decode28.cuh)
+  int32_t st = g1_decompress28(x, y, is_inf, buf, true);  // radix-2^28 field path; stored points stay in the 2^392 domain (k_var_buckets)
   (second ? status_b : status_a)[i] = st;
   if (affine != nullptr) {
     if (st != 0 || is_inf) {

@@ -169,7 +169,7 @@ static int32_t ctx_build(kzg_ctx* ctx, const uint8_t* g1_lagrange, const uint8_t
   }
   // ---- G1 generator (BLS12_381_G1, src/bls.rs:391) ----
   {
-    const uint32_t gx[12] = KZG_FP_G1X_MONT, gy[12] = KZG_FP_G1Y_MONT;
+    const uint32_t gx[12] = KZG_FP_G1X_R392, gy[12] = KZG_FP_G1Y_R392;  // operand of the variable-base MSM: 2^392 domain
     uint32_t h[24];
     for (int q = 0; q < 12; q++) {
       h[q] = gx[q];

@@ -137,8 +137,10 @@ KZG_HD_NOINLINE bool g1_in_subgroup28(const fp28& x, const fp28& y) {
   return f28_is_zero(t);
 }
 
-// Same contract as g1_decompress (g1.cuh): status code, canonical 2^384-Montgomery x and y, *inf.
-KZG_HD_NOINLINE int32_t g1_decompress28(fp_t& x, fp_t& y, bool& inf, const uint8_t* in48) {
+// Same contract as g1_decompress (g1.cuh): status code, canonical 2^384-Montgomery x and y (unless r392_out), *inf.
+// r392_out: leave the coordinates in the 2^392-Montgomery domain (canonical, 12 x 32 limbs) -- the operand format of
+// the radix-2^28 adders (k_var_buckets) -- instead of converting to 2^384.
+KZG_HD_NOINLINE int32_t g1_decompress28(fp_t& x, fp_t& y, bool& inf, const uint8_t* in48, bool r392_out = false) {
   inf = false;
   const uint8_t b0 = in48[0];
   if (!(b0 & 0x80)) return KZG_ERR_EC_INVALID_ENCODING;
@@ -185,8 +187,15 @@ KZG_HD_NOINLINE int32_t g1_decompress28(fp_t& x, fp_t& y, bool& inf, const uint8
     f28_mul(y28, ny, f28_one());    // N-form
   }
   if (!g1_in_subgroup28(x28, y28)) return KZG_ERR_EC_NOT_IN_GROUP;
-  f28_to_fp(x, x28);
-  f28_to_fp(y, y28);
+  if (r392_out) {
+    f28_to_bn(x, x28);  // N-form: limbs strictly normalised, value < 2p
+    canonicalize<FpParams>(x);
+    f28_to_bn(y, y28);
+    canonicalize<FpParams>(y);
+  } else {
+    f28_to_fp(x, x28);
+    f28_to_fp(y, y28);
+  }
   return KZG_OK;
 }
 

@@ -407,7 +407,10 @@ static __global__ __launch_bounds__(256) void k_var_scatter(const fr_t* __restri
   });
 }
 
-// thread = (bucket, k of K): entries lo+k, lo+k+K, ... of the bucket's sorted list
+// thread = (bucket, k of K): entries lo+k, lo+k+K, ... of the bucket's sorted list.  Points are affine in the
+// 2^392-Montgomery domain (k_g1_decompress), the accumulator is XYZZ in radix-2^28 limbs with the MSM hot loop's inline
+// adder (xyzz28_madd_fast; the out-of-line complete adder takes the identity and the P == +-Q cases, which DO occur
+// here: a batch may repeat a point); the next entry is in flight while the current one is added.
 static __global__ __launch_bounds__(64, 2) void k_var_buckets(const uint4* __restrict__ points, const uint32_t* __restrict__ offsets,
                                                        const uint32_t* __restrict__ entries, uint32_t nbuckets, uint32_t K,
                                                        g1_xyzz* __restrict__ partial_sums) {
@@ -415,17 +418,40 @@ static __global__ __launch_bounds__(64, 2) void k_var_buckets(const uint4* __res
   if (id >= (uint64_t)nbuckets * K) return;
   const uint32_t bkt = (uint32_t)(id / K), k0 = (uint32_t)(id % K);
   const uint32_t lo = offsets[bkt], hi = offsets[bkt + 1];
-  g1_xyzz acc;
-  xyzz_set_inf(acc);
+  g1_xyzz28 acc;
+  xyzz28_set_inf(acc);
+  fp_t nx, ny;
+  bn_zero(nx);
+  bn_zero(ny);
+  uint32_t ne = 0;
+  if (lo + k0 < hi) {
+    ne = entries[lo + k0];
+    load_affine96(nx, ny, points, ne >> 1);
+  }
 #pragma unroll 1
   for (uint32_t k = lo + k0; k < hi; k += K) {
-    const uint32_t e = entries[k];
-    fp_t x, y;
-    load_affine96(x, y, points, e >> 1);
-    if (e & 1u) fp_neg(y, y);
-    xyzz_madd(acc, x, y);
+    const uint32_t e = ne;
+    fp28 cx, cy;
+    f28_load_entry(cx, cy, nx, ny, (e & 1u) != 0);
+    if (k + K < hi) {
+      ne = entries[k + K];
+      load_affine96(nx, ny, points, ne >> 1);
+    }
+    bool done = false;
+    if (!acc.inf) done = xyzz28_madd_fast(acc, cx, cy);
+    if (!done) {
+      g1_xyzz28 tmp = acc;  // copy: the call takes addresses
+      fp_t rx, ry;
+      load_affine96(rx, ry, points, e >> 1);
+      fp28 sx, sy;
+      f28_load_entry(sx, sy, rx, ry, (e & 1u) != 0);
+      xyzz28_madd_complete(tmp, sx, sy);
+      acc = tmp;
+    }
   }
-  partial_sums[id] = acc;
+  g1_xyzz out;
+  xyzz28_to_xyzz(out, acc);
+  partial_sums[id] = out;
 }
 
 // One wave folds the K partial sums of 64/K buckets: K is a power of two <= 64, lanes
