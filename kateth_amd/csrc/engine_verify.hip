@@ -313,11 +313,12 @@ extern "C" int32_t kzg_verify_phase1_dev(const kzg_ctx* ctx, const void* d_blobs
         hipLaunchKernelGGL(k_eval_frac<16>, dim3(blocks_for(n, 4)), dim3(64), 0, st, blobs, s->z, ctx->d_roots_brp, ctx->d_eval_tab, s->y, stat, n);
       else  // latency first: the whole wave on one blob
         hipLaunchKernelGGL(k_eval_frac<64>, dim3((unsigned)n), dim3(64), 0, st, blobs, s->z, ctx->d_roots_brp, ctx->d_eval_tab, s->y, stat, n);
+      // the transcript hashes the input BYTES and (z, y): it does not wait for the decoded points
+      hipLaunchKernelGGL(k_transcript_leaves, dim3(blocks_for(n, 256)), dim3(256), 0, st, com, prf, s->z, s->y, n, leaves);
+      hipLaunchKernelGGL(k_transcript_nodes, dim3(blocks_for(groups, 64)), dim3(64), 0, st, leaves, n, nodes);
       (void)hipStreamWaitEvent(st, ev_join, 0);
       (void)hipEventDestroy(ev_fork);
       (void)hipEventDestroy(ev_join);
-      hipLaunchKernelGGL(k_transcript_leaves, dim3(blocks_for(n, 256)), dim3(256), 0, st, com, prf, s->z, s->y, n, leaves);
-      hipLaunchKernelGGL(k_transcript_nodes, dim3(blocks_for(groups, 64)), dim3(64), 0, st, leaves, n, nodes);
       if (hipGetLastError() != hipSuccess) {
         rc = fail(KZG_FAIL_HIP, "verify phase 1 launch failed");
         break;
