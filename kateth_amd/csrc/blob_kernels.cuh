@@ -346,8 +346,9 @@ static __global__ __launch_bounds__(64) void k_poly_root_inverse(const fr_t* __r
   inv_root[b] = r;
 }
 
+// (512, 4): at most 128 VGPRs, so that two 8-wave workgroups share a CU (129 VGPRs would halve the occupancy)
 template <bool QUOTIENT>
-static __global__ __launch_bounds__(512) void k_poly(const uint8_t* __restrict__ blobs, const fr_t* __restrict__ z_plain,
+static __global__ __launch_bounds__(512, 4) void k_poly(const uint8_t* __restrict__ blobs, const fr_t* __restrict__ z_plain,
                                               const fr_t* __restrict__ roots_brp, const fr_t* __restrict__ inv_root,
                                               fr_t* __restrict__ y_plain, fr_t* __restrict__ q_plain, int32_t* __restrict__ status) {
   __shared__ fr_t tree[1024];
@@ -379,7 +380,7 @@ static __global__ __launch_bounds__(512) void k_poly(const uint8_t* __restrict__
       bad = true;
       bn_zero(v);
     }
-    to_mont<FrParams>(e[k], v);
+    e[k] = v;  // kept PLAIN: mont_mul(plain, X*R) = plain*X, so neither a to_mont nor a from_mont per element is needed
     fr_t d;
     fr_sub(d, z, roots_brp[i]);
     if (bn_is_zero(d)) {
@@ -433,8 +434,8 @@ static __global__ __launch_bounds__(512) void k_poly(const uint8_t* __restrict__
       fr_mul(inv_d, inv_run, pre[k - 1]);
     fr_mul(inv_run, inv_run, d);
     pre[k] = inv_d;  // slot k now holds 1/(z - w_i)
-    fr_mul(term, e[k], w);
-    fr_mul(term, term, inv_d);
+    fr_mul(term, w, inv_d);      // (w R)(inv_d R)/R = w inv_d R
+    fr_mul(term, e[k], term);    // plain e * (w inv_d R) / R = plain e w / (z - w)
     if (i != domain) fr_add(ysum, ysum, term);
   }
   // block sum of ysum
@@ -458,7 +459,7 @@ static __global__ __launch_bounds__(512) void k_poly(const uint8_t* __restrict__
       for (int q = 0; q < 8; q++) f.v[q] = c4096[q];
     }
     fr_mul(f, f, zn);
-    fr_mul(total, total, f);
+    fr_mul(total, total, f);  // plain sum * Montgomery factor = plain y
     sh_y = total;
   }
   __syncthreads();
@@ -468,11 +469,9 @@ static __global__ __launch_bounds__(512) void k_poly(const uint8_t* __restrict__
       if (k == (domain >> 9)) sh_y = e[k];  // y = e_m (poly.rs:14-18)
   }
   __syncthreads();
-  const fr_t y = sh_y;
+  const fr_t y = sh_y;  // plain
   if (t == 0) {
-    fr_t yp;
-    from_mont<FrParams>(yp, y);
-    y_plain[b] = yp;
+    y_plain[b] = y;
     if (sh_bad) atomicOr(&status[b], KZG_ERR_BLOB_INVALID_FIELD_ELEMENT);
   }
   if (QUOTIENT) {
@@ -482,17 +481,16 @@ static __global__ __launch_bounds__(512) void k_poly(const uint8_t* __restrict__
 #pragma unroll
     for (int k = 0; k < 8; k++) {
       const int i = k * 512 + t;
-      fr_t q, qp;
-      fr_sub(q, y, e[k]);
-      fr_mul(q, q, pre[k]);
+      fr_t q;
+      fr_sub(q, y, e[k]);        // plain
+      fr_mul(q, q, pre[k]);      // plain * (1/(z - w_i)) R / R: plain quotient element
       if (i == domain) bn_zero(q);
       if (domain >= 0) {  // block-uniform
         fr_t qw;
-        fr_mul(qw, q, roots_brp[i]);
+        fr_mul(qw, q, roots_brp[i]);  // plain q_i w_i
         fr_add(ssum, ssum, qw);
       }
-      from_mont<FrParams>(qp, q);
-      qout[i] = qp;
+      qout[i] = q;
     }
     if (domain >= 0) {  // rare in-domain branch (poly.rs:50-64)
       __syncthreads();
@@ -507,12 +505,11 @@ static __global__ __launch_bounds__(512) void k_poly(const uint8_t* __restrict__
         __syncthreads();
       }
       if (t == 0) {
-        fr_t wm = roots_brp[domain], wi, qm, qp;
+        fr_t wm = roots_brp[domain], wi, qm;
         fr_inv(wi, wm);
-        fr_mul(qm, tree[0], wi);
+        fr_mul(qm, tree[0], wi);  // plain sum * Montgomery 1/w_m = plain
         fr_neg(qm, qm);
-        from_mont<FrParams>(qp, qm);
-        qout[domain] = qp;
+        qout[domain] = qm;
       }
     }
   }
