@@ -378,6 +378,29 @@ KZG_HD void xyzz28_to_xyzz(g1_xyzz& r, const g1_xyzz28& p) {
   f28_to_fp(r.zz, p.zz);
   f28_to_fp(r.zzz, p.zzz);
 }
+// the 12 x 32-limb XYZZ format (canonical 2^384-Montgomery) -> radix-2^28 accumulator (invariant of g1_xyzz28)
+KZG_HD void xyzz28_from_xyzz(g1_xyzz28& r, const g1_xyzz& p) {
+  if (xyzz_is_inf(p)) {
+    xyzz28_set_inf(r);
+    return;
+  }
+  fp28 k;
+  {
+    constexpr uint32_t t[F28_N] = KZG_FP28_R400;
+    KZG_UNROLL_FULL
+    for (int i = 0; i < F28_N; i++) k.l[i] = t[i];
+  }
+  // v * 2^384 read as an integer, times 2^400 / 2^392  ->  v * 2^392, N-form
+  f28_from_bn(r.x, p.x);
+  f28_mul(r.x, r.x, k);
+  f28_from_bn(r.y, p.y);
+  f28_mul(r.y, r.y, k);
+  f28_from_bn(r.zz, p.zz);
+  f28_mul(r.zz, r.zz, k);
+  f28_from_bn(r.zzz, p.zzz);
+  f28_mul(r.zzz, r.zzz, k);
+  r.inf = 0;
+}
 // table entry (canonical x*2^392, y*2^392 as 12 x 32 limbs) -> operands of xyzz28_madd
 KZG_HD void f28_load_entry(fp28& x, fp28& y, const fp_t& rx, const fp_t& ry, bool neg) {
   f28_from_bn(x, rx);
