@@ -40,6 +40,7 @@ struct kzg_ctx {
   uint64_t table_bytes = 0;
   uint32_t num_cus = 256;
   hipStream_t side_stream = nullptr;  // non-blocking stream for work that overlaps the caller's stream
+  hipStream_t copy_stream = nullptr;  // non-blocking stream for the chunked host-to-device copies of the host-buffer entry points
   // true (default): table in 2^392-Montgomery form, k_msm_fixed28 (radix-2^28 limbs, fp28.cuh);
   // KATETH_AMD_MSM_RADIX=32 at context creation: 2^384-Montgomery table, k_msm_fixed (12 x 32-bit limbs)
   bool msm_radix28 = true;
@@ -84,10 +85,11 @@ static inline void launch_challenge_and_decode(hipStream_t st, const uint8_t* bl
                      n_b, status_b, affine, inf);
 }
 
-// launches the fixed-base MSM + reduce + compress over `n` scalar vectors already on device
+// The fixed-base MSM kernel alone over `n` scalar vectors on the device: 64 lane sums per (blob, split) unit into
+// partials[unit * 64 + lane].
 template <bool BE_BYTES>
-static int32_t msm_pipeline(const kzg_ctx* ctx, const uint8_t* d_scalars, uint64_t n, uint8_t* d_out48, int32_t* d_status, g1_xyzz* partials,
-                            g1_xyzz* sums, uint32_t splits, hipStream_t st) {
+static int32_t msm_launch(const kzg_ctx* ctx, const uint8_t* d_scalars, uint64_t n, int32_t* d_status, g1_xyzz* partials, uint32_t splits,
+                          hipStream_t st) {
   hipEvent_t pe0, pe1;
   int32_t rc = prof_next(ctx, &pe0, &pe1);
   if (rc) return rc;
@@ -100,12 +102,25 @@ static int32_t msm_pipeline(const kzg_ctx* ctx, const uint8_t* d_scalars, uint64
                        partials, d_status);
   HIP_TRY(hipGetLastError());
   if (pe1) HIP_TRY(hipEventRecord(pe1, st));
-  // two tree stages: the 64 lane sums of every (blob, split) unit, then the units of a blob -- 6 + log2(splits) levels of
-  // latency instead of the splits + 5 a sequential walk over the splits costs (a single blob uses 64 splits)
+  return 0;
+}
+// Lane sums of n blobs -> 48-byte encodings.  Two tree stages: the 64 lane sums of every (blob, split) unit, then the units
+// of a blob -- 6 + log2(splits) levels of latency instead of the splits + 5 a sequential walk over the splits costs (a
+// single blob uses 64 splits).  `partials` must have room for n * splits unit sums after the n * splits * 64 lane sums.
+static inline int32_t msm_finish(uint64_t n, uint8_t* d_out48, const int32_t* d_status, g1_xyzz* partials, g1_xyzz* sums, uint32_t splits,
+                                 hipStream_t st) {
   g1_xyzz* unit_sums = (splits == 1) ? sums : partials + (size_t)n * splits * 64;
   hipLaunchKernelGGL(k_msm_reduce, dim3((unsigned)(n * splits)), dim3(64), 0, st, partials, n * splits, unit_sums);
   if (splits > 1) hipLaunchKernelGGL(k_msm_reduce_splits, dim3((unsigned)n), dim3(64), 0, st, unit_sums, splits, n, sums);
   hipLaunchKernelGGL(k_g1_compress, dim3(blocks_for(n, 64)), dim3(64), 0, st, sums, n, d_status, d_out48);
   HIP_TRY(hipGetLastError());
   return 0;
+}
+// MSM + reduce + compress
+template <bool BE_BYTES>
+static int32_t msm_pipeline(const kzg_ctx* ctx, const uint8_t* d_scalars, uint64_t n, uint8_t* d_out48, int32_t* d_status, g1_xyzz* partials,
+                            g1_xyzz* sums, uint32_t splits, hipStream_t st) {
+  int32_t rc = msm_launch<BE_BYTES>(ctx, d_scalars, n, d_status, partials, splits, st);
+  if (rc) return rc;
+  return msm_finish(n, d_out48, d_status, partials, sums, splits, st);
 }

@@ -591,6 +591,28 @@ def test_radix28_and_radix32_kernels_agree_at_scale(torch_cuda, monkeypatch):
     assert len(set(outs[0][48 * i:48 * i + 48] for i in range(n))) == n  # all distinct: nothing degenerate was compared
 
 
+def test_host_buffer_commitment_pipeline_matches_device_path(engine, torch_cuda):
+    """kzg_blob_to_commitment_batch streams host blobs in 512-blob chunks (copy of chunk k+1 beside the MSM of chunk k, one
+    reduce/compress per group): two full chunks and a ragged one, an invalid blob in the last chunk, against the
+    device-pointer entry point"""
+    torch = torch_cuda
+    n = 1111
+    d_blobs = torch.empty(n * 131072, dtype=torch.uint8, device="cuda")
+    engine.synth_blobs_dev(0xB10B, 11, n, d_blobs.data_ptr())
+    d_blobs[1100 * 131072 + 32 * 5: 1100 * 131072 + 32 * 5 + 32] = 0xFF  # blob 1100, element 5: not canonical
+    d_c = torch.empty(n * 48, dtype=torch.uint8, device="cuda")
+    d_st = torch.empty(n, dtype=torch.int32, device="cuda")
+    engine.blob_to_commitment_batch_dev(d_blobs.data_ptr(), n, d_c.data_ptr(), d_st.data_ptr())
+    torch.cuda.synchronize()
+    want, want_st = d_c.cpu().numpy().tobytes(), d_st.cpu().tolist()
+    assert want_st[1100] == 2 and sum(1 for v in want_st if v) == 1
+    host_blobs = d_blobs.cpu().numpy().tobytes()
+    for m in (n, 512, 513, 1):
+        got, got_st = engine.blob_to_commitment_batch(host_blobs[: m * 131072], m)
+        assert got_st == want_st[:m], m
+        assert got == want[: 48 * m], m
+
+
 def test_radix32_msm_kernel_is_bit_exact(golden, monkeypatch):
     """KATETH_AMD_MSM_RADIX=32 selects the 12 x 32-bit-limb MSM kernel and the 2^384-Montgomery table; the default is the
     radix-2^28 kernel (fp28.cuh).  Both must produce the same bytes (the rest of this file runs the default)."""
