@@ -141,6 +141,7 @@ extern "C" void kzg_ctx_destroy(kzg_ctx* ctx) {
 
 
 static int32_t ctx_build(kzg_ctx* ctx, const uint8_t* g1_lagrange, const uint8_t* g2_monomial) {
+  TraceTimer tt("ctx_build");
   const MsmGeom g = ctx->geom;
   hipStream_t st = nullptr;
   // ---- G2 monomial points (host): P2::decompress of all 65 (src/kzg/setup.rs:67-72) ----
@@ -168,6 +169,7 @@ static int32_t ctx_build(kzg_ctx* ctx, const uint8_t* g1_lagrange, const uint8_t
     ctx->pairing->lines_g2 = host::precompute_lines(gen);
     ctx->pairing->lines_tau = host::precompute_lines(tau);
   }
+  tt.mark("G2 decode + Miller lines (host)");
   // ---- G1 generator (BLS12_381_G1, src/bls.rs:391) ----
   {
     const uint32_t gx[12] = KZG_FP_G1X_R392, gy[12] = KZG_FP_G1Y_R392;  // operand of the variable-base MSM: 2^392 domain
@@ -196,6 +198,7 @@ static int32_t ctx_build(kzg_ctx* ctx, const uint8_t* g1_lagrange, const uint8_t
     if (h_status[i] != 0)
       return fail(KZG_FAIL_SETUP_G1, "g1_lagrange[" + std::to_string(i) + "] rejected, code " + std::to_string(h_status[i]) +
                                          (h_status[i] == 100 ? " (point at infinity is not supported as a setup base)" : ""));
+  tt.mark("G1 decode");
   // ---- roots of unity -------------------------------------------------------
   HIP_TRY(hipMalloc(&ctx->d_roots_brp, 4096 * sizeof(fr_t)));
   hipLaunchKernelGGL(k_setup_roots, dim3(64), dim3(64), 0, st, ctx->d_roots_brp);
@@ -206,6 +209,7 @@ static int32_t ctx_build(kzg_ctx* ctx, const uint8_t* g1_lagrange, const uint8_t
   const uint64_t entries = table_entries(g);
   ctx->table_bytes = entries * 96;
   HIP_TRY(hipMalloc(&ctx->d_table, ctx->table_bytes));
+  tt.mark("table allocation");
   uint4* d_win_bases = nullptr;
   HIP_TRY(hipMalloc(&d_win_bases, (size_t)g.W * 4096 * 96));
   hipLaunchKernelGGL(k_table_window_bases, dim3(64), dim3(64), 0, st, ctx->d_bases_brp, d_win_bases, g);
@@ -215,7 +219,9 @@ static int32_t ctx_build(kzg_ctx* ctx, const uint8_t* g1_lagrange, const uint8_t
   for (uint32_t j = 0; j < g.W; j++) {
     const uint32_t e = (j + 1 < g.W) ? g.half : g.top_entries;
     const uint64_t count = (uint64_t)4096 * e;
-    hipLaunchKernelGGL(k_table_chain, dim3(64), dim3(64), 0, st, d_win_bases, j, e, d_tmp);
+    uint32_t segs = e / 64;  // slices of >= 64 entries, at most 32 per base (two waves per SIMD)
+    segs = segs < 1 ? 1 : (segs > 32 ? 32 : segs);
+    hipLaunchKernelGGL(k_table_chain, dim3(64 * segs), dim3(64), 0, st, d_win_bases, j, e, segs, d_tmp);
     constexpr int KN = 8;
     const uint64_t threads = (count + KN - 1) / KN;
     hipLaunchKernelGGL(k_table_normalize<KN>, dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, st, d_tmp, count, ctx->d_table,
@@ -223,6 +229,7 @@ static int32_t ctx_build(kzg_ctx* ctx, const uint8_t* g1_lagrange, const uint8_t
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipDeviceSynchronize());
+  tt.mark("table build kernels");
   HIP_TRY(hipFree(d_tmp));
   HIP_TRY(hipFree(d_win_bases));
   return 0;

@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <mutex>
 #include <new>
 #include <string>
@@ -27,6 +28,19 @@ const std::string& last_error_text();
     hipError_t _e = (expr);                                                                                \
     if (_e != hipSuccess) return fail(KZG_FAIL_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));  \
   } while (0)
+
+struct TraceTimer {  // KATETH_AMD_TRACE=1: host-side wall-clock marks on stderr
+  bool on;
+  std::chrono::steady_clock::time_point t0;
+  const char* what;
+  explicit TraceTimer(const char* w) : on(getenv("KATETH_AMD_TRACE") != nullptr), t0(std::chrono::steady_clock::now()), what(w) {}
+  void mark(const char* label) {
+    if (!on) return;
+    auto t1 = std::chrono::steady_clock::now();
+    fprintf(stderr, "[kateth_amd trace] %s: %s +%.3f ms\n", what, label, std::chrono::duration<double, std::milli>(t1 - t0).count());
+    t0 = t1;
+  }
+};
 
 struct kzg_ctx {
   int device = 0;

@@ -7,19 +7,6 @@
 
 #include "engine_internal.hpp"
 #include "verify_kernels.cuh"
-struct TraceTimer {  // KATETH_AMD_TRACE=1: host-side wall-clock marks on stderr
-  bool on;
-  std::chrono::steady_clock::time_point t0;
-  const char* what;
-  explicit TraceTimer(const char* w) : on(getenv("KATETH_AMD_TRACE") != nullptr), t0(std::chrono::steady_clock::now()), what(w) {}
-  void mark(const char* label) {
-    if (!on) return;
-    auto t1 = std::chrono::steady_clock::now();
-    fprintf(stderr, "[kateth_amd trace] %s: %s +%.3f ms\n", what, label, std::chrono::duration<double, std::milli>(t1 - t0).count());
-    t0 = t1;
-  }
-};
-
 struct kzg_verify_session {
   const kzg_ctx* ctx = nullptr;
   uint64_t n = 0;

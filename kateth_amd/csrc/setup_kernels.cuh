@@ -40,19 +40,38 @@ static __global__ __launch_bounds__(64) void k_table_window_bases(const uint4* _
   }
 }
 
-// thread (i) of window j: chain d*Q for d = 1..entries, XYZZ results to tmp
-// (tmp index = i*entries + d-1).
-static __global__ __launch_bounds__(64) void k_table_chain(const uint4* __restrict__ win_bases, uint32_t j, uint32_t entries, g1_xyzz* __restrict__ tmp) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 4096) return;
+// thread (i, s) of window j: the chain d*Q for the s-th of `segs` slices of d = 1..entries, XYZZ results to tmp
+// (tmp index = i*entries + d-1).  A slice starts from [first]Q by double-and-add (15 steps at most) and then adds Q once
+// per entry; with one thread per base the 4,096 chains of 32,768 sequential additions were pure latency (0.44 s per
+// window at c = 16), sliced 32 ways they fill the chip.
+static __global__ __launch_bounds__(64) void k_table_chain(const uint4* __restrict__ win_bases, uint32_t j, uint32_t entries, uint32_t segs,
+                                                           g1_xyzz* __restrict__ tmp) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 4096u * segs) return;
+  const uint32_t i = t / segs, sg = t % segs;
+  const uint32_t len = (entries + segs - 1) / segs;
+  const uint32_t first = sg * len + 1;  // d of this slice's first entry
+  if (first > entries) return;
+  const uint32_t last = (first + len - 1 < entries) ? first + len - 1 : entries;
   fp_t x, y;
   load_affine96(x, y, win_bases, (uint64_t)j * 4096u + i);
   g1_xyzz acc;
   xyzz_from_affine(acc, x, y);
+  if (first > 1) {  // acc = [first]Q, MSB-first
+    const int top = 31 - __builtin_clz(first);
+    for (int bit = top - 1; bit >= 0; bit--) {
+      xyzz_dbl(acc);
+      if ((first >> bit) & 1u) {
+        g1_xyzz mine = acc;
+        xyzz_madd(mine, x, y);
+        acc = mine;
+      }
+    }
+  }
   g1_xyzz* o = tmp + (uint64_t)i * entries;
-  o[0] = acc;
+  o[first - 1] = acc;
 #pragma unroll 1
-  for (uint32_t d = 1; d < entries; d++) {
+  for (uint32_t d = first; d < last; d++) {
     xyzz_madd(acc, x, y);
     o[d] = acc;
   }
@@ -86,7 +105,16 @@ static __global__ __launch_bounds__(64) void k_table_normalize(const g1_xyzz* __
     }
   }
   fp_t inv;
-  fp_inv(inv, total);
+  {  // the one inversion per KN entries: sliding-window power in the radix-2^28 field (half the instructions of fp_inv)
+    fp28 t28, k, i28;
+    constexpr uint32_t r400[F28_N] = KZG_FP28_R400;
+    KZG_UNROLL_FULL
+    for (int q = 0; q < F28_N; q++) k.l[q] = r400[q];
+    f28_from_bn(t28, total);
+    f28_mul(t28, t28, k);  // total * 2^384 * 2^400 / 2^392 = total * 2^392
+    f28_inv(i28, t28);
+    f28_to_fp(inv, i28);   // back to canonical 2^384-Montgomery
+  }
 #pragma unroll
   for (int k = KN - 1; k >= 0; k--) {
     if (k < m) {
