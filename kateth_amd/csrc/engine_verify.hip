@@ -119,8 +119,8 @@ static MsmVarLayout msm_var_layout(uint64_t nterms) {
   // split every bucket over K threads (power of two <= 64) so that a thread chains ~16 additions
   uint64_t load = nterms / L.g.half + 1;
   while (L.K < 64 && (uint64_t)L.K * 16 < load) L.K <<= 1;
-  L.o_part = take((size_t)L.nb * L.K * sizeof(g1_xyzz));
-  L.o_bsum = take((size_t)L.nb * sizeof(g1_xyzz));
+  L.o_part = take((size_t)L.nb * L.K * sizeof(g1_xyzz28));
+  L.o_bsum = take((size_t)L.nb * sizeof(g1_xyzz28));
   L.o_win = take((size_t)L.g.W * sizeof(g1_xyzz));
   L.total = off;
   return L;
@@ -157,8 +157,8 @@ static int32_t msm_var_launch(MsmVarJob& job, const uint4* d_points, const uint8
   uint32_t* offsets = (uint32_t*)(buf + L.o_offsets);
   uint32_t* cursors = (uint32_t*)(buf + L.o_cursors);
   uint32_t* entries = (uint32_t*)(buf + L.o_entries);
-  g1_xyzz* bpart = (g1_xyzz*)(buf + L.o_part);
-  g1_xyzz* bsum = (g1_xyzz*)(buf + L.o_bsum);
+  g1_xyzz28* bpart = (g1_xyzz28*)(buf + L.o_part);
+  g1_xyzz28* bsum = (g1_xyzz28*)(buf + L.o_bsum);
   g1_xyzz* winsum = (g1_xyzz*)(buf + L.o_win);
   job.win.resize(g.W);
   job.active = true;

@@ -413,7 +413,7 @@ static __global__ __launch_bounds__(256) void k_var_scatter(const fr_t* __restri
 // here: a batch may repeat a point); the next entry is in flight while the current one is added.
 static __global__ __launch_bounds__(64, 2) void k_var_buckets(const uint4* __restrict__ points, const uint32_t* __restrict__ offsets,
                                                        const uint32_t* __restrict__ entries, uint32_t nbuckets, uint32_t K,
-                                                       g1_xyzz* __restrict__ partial_sums) {
+                                                       g1_xyzz28* __restrict__ partial_sums) {
   const uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (id >= (uint64_t)nbuckets * K) return;
   const uint32_t bkt = (uint32_t)(id / K), k0 = (uint32_t)(id % K);
@@ -449,33 +449,33 @@ static __global__ __launch_bounds__(64, 2) void k_var_buckets(const uint4* __res
       acc = tmp;
     }
   }
-  g1_xyzz out;
-  xyzz28_to_xyzz(out, acc);
-  partial_sums[id] = out;
+  partial_sums[id] = acc;  // the fold and window kernels stay in the radix-2^28 field
 }
 
 // One wave folds the K partial sums of 64/K buckets: K is a power of two <= 64, lanes
 // [g*K, (g+1)*K) hold bucket g's partials and are summed by a segmented tree through LDS.
-static __global__ __launch_bounds__(64) void k_var_fold(const g1_xyzz* __restrict__ partial_sums, uint32_t nbuckets, uint32_t K,
-                                                        g1_xyzz* __restrict__ bucket_sums) {
-  __shared__ g1_xyzz lds[32];
+// (Radix-2^28 field throughout: a full XYZZ addition is ~7.5 k instead of ~11 k VALU instructions, and these two kernels
+// are chains of dependent additions.)
+static __global__ __launch_bounds__(64) void k_var_fold(const g1_xyzz28* __restrict__ partial_sums, uint32_t nbuckets, uint32_t K,
+                                                        g1_xyzz28* __restrict__ bucket_sums) {
+  __shared__ g1_xyzz28 lds[32];
   const int lane = threadIdx.x;
   const uint64_t id = (uint64_t)blockIdx.x * 64 + lane;
   const uint32_t bkt = (uint32_t)(id / K);
-  g1_xyzz acc;
+  g1_xyzz28 acc;
   if (bkt < nbuckets)
     acc = partial_sums[id];
   else
-    xyzz_set_inf(acc);
+    xyzz28_set_inf(acc);
 #pragma unroll 1
   for (uint32_t step = 1; step < K; step <<= 1) {
     const uint32_t m = 2 * step - 1;
     if ((lane & m) == step) lds[lane >> 1] = acc;
     __syncthreads();
     if ((lane & m) == 0) {
-      g1_xyzz other = lds[(lane + step) >> 1];
-      g1_xyzz mine = acc;
-      xyzz_add(mine, other);
+      g1_xyzz28 other = lds[(lane + step) >> 1];
+      g1_xyzz28 mine = acc;
+      xyzz28_add_complete(mine, other);
       acc = mine;
     }
     __syncthreads();
@@ -486,25 +486,26 @@ static __global__ __launch_bounds__(64) void k_var_fold(const g1_xyzz* __restric
 // One wave per window:  sum_d d * B_d  =  sum over j of the suffix sums  sum_{d >= j} B_d .
 // Lane l owns `per` consecutive buckets; local suffix sums, a 6-step suffix scan of the lane
 // totals across the wave (Hillis-Steele through LDS), then a tree sum of all suffix sums:
-// ~2*per + 13 sequential additions, no scalar multiplications.
-static __global__ __launch_bounds__(64) void k_var_windows(const g1_xyzz* __restrict__ bucket_sums, VarGeom g, g1_xyzz* __restrict__ window_sums) {
-  __shared__ g1_xyzz buf[2][64];
-  __shared__ g1_xyzz lds[32];
+// ~2*per + 13 sequential additions, no scalar multiplications.  The window sum leaves in the 12 x 32-limb format
+// (host Horner).
+static __global__ __launch_bounds__(64) void k_var_windows(const g1_xyzz28* __restrict__ bucket_sums, VarGeom g, g1_xyzz* __restrict__ window_sums) {
+  __shared__ g1_xyzz28 buf[2][64];
+  __shared__ g1_xyzz28 lds[32];
   const int lane = threadIdx.x;
   const uint32_t j = blockIdx.x;
   const uint32_t per = (g.half + 63) / 64;
-  const g1_xyzz* B = bucket_sums + (uint64_t)j * g.half;
+  const g1_xyzz28* B = bucket_sums + (uint64_t)j * g.half;
   // local pass (descending): run = suffix sum within the lane, tot = sum of the lane's suffix sums
-  g1_xyzz run, tot;
-  xyzz_set_inf(run);
-  xyzz_set_inf(tot);
+  g1_xyzz28 run, tot;
+  xyzz28_set_inf(run);
+  xyzz28_set_inf(tot);
   uint32_t owned = 0;
   for (int k = (int)per - 1; k >= 0; k--) {
     const uint32_t idx = lane * per + k;
     if (idx < g.half) {
-      g1_xyzz b = B[idx];
-      xyzz_add(run, b);
-      xyzz_add(tot, run);
+      g1_xyzz28 b = B[idx];
+      xyzz28_add_complete(run, b);
+      xyzz28_add_complete(tot, run);
       owned++;
     }
   }
@@ -514,25 +515,41 @@ static __global__ __launch_bounds__(64) void k_var_windows(const g1_xyzz* __rest
   __syncthreads();
 #pragma unroll 1
   for (int off = 1; off < 64; off <<= 1) {
-    g1_xyzz v = buf[cur][lane];
+    g1_xyzz28 v = buf[cur][lane];
     if (lane + off < 64) {
-      g1_xyzz o = buf[cur][lane + off];
-      xyzz_add(v, o);
+      g1_xyzz28 o = buf[cur][lane + off];
+      xyzz28_add_complete(v, o);
     }
     buf[cur ^ 1][lane] = v;
     __syncthreads();
     cur ^= 1;
   }
   // inclusive suffix sum is buf[cur][lane]; exclusive = that of lane+1
-  g1_xyzz X;
+  g1_xyzz28 X;
   if (lane + 1 < 64)
     X = buf[cur][lane + 1];
   else
-    xyzz_set_inf(X);
+    xyzz28_set_inf(X);
   // each of the lane's `owned` suffix sums gains X: tot += owned * X  (owned <= per, tiny)
-  for (uint32_t k = 0; k < owned; k++) xyzz_add(tot, X);
-  wave_reduce_xyzz(tot, lds, lane);
-  if (lane == 0) window_sums[j] = tot;
+  for (uint32_t k = 0; k < owned; k++) xyzz28_add_complete(tot, X);
+#pragma unroll 1
+  for (int step = 1; step < 64; step <<= 1) {
+    const int m = 2 * step - 1;
+    if ((lane & m) == step) lds[lane >> 1] = tot;
+    __syncthreads();
+    if ((lane & m) == 0) {
+      g1_xyzz28 other = lds[(lane + step) >> 1];
+      g1_xyzz28 mine = tot;
+      xyzz28_add_complete(mine, other);
+      tot = mine;
+    }
+    __syncthreads();
+  }
+  if (lane == 0) {
+    g1_xyzz out;
+    xyzz28_to_xyzz(out, tot);
+    window_sums[j] = out;
+  }
 }
 
 #endif
