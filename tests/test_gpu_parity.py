@@ -613,6 +613,31 @@ def test_host_buffer_commitment_pipeline_matches_device_path(engine, torch_cuda)
         assert got == want[: 48 * m], m
 
 
+def test_mid_size_batches_take_the_unfused_preparation_path(engine, torch_cuda):
+    """8,192 < n <= 32,768: the two-wave SHA-256 kernel runs on its own and the points are decoded on the side stream
+    (smaller batches fuse the two, larger ones use the one-lane-per-blob hash); commit -> prove -> verify closes, a swapped
+    proof is rejected and the proofs equal those of the fused path on a prefix"""
+    torch = torch_cuda
+    n = 8200
+    d_blobs = torch.empty(n * 131072, dtype=torch.uint8, device="cuda")
+    engine.synth_blobs_dev(0x8200, 0, n, d_blobs.data_ptr())
+    d_c = torch.empty(n * 48, dtype=torch.uint8, device="cuda")
+    d_p = torch.empty(n * 48, dtype=torch.uint8, device="cuda")
+    d_st = torch.empty(n, dtype=torch.int32, device="cuda")
+    engine.blob_to_commitment_batch_dev(d_blobs.data_ptr(), n, d_c.data_ptr(), d_st.data_ptr())
+    engine.compute_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), n, d_p.data_ptr(), d_st.data_ptr())
+    torch.cuda.synchronize()
+    assert int(d_st.abs().sum()) == 0
+    assert engine.verify_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n) is True
+    p_small = torch.empty(100 * 48, dtype=torch.uint8, device="cuda")
+    engine.compute_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), 100, p_small.data_ptr(), d_st.data_ptr())
+    torch.cuda.synchronize()
+    assert p_small.cpu().numpy().tobytes() == d_p[: 100 * 48].cpu().numpy().tobytes()
+    d_p[8199 * 48: 8200 * 48] = d_p[0:48].clone()
+    assert engine.verify_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n) is False
+    assert engine.verify_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), 8199) is True
+
+
 def test_radix32_msm_kernel_is_bit_exact(golden, monkeypatch):
     """KATETH_AMD_MSM_RADIX=32 selects the 12 x 32-bit-limb MSM kernel and the 2^384-Montgomery table; the default is the
     radix-2^28 kernel (fp28.cuh).  Both must produce the same bytes (the rest of this file runs the default)."""
