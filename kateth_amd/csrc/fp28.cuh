@@ -297,7 +297,7 @@ KZG_HD bool f28_is_zero(const fp28& a) { return f28_maybe_zero(a) && f28_is_zero
 
 // p = 2 p   (dbl-2008-s-1, a = 0) on an accumulator that satisfies the invariant of g1_xyzz28
 // (x: limbs <= 2^28 + 16, value < 10p; y, zz, zzz: N-form); the invariant holds again afterwards.
-KZG_HD_NOINLINE void xyzz28_dbl(g1_xyzz28& p) {
+KZG_HD void xyzz28_dbl_inl(g1_xyzz28& p) {
   if (p.inf) return;
   if (f28_is_zero(p.y)) {  // a point of order two
     xyzz28_set_inf(p);
@@ -324,6 +324,7 @@ KZG_HD_NOINLINE void xyzz28_dbl(g1_xyzz28& p) {
   f28_mul(p.zz, p.zz, v);
   f28_mul(p.zzz, p.zzz, w);
 }
+KZG_HD_NOINLINE void xyzz28_dbl(g1_xyzz28& p) { xyzz28_dbl_inl(p); }
 
 // p += q, both XYZZ accumulators under the invariant; complete   (add-2008-s)
 KZG_HD_NOINLINE void xyzz28_add_complete(g1_xyzz28& p, const g1_xyzz28& q) {

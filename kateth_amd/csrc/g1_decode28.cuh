@@ -107,8 +107,12 @@ KZG_HD_NOINLINE void g1_mul_by_z28(g1_xyzz28& out, const g1_xyzz28& base) {
   g1_xyzz28 acc = base;
 #pragma unroll 1
   for (int i = 62; i >= 0; i--) {
-    xyzz28_dbl(acc);
-    if ((zabs >> i) & 1ull) xyzz28_add_complete(acc, base);
+    xyzz28_dbl_inl(acc);  // inline: the accumulator stays in registers over the runs of doublings (126 of them per point)
+    if ((zabs >> i) & 1ull) {
+      g1_xyzz28 mine = acc;  // copy: the out-of-line adder takes addresses
+      xyzz28_add_complete(mine, base);
+      acc = mine;
+    }
   }
   out = acc;
 }
