@@ -194,7 +194,7 @@ static __global__ __launch_bounds__(64) void k_challenge(const uint8_t* __restri
 
 // The same hash for LATENCY-bound batch sizes (a handful of waves on an otherwise idle chip: the proof path's 4,096-blob
 // chunks, single-blob calls): 128-thread workgroups of 64 blobs, wave 1 expands the message schedule one block ahead
-// (sha256_expand_to_lds), wave 0 runs the rounds.  3.9 ms instead of 5.6 ms per 2,050-block stream; the total
+// (sha256_expand_to_lds), wave 0 runs the rounds.  3.7 ms instead of 5.6 ms per 2,050-block stream; the total
 // instruction count is slightly higher, so batches that fill the chip keep k_challenge.
 __device__ __forceinline__ void challenge_split_workgroup(uint32_t (*wk)[64 * 64], uint64_t wg, const uint8_t* __restrict__ blobs,
                                                           const uint8_t* __restrict__ commitments48, uint64_t n, fr_t* __restrict__ z_plain) {

@@ -98,8 +98,8 @@ static int32_t proof_dev_locked(const kzg_ctx* ctx, const uint8_t* d_blobs, cons
         launch_challenge_and_decode(side, blobs, com, m, z, com, m, cstat, (const uint8_t*)nullptr, (uint64_t)0, (int32_t*)nullptr, (uint4*)nullptr,
                                     (uint8_t*)nullptr);
       } else {
-        // the commitment check (one lane per point: ~2.6 ms of latency for any chunk size) runs beside the SHA-256
-        // challenge (one lane per blob: ~5.6 ms) on a second stream; both are far too small to compete for CUs
+        // chunks above the fused-launch limit: the commitment check (one lane per point) runs beside the SHA-256
+        // challenge on a second stream
         hipStream_t dec = overlap ? side : ctx->side_stream;
         if (dec != side) {
           (void)hipEventRecord(ev_fork[k], side);

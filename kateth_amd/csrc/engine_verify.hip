@@ -281,7 +281,7 @@ extern "C" int32_t kzg_verify_phase1_dev(const kzg_ctx* ctx, const void* d_blobs
       }
       hipStream_t side = ctx->side_stream;
       // Small batches (everything together below one wave per SIMD) are latency-bound instead: there hashing and
-      // decoding are ONE launch whose workgroups the dispatcher deals over different CUs (single blob: 12.4 -> 6.2 ms
+      // decoding are ONE launch whose workgroups the dispatcher deals over different CUs (single blob: 12.4 -> 4.9 ms
       // together with the two-wave SHA-256).
       const bool small = n <= KZG_FUSED_PREP_MAX;
       if (small) {

@@ -175,7 +175,7 @@ static __global__ __launch_bounds__(64, OCC) void k_msm_fixed(const uint8_t* __r
   xyzz_canonicalize(acc);
 
   // lane sums go to HBM (12 KB per wave); the cross-lane tree and the encoding run in
-  // k_msm_finalize so that this kernel has no calls and no LDS
+  // k_msm_reduce / k_g1_compress so that this kernel has no calls and no LDS
   partials[unit * 64 + lane] = acc;
   if (BE_BYTES) {
     if (__any(bad) && lane == 0) atomicOr(&status[blob], KZG_ERR_BLOB_INVALID_FIELD_ELEMENT);

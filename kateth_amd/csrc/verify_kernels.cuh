@@ -10,14 +10,13 @@ namespace kzg {
 
 // ---------------------------------------------------------------------------
 // K1 + K5 for verification: Blob::from_slice validation + Polynomial::evaluate
-// (src/kzg/poly.rs:10-33), one wave per blob, 64 elements per lane.
+// (src/kzg/poly.rs:10-33), G lanes per blob.
 //
 // The reference spends one field inversion per element (poly.rs:26).  Here the
 // barycentric sum  S = sum_i e_i w_i / (z - w_i)  is accumulated as ONE fraction
-// per lane,  (N, D) <- (N*d_i + e_i*w_i*D, D*d_i),  d_i = z - w_i  (4 Fr mults
-// per element, nothing stored), the 64 lane fractions are merged by a shuffle
-// tree.  roots_r2[i] = w_i * R^2 (doubly Montgomery) lets the plain blob element
-// be multiplied in directly: mont_mul(e_plain, w_i R^2) = (e w_i) R.
+// per lane,  (N, D) <- (N*d + a*D, D*d)  per PAIR of elements (below), nothing stored;
+// the lane fractions are merged by a shuffle tree.  The blob elements stay plain:
+// mont_mul(plain, X*R) = plain*X, mont_mul(plain, X*R^2) = plain*X*R.
 // Because prod_i (z - w_i) = z^4096 - 1, the merged denominator cancels the
 // barycentric factor and y = N / 4096: the whole evaluation needs no inversion.
 // ---------------------------------------------------------------------------
