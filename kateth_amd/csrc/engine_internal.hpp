@@ -89,7 +89,7 @@ static inline void launch_challenge(const kzg_ctx* ctx, hipStream_t st, const ui
 }
 
 // Small batches: challenges of n blobs and decoding of n_a + n_b points in one launch (k_challenge_and_decode).
-constexpr uint64_t KZG_FUSED_PREP_MAX = 8192;
+constexpr uint64_t KZG_FUSED_PREP_MAX = 16384;  // 512 hash waves + 512 decode waves (verify): still one wave per SIMD on 256 CUs
 static inline void launch_challenge_and_decode(hipStream_t st, const uint8_t* blobs, const uint8_t* commitments48, uint64_t n, fr_t* z,
                                                const uint8_t* in_a, uint64_t n_a, int32_t* status_a, const uint8_t* in_b, uint64_t n_b,
                                                int32_t* status_b, uint4* affine, uint8_t* inf) {
