@@ -614,13 +614,13 @@ def test_host_buffer_commitment_pipeline_matches_device_path(engine, torch_cuda)
 
 
 def test_mid_size_batches_take_the_unfused_preparation_path(engine, torch_cuda):
-    """8,192 < n <= 32,768: the two-wave SHA-256 kernel runs on its own and the points are decoded on the side stream
+    """16,384 < n <= 32,768: the two-wave SHA-256 kernel runs on its own and the points are decoded on the side stream
     (smaller batches fuse the two, larger ones use the one-lane-per-blob hash); commit -> prove -> verify closes, a swapped
     proof is rejected and the proofs equal those of the fused path on a prefix"""
     torch = torch_cuda
-    n = 8200
+    n = 16500
     d_blobs = torch.empty(n * 131072, dtype=torch.uint8, device="cuda")
-    engine.synth_blobs_dev(0x8200, 0, n, d_blobs.data_ptr())
+    engine.synth_blobs_dev(0x16500, 0, n, d_blobs.data_ptr())
     d_c = torch.empty(n * 48, dtype=torch.uint8, device="cuda")
     d_p = torch.empty(n * 48, dtype=torch.uint8, device="cuda")
     d_st = torch.empty(n, dtype=torch.int32, device="cuda")
@@ -633,9 +633,9 @@ def test_mid_size_batches_take_the_unfused_preparation_path(engine, torch_cuda):
     engine.compute_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), 100, p_small.data_ptr(), d_st.data_ptr())
     torch.cuda.synchronize()
     assert p_small.cpu().numpy().tobytes() == d_p[: 100 * 48].cpu().numpy().tobytes()
-    d_p[8199 * 48: 8200 * 48] = d_p[0:48].clone()
+    d_p[(n - 1) * 48: n * 48] = d_p[0:48].clone()
     assert engine.verify_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n) is False
-    assert engine.verify_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), 8199) is True
+    assert engine.verify_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n - 1) is True
 
 
 def test_radix32_msm_kernel_is_bit_exact(golden, monkeypatch):
