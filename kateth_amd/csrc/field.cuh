@@ -659,7 +659,7 @@ KZG_HD void fp_sub(fp_t& r, const fp_t& a, const fp_t& b) { sub_mod<FpParams>(r,
 KZG_HD void fp_neg(fp_t& r, const fp_t& a) { neg_mod<FpParams>(r, a); }
 KZG_HD void fp_dbl(fp_t& r, const fp_t& a) { dbl_mod<FpParams>(r, a); }
 KZG_HD fp_t fp_one() { return mont_one<FpParams>(); }
-KZG_HD void fp_inv(fp_t& r, const fp_t& a) { mont_pow_const<FpParams>(r, a, FpInvExp()); }  // 0 -> 0
+KZG_HD void fp_inv_fermat(fp_t& r, const fp_t& a) { mont_pow_const<FpParams>(r, a, FpInvExp()); }  // a^(p-2); 0 -> 0.  fp_inv: modinv30.cuh
 // candidate square root a^((p+1)/4); caller checks r*r == a
 KZG_HD void fp_sqrt_candidate(fp_t& r, const fp_t& a) { mont_pow_const<FpParams>(r, a, FpSqrtExp()); }
 
@@ -669,7 +669,7 @@ KZG_HD void fr_add(fr_t& r, const fr_t& a, const fr_t& b) { add_mod<FrParams>(r,
 KZG_HD void fr_sub(fr_t& r, const fr_t& a, const fr_t& b) { sub_mod<FrParams>(r, a, b); }
 KZG_HD void fr_neg(fr_t& r, const fr_t& a) { neg_mod<FrParams>(r, a); }
 KZG_HD fr_t fr_one() { return mont_one<FrParams>(); }
-KZG_HD void fr_inv(fr_t& r, const fr_t& a) { mont_pow_const<FrParams>(r, a, FrInvExp()); }  // 0 -> 0
+KZG_HD void fr_inv_fermat(fr_t& r, const fr_t& a) { mont_pow_const<FrParams>(r, a, FrInvExp()); }  // a^(r-2); 0 -> 0.  fr_inv: modinv30.cuh
 
 // ---------------------------------------------------------------------------
 // byte <-> limb conversions (wire formats of src/bls.rs:130-159)
@@ -714,3 +714,5 @@ KZG_HD void fp_to_be_bytes_plain(uint8_t* p, const fp_t& a) {
 }
 
 }  // namespace kzg
+
+#include "modinv30.cuh"  // fp_inv / fr_inv (safegcd); needs everything above

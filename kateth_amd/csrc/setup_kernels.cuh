@@ -105,16 +105,7 @@ static __global__ __launch_bounds__(64) void k_table_normalize(const g1_xyzz* __
     }
   }
   fp_t inv;
-  {  // the one inversion per KN entries: sliding-window power in the radix-2^28 field (half the instructions of fp_inv)
-    fp28 t28, k, i28;
-    constexpr uint32_t r400[F28_N] = KZG_FP28_R400;
-    KZG_UNROLL_FULL
-    for (int q = 0; q < F28_N; q++) k.l[q] = r400[q];
-    f28_from_bn(t28, total);
-    f28_mul(t28, t28, k);  // total * 2^384 * 2^400 / 2^392 = total * 2^392
-    f28_inv(i28, t28);
-    f28_to_fp(inv, i28);   // back to canonical 2^384-Montgomery
-  }
+  fp_inv(inv, total);  // safegcd (modinv30.cuh): one inversion per KN entries
 #pragma unroll
   for (int k = KN - 1; k >= 0; k--) {
     if (k < m) {

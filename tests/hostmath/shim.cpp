@@ -10,6 +10,7 @@
 #include "../../kateth_amd/csrc/fp28.cuh"
 #include "../../kateth_amd/csrc/fr29.cuh"
 #include "../../kateth_amd/csrc/g1_decode28.cuh"
+#include "../../kateth_amd/csrc/modinv30.cuh"
 #include "../../kateth_amd/csrc/sha256.cuh"
 
 using namespace kzg;
@@ -397,4 +398,19 @@ extern "C" int32_t hm_g1_sum_compress28(uint8_t* out48, const uint8_t* pts48, in
   g1_compress_xyzz(ref, acc);
   g1_compress_xyzz28(out48, acc);
   return memcmp(ref, out48, 48) == 0 ? 1 : 0;
+}
+
+// ---- safegcd inversion (kateth_amd/csrc/modinv30.cuh): plain residue in, plain inverse out ----------------------
+extern "C" void hm_modinv30(int which, uint8_t* out, const uint8_t* a) {
+  if (which == 0) {
+    fp_t x, r;
+    load_le(x, a);
+    modinv30<FpInv30>(r, x);
+    store_le(out, r);
+  } else {
+    fr_t x, r;
+    load_le(x, a);
+    modinv30<FrInv30>(r, x);
+    store_le(out, r);
+  }
 }

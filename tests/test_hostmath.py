@@ -403,3 +403,21 @@ def test_g1_compress_radix28_matches_reference_path(hm):
         assert hm.hm_g1_sum_compress28(out, neg, 1) == 1 and out.raw == neg
     assert hm.hm_g1_sum_compress28(out, enc[0] + bls.g1_compress(bls.g1_neg(pts[0])), 2) == 1 and out.raw == bls.g1_compress(None)
     assert hm.hm_f28_violations() == 0
+
+
+def test_safegcd_inversion(hm):
+    """modinv30 (Bernstein-Yang divsteps on signed 30-bit limbs) against pow(a, -1, m) for Fp and Fr: edge values,
+    values with long runs of zero bits, random values; 0 -> 0"""
+    rnd = random.Random(30)
+    for which, m, nb in ((0, P, 48), (1, R, 32)):
+        out = ctypes.create_string_buffer(nb)
+        vals = [1, 2, 3, m - 1, m - 2, (m - 1) // 2, (m + 1) // 2, 1 << 30, (1 << 30) - 1, 1 << 60, (1 << (m.bit_length() - 1)), (1 << 200) + 1,
+                m - (1 << 100), 0x5555555555555555555555555555555555555555 % m]
+        vals += [rnd.randrange(1, m) for _ in range(400)]
+        vals += [rnd.randrange(1, 1 << k) for k in (1, 5, 29, 30, 31, 59, 60, 61, 90, 128) for _ in range(5)]
+        for a in vals:
+            hm.hm_modinv30(which, out, int(a).to_bytes(nb, "little"))
+            got = int.from_bytes(out.raw, "little")
+            assert got == pow(a, -1, m), (which, hex(a))
+        hm.hm_modinv30(which, out, bytes(nb))
+        assert int.from_bytes(out.raw, "little") == 0
