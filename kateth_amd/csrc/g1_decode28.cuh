@@ -65,7 +65,10 @@ KZG_HD void f28_inv(fp28& r, const fp28& a) {
   fp_t c, ci;
   f28_to_bn(c, a);
   canonicalize<FpParams>(c);
-  modinv30<FpInv30>(ci, c);
+  if (!modinv30<FpInv30>(ci, c)) {
+    f28_inv_fermat(r, a);
+    return;
+  }
   fp28 t, k;
   f28_from_bn(t, ci);
   constexpr uint32_t r3[F28_N] = KZG_FP28_R3;

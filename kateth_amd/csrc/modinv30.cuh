@@ -19,7 +19,7 @@ struct s30 {
 };
 
 struct FpInv30 {
-  static constexpr int NB = 12, NL = 13, MAX_BATCHES = 40;  // (49*381 + 80) / 17 = 1,102 divsteps suffice: 37 batches
+  static constexpr int NB = 12, NL = 13, MAX_BATCHES = 45;  // typical 26; the paper's bound (49*381 + 80) / 17 = 1,102 divsteps is 37 batches
   static constexpr uint32_t MODINV30 = KZG_FP_MODINV30;
   KZG_HD static constexpr int32_t mod(int i) {
     constexpr int32_t t[NL] = KZG_FP_MOD30;
@@ -27,7 +27,7 @@ struct FpInv30 {
   }
 };
 struct FrInv30 {
-  static constexpr int NB = 8, NL = 9, MAX_BATCHES = 28;  // (49*255 + 80) / 17 = 739 divsteps: 25 batches
+  static constexpr int NB = 8, NL = 9, MAX_BATCHES = 32;  // typical 18; the paper's bound (49*255 + 80) / 17 = 739 divsteps is 25 batches
   static constexpr uint32_t MODINV30 = KZG_FR_MODINV30;
   KZG_HD static constexpr int32_t mod(int i) {
     constexpr int32_t t[NL] = KZG_FR_MOD30;
@@ -147,9 +147,10 @@ KZG_HD void modinv30_normalize(s30<M::NL>& r, int32_t sign) {
   }
 }
 
-// r = a^-1 mod m for a canonical plain residue a (0 -> 0)
+// r = a^-1 mod m for a canonical plain residue a (0 -> 0).  Returns false if g did not reach 0 within MAX_BATCHES (never
+// observed; the callers then fall back to the Fermat power).
 template <class M>
-KZG_HD_NOINLINE void modinv30(bn<M::NB>& r, const bn<M::NB>& a) {
+KZG_HD_NOINLINE bool modinv30(bn<M::NB>& r, const bn<M::NB>& a) {
   constexpr int NL = M::NL, NB = M::NB;
   constexpr uint32_t M30 = (1u << 30) - 1u;
   s30<NL> f, g, d, e;
@@ -164,6 +165,7 @@ KZG_HD_NOINLINE void modinv30(bn<M::NB>& r, const bn<M::NB>& a) {
     e.v[i] = (i == 0) ? 1 : 0;
   }
   int32_t zeta = -1;
+  int32_t nz_last = 1;
 #pragma unroll 1
   for (int batch = 0; batch < M::MAX_BATCHES; batch++) {
     divsteps_matrix t;
@@ -173,6 +175,7 @@ KZG_HD_NOINLINE void modinv30(bn<M::NB>& r, const bn<M::NB>& a) {
     int32_t nz = 0;
     KZG_UNROLL_FULL
     for (int i = 0; i < NL; i++) nz |= g.v[i];
+    nz_last = nz;
 #if defined(__HIP_DEVICE_COMPILE__)
     if (!__any(nz != 0)) break;  // wave-uniform exit: extra divsteps with g == 0 change nothing
 #else
@@ -188,12 +191,16 @@ KZG_HD_NOINLINE void modinv30(bn<M::NB>& r, const bn<M::NB>& a) {
     if (i + 2 < NL && 60 - s < 32) x |= (uint64_t)(uint32_t)d.v[i + 2 < NL ? i + 2 : 0] << (60 - s);
     r.v[w] = (uint32_t)x;
   }
+  return nz_last == 0;
 }
 
 // Montgomery-domain inverses (radix 2^384 / 2^256): (a R)^-1 * R^3 / R = a^-1 R.  0 -> 0.
 KZG_HD void fp_inv(fp_t& r, const fp_t& a) {
   fp_t t, k;
-  modinv30<FpInv30>(t, a);
+  if (!modinv30<FpInv30>(t, a)) {
+    fp_inv_fermat(r, a);
+    return;
+  }
   constexpr uint32_t r3[12] = KZG_FP_R3;
   KZG_UNROLL_FULL
   for (int i = 0; i < 12; i++) k.v[i] = r3[i];
@@ -201,7 +208,10 @@ KZG_HD void fp_inv(fp_t& r, const fp_t& a) {
 }
 KZG_HD void fr_inv(fr_t& r, const fr_t& a) {
   fr_t t, k;
-  modinv30<FrInv30>(t, a);
+  if (!modinv30<FrInv30>(t, a)) {
+    fr_inv_fermat(r, a);
+    return;
+  }
   constexpr uint32_t r3[8] = KZG_FR_R3;
   KZG_UNROLL_FULL
   for (int i = 0; i < 8; i++) k.v[i] = r3[i];
