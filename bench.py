@@ -277,7 +277,9 @@ def main():
             "algorithmic_bytes_per_blob": ALG_BYTES_COMMIT,
             "note": "integer-ALU bound, not HBM bound: see valu_* fields and DESIGN.md section 5",
             "table_gather_bytes_per_blob": adds_per_blob * 96,
-            "valu_fp_mul_per_s": (adds_per_blob * 10 * n / (k_ms * 1e-3)) if k_ms > 0 else None,  # 10 products per mixed add
+            # multiply-equivalents per mixed add, weighted by v_mad_u64_u32 count: radix-2^28 kernel 6 products + 2 squarings
+            # (301/392 each) + 2 products sharing one reduction (588/392) = 9.04; 32-bit-limb kernel 10
+            "valu_fp_mul_per_s": (adds_per_blob * (10.0 if os.environ.get("KATETH_AMD_MSM_RADIX") == "32" else 9.04) * n / (k_ms * 1e-3)) if k_ms > 0 else None,
             "valu_fp_mul_peak_per_s": prof.get("fp_mul_peak_per_s"),
         }
         if result["roofline"]["valu_fp_mul_peak_per_s"]:
