@@ -506,7 +506,7 @@ static __global__ __launch_bounds__(512, 4) void k_poly(const uint8_t* __restric
       }
       if (t == 0) {
         fr_t wm = roots_brp[domain], wi, qm;
-        fr_inv(wi, wm);
+        fr_inv_fermat(wi, wm);  // rare branch, one thread: the leaner out-of-line power keeps the kernel at 128 VGPRs
         fr_mul(qm, tree[0], wi);  // plain sum * Montgomery 1/w_m = plain
         fr_neg(qm, qm);
         qout[domain] = qm;
