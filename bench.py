@@ -1,23 +1,36 @@
 #!/usr/bin/env python3
 """bench.py -- BASELINE.json's metric on MI355X.
 
-One "step" = one pass of the hot path over one batch of synthetic blobs that
-are already resident in HBM: `blob_to_kzg_commitment` on 4096 blobs per GPU
-(BASELINE.json configs[1]).  With --gpus N the driver launches N ranks (one per
-GPU); every rank commits its own 4096 blobs (weak scaling, blobs are
-independent) and the 48-byte commitments are all-gathered with RCCL.
+One "step" = one pass of the hot path over one batch of synthetic blobs that are
+already resident in HBM.  Default workload: `blob_to_kzg_commitment` on 4096
+blobs per GPU (BASELINE.json configs[1]); `--workload proof` is configs[2]
+(compute_blob_kzg_proof, 4096 per GPU), `--workload verify` configs[3]
+(verify_blob_kzg_proof_batch, 65,536 triples per GPU), and `--workload commit
+--batch 131072 --gpus 8` is configs[4] (2^20 blobs over 8 GPUs).
+
+`--gpus N` with no WORLD_SIZE in the environment makes THIS process the
+launcher: it starts N rank processes (one GPU each, RANK/LOCAL_RANK/WORLD_SIZE/
+MASTER_* set) before anything touches HIP and relays rank 0's JSON line.  Under
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` the ranks
+already exist and WORLD_SIZE must equal N.  Blobs are independent, so ranks own
+contiguous global index ranges (weak scaling: `--batch` blobs per rank) and the
+data path has no collective; the exchanges are one RCCL all-gather of 48 B per
+blob (commit / proof) or, for batch verification, the all-gathers of
+kateth_amd/dist.py (32-B transcript roots + first-error records, 192 B of
+partial sums).
 
 Prints ONE JSON line on rank 0 (contract in the task description) carrying
-`roofline` (dominant kernel k_msm_fixed28, HIP-event timed inside the library on
-the stream it runs on) and `cpu_baseline` (the C port of the reference's CPU
-algorithm, oracle/cport, timed on the host cores on a bounded sample).
-Secondary workloads (`compute_blob_kzg_proof`, `verify_blob_kzg_proof_batch`)
-are reported under "extra" and are not part of `value`.
+`roofline` (dominant kernel of the workload, HIP-event timed inside the library
+on the stream it runs on) and `cpu_baseline` (the C port of the reference's CPU
+algorithm, oracle/cport, timed on the host cores on a bounded sample; rank 0,
+N = 1 only).  With the default workload the proof and verify workloads are also
+reported under "extra" (each with its own roofline object); they are not part
+of `value`.
 """
 import argparse
-import ctypes
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -25,9 +38,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 BYTES_PER_BLOB = 131072
-ALG_BYTES_COMMIT = 131072 + 48  # blob in + commitment out
+ALG_BYTES = {"commit": 131072 + 48, "proof": 131072 + 48 + 48, "verify": 131072 + 96}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 SEED = 0x4844
+METRIC = {
+    "commit": "blobs/sec for blob_to_kzg_commitment (n=4096 field elements per blob)",
+    "proof": "blobs/sec for compute_blob_kzg_proof (n=4096 field elements per blob)",
+    "verify": "blobs/sec for verify_blob_kzg_proof_batch (n=4096 field elements per blob)",
+}
+DEFAULT_BATCH = {"commit": 4096, "proof": 4096, "verify": 65536}
+DTYPE = "u32 limbs (381-bit Fp / 255-bit Fr Montgomery integer arithmetic; 28/29-bit radix in the hot loops)"
 
 
 def parse():
@@ -35,22 +55,52 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=4096, help="blobs per GPU per step (BASELINE configs[1]: 4096)")
+    ap.add_argument("--workload", choices=("commit", "proof", "verify"), default="commit")
+    ap.add_argument("--batch", type=int, default=0, help="blobs per GPU per step (default: 4096 commit/proof, 65536 verify; configs[4]: 131072 with --gpus 8)")
     ap.add_argument("--window-bits", type=int, default=int(os.environ.get("KATETH_AMD_WINDOW_BITS", "16")),
-                    help="fixed-base window c (table: c=16 -> 192 GiB of the 288 GB HBM, 16 s to build; c=15 -> 102 GiB, 9 s; c=12 -> 16 GiB, 1 s); falls back to smaller windows if the table cannot be allocated")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL, the measured path) or gloo (rehearsal: gathers via host)")
+                    help="fixed-base window c (table: c=16 -> 192 GiB of the 288 GB HBM; c=15 -> 102 GiB; c=14 -> 54 GiB, the library default; c=12 -> 16 GiB); falls back to smaller windows if the table cannot be allocated")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL, the measured path) or gloo (rehearsal: ranks may share one card, gathers go through the host)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary proof/verify workloads")
     ap.add_argument("--cpu-sample", type=int, default=0, help="blobs in the CPU baseline sample (0 = auto, ~10-30 s)")
     return ap.parse_args()
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# launcher: --gpus N without a rendezvous in the environment
+# ---------------------------------------------------------------------------------------------------------------
+def launch_ranks(args):
+    """Start N rank processes of this script BEFORE anything here touches HIP (this process never imports torch),
+    relay rank 0's stdout, and exit with the first non-zero rank exit code."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(args.gpus):
+        env = dict(os.environ)
+        env.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(args.gpus), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
+                    "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+        out = subprocess.PIPE if rank == 0 else subprocess.DEVNULL
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out))
+    text, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(text.decode())
+    sys.stdout.flush()
+    bad = [c for c in codes if c != 0]
+    if bad:
+        sys.stderr.write("bench.py launcher: rank exit codes %r\n" % codes)
+        sys.exit(bad[0] if bad[0] > 0 else 1)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# CPU baseline and roofline helpers (rank 0)
+# ---------------------------------------------------------------------------------------------------------------
 def cpu_baseline(sample_blobs, setup_path, gpu_out48):
-    """oracle/cport (C port of kateth's CPU path: Pippenger c=10 signed digits as
-    blst uses, bases re-normalised on every call, one thread and all host cores)
-    timed on a bounded sample of the same synthetic blobs, rank 0 only.  Checker
-    code: never the thing measured as `value`.  Its outputs are compared byte for
-    byte with the GPU's for the same blobs."""
+    """oracle/cport (C port of kateth's CPU path: Pippenger c=10 signed digits as blst uses, bases re-normalised on
+    every call, one thread and all host cores) timed on a bounded sample of the same synthetic blobs, rank 0 only.
+    Checker code: never the thing measured as `value`.  Its outputs are compared byte for byte with the GPU's."""
     from oracle.cport import binding
 
     res = binding.time_commitment(None, setup_path, sample_blobs, SEED)
@@ -60,179 +110,290 @@ def cpu_baseline(sample_blobs, setup_path, gpu_out48):
     return res
 
 
-def pmc_traffic(n, window_bits):
-    """HBM bytes per MSM-kernel launch from the committed rocprofv3 PMC passes
-    (profiles/r01/pmc_traffic.json; separate --pmc FETCH_SIZE / WRITE_SIZE runs of this
-    same command, calibrated against the kernel's known gather bytes as MI355X_MICROARCH.md
-    prescribes: factor 1.0 for this access pattern, see the note in that file).
-    bench.py cannot run the profiler on itself, so this is the profiled value for the
-    same (batch, window) configuration, or null when none has been recorded."""
-    path = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")
-    try:
-        rec = json.load(open(path))
-        key = "n%d_c%d" % (n, window_bits)
-        return rec[key]["hbm_bytes_per_launch"] if key in rec else None
-    except (OSError, ValueError, KeyError):
+def pmc_traffic(workload, n, window_bits):
+    """HBM bytes per launch of the workload's dominant kernel from the committed rocprofv3 PMC passes (separate --pmc
+    FETCH_SIZE / WRITE_SIZE runs of this same command, corrected as MI355X_MICROARCH.md prescribes; see the note in the
+    file).  bench.py cannot run the profiler on itself, so this is the profiled value for the same (workload, batch,
+    window) configuration, or null when none has been recorded."""
+    for rel in (("profiles", "r02", "pmc_traffic.json"), ("profiles", "r01", "pmc_traffic.json")):
+        try:
+            rec = json.load(open(os.path.join(ROOT, *rel)))
+        except (OSError, ValueError):
+            continue
+        for key in ("%s_n%d_c%d" % (workload, n, window_bits), "n%d_c%d" % (n, window_bits) if workload == "commit" else ""):
+            if key and key in rec:
+                return rec[key]["hbm_bytes_per_launch"]
+    return None
+
+
+def roofline_object(workload, n, prof, window_bits):
+    """`roofline` for one workload from the library's HIP-event kernel times: achieved = algorithmic bytes per launch
+    (SURVEY.md section 8(d) bytes per blob x blobs per launch) / the dominant kernel's average launch duration."""
+    kinds = {k: v for k, v in prof["kinds"].items() if v[1]}
+    if not kinds:
         return None
+    dominant = max(kinds, key=lambda k: kinds[k][0])
+    ms_total, launches = kinds[dominant]
+    k_ms = ms_total / launches
+    calls = max(1, prof.get("calls", 1))
+    blobs_per_launch = n * calls / launches  # batches above the engine's chunk size run the kernel once per chunk
+    alg = ALG_BYTES[workload] * blobs_per_launch
+    ach = alg / (k_ms * 1e-3) / 1e9
+    summed = sum(v[0] for v in kinds.values())
+    return {
+        "kernel": dominant,
+        "bound": "hbm",
+        "achieved": ach,
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": ach / HBM_PEAK_GBS,
+        "traffic": pmc_traffic(workload, n, window_bits),
+        "kernel_ms": k_ms,
+        "launches": launches,
+        "blobs_per_launch": blobs_per_launch,
+        "algorithmic_bytes_per_blob": ALG_BYTES[workload],
+        "kernel_ms_by_class_per_call": {k: v[0] / calls for k, v in kinds.items()},
+        "summed_kernel_ms_per_call": summed / calls,
+        "achieved_over_summed_kernels": ALG_BYTES[workload] * n / (summed / calls * 1e-3) / 1e9,
+        "note": "integer-ALU bound, not HBM bound (DESIGN.md section 5): frac is the algorithmic HBM rate the north star asks for",
+    }
 
 
-def extra_workloads(torch, setup, dev, stream, d_blobs, d_commitments, n):
-    """BASELINE.json configs[2] and configs[3] (secondary numbers, not `value`):
-    compute_blob_kzg_proof on the same 4096 resident blobs, and
-    verify_blob_kzg_proof_batch on 65,536 resident (blob, commitment, proof) triples
-    (the 4096 blobs tiled 16x: every triple is valid, so the batch verifies true)."""
-    import time as _t
+# ---------------------------------------------------------------------------------------------------------------
+# one rank
+# ---------------------------------------------------------------------------------------------------------------
+class Rank:
+    def __init__(self, args, rank, local_rank, world):
+        import torch
+        import torch.distributed as dist
 
-    out = {}
-    d_proofs = torch.empty(n * 48, dtype=torch.uint8, device=dev)
-    d_status = torch.empty(n, dtype=torch.int32, device=dev)
-    setup.compute_blob_proof_batch_dev(d_blobs.data_ptr(), d_commitments.data_ptr(), n, d_proofs.data_ptr(), d_status.data_ptr(), stream)
-    torch.cuda.synchronize()
-    assert int(d_status.abs().sum()) == 0
-    t0 = _t.perf_counter()
-    reps = 2
-    for _ in range(reps):
-        setup.compute_blob_proof_batch_dev(d_blobs.data_ptr(), d_commitments.data_ptr(), n, d_proofs.data_ptr(), d_status.data_ptr(), stream)
-    torch.cuda.synchronize()
-    dt = (_t.perf_counter() - t0) / reps
-    out["compute_blob_kzg_proof"] = {"workload": "batch=%d blobs resident in HBM" % n, "blobs_per_s": n / dt, "ms_per_batch": 1e3 * dt,
-                                     "algorithmic_GBps": n * 131168 / dt / 1e9}
-    tile = max(1, 65536 // n)
-    nv = tile * n
-    vb = d_blobs.repeat(tile)
-    vc = d_commitments.repeat(tile)
-    vp = d_proofs.repeat(tile)
-    torch.cuda.synchronize()
-    ok = setup.verify_blob_proof_batch_dev(vb.data_ptr(), vc.data_ptr(), vp.data_ptr(), nv, stream)
-    assert ok is True, "verify_blob_kzg_proof_batch must accept the engine's own proofs"
-    t0 = _t.perf_counter()
-    for _ in range(reps):
-        ok = setup.verify_blob_proof_batch_dev(vb.data_ptr(), vc.data_ptr(), vp.data_ptr(), nv, stream)
-    dt = (_t.perf_counter() - t0) / reps
-    out["verify_blob_kzg_proof_batch"] = {"workload": "batch=%d (blob, commitment, proof) triples resident in HBM, includes the host pairing" % nv,
-                                          "blobs_per_s": nv / dt, "ms_per_batch": 1e3 * dt, "result": bool(ok),
-                                          "algorithmic_GBps": nv * 131168 / dt / 1e9, "hbm_frac_of_8TBps": nv * 131168 / dt / 8e12}
-    # CPU baseline for the same metric: C port of the reference's verify path on the first 32 triples
+        self.torch, self.dist, self.args = torch, dist, args
+        self.rank, self.world = rank, world
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
+        assert torch.cuda.is_available(), "bench.py needs an MI355X; the engine has no CPU fallback"
+        ndev = torch.cuda.device_count()
+        if args.backend == "nccl" and world > ndev:
+            raise SystemExit("bench.py: %d ranks but %d GPUs visible (RCCL needs one GPU per rank; use --backend gloo to rehearse on one card)" % (world, ndev))
+        self.local_dev = local_rank % max(1, ndev)  # ranks share a card only in the gloo rehearsal
+        torch.cuda.set_device(self.local_dev)
+        self.dev = torch.device("cuda", self.local_dev)
+        import kateth_amd
+
+        self.kateth_amd = kateth_amd
+        self.setup_path = os.path.join(ROOT, "tests", "golden", "trusted_setup_4096.json")
+        t0 = time.time()
+        self.setup, tried = None, []
+        for c in [args.window_bits] + [w for w in (15, 14, 12) if w < args.window_bits]:
+            try:  # the table is sized for 288 GB of HBM; step down if this device cannot hold it
+                self.setup = kateth_amd.Setup.load_json(self.setup_path, device=self.local_dev, window_bits=c)
+                break
+            except kateth_amd.kzg.EngineError as err:
+                tried.append("c=%d: %s" % (c, err))
+                torch.cuda.empty_cache()
+        assert self.setup is not None, "context creation failed for every window size: %r" % tried
+        self.t_setup = time.time() - t0
+        self.stream = torch.cuda.current_stream().cuda_stream
+
+    # -- inputs ---------------------------------------------------------------------------------------------------
+    def make_blobs(self, n, first_index):
+        d = self.torch.empty(n * BYTES_PER_BLOB, dtype=self.torch.uint8, device=self.dev)
+        self.setup.synth_blobs_dev(SEED, first_index, n, d.data_ptr(), self.stream)
+        return d
+
+    def commit(self, d_blobs, n, d_out=None, d_status=None):
+        t = self.torch
+        d_out = t.empty(n * 48, dtype=t.uint8, device=self.dev) if d_out is None else d_out
+        d_status = t.empty(n, dtype=t.int32, device=self.dev) if d_status is None else d_status
+        self.setup.blob_to_commitment_batch_dev(d_blobs.data_ptr(), n, d_out.data_ptr(), d_status.data_ptr(), self.stream)
+        return d_out, d_status
+
+    def prove(self, d_blobs, d_com, n, d_out=None, d_status=None):
+        t = self.torch
+        d_out = t.empty(n * 48, dtype=t.uint8, device=self.dev) if d_out is None else d_out
+        d_status = t.empty(n, dtype=t.int32, device=self.dev) if d_status is None else d_status
+        self.setup.compute_blob_proof_batch_dev(d_blobs.data_ptr(), d_com.data_ptr(), n, d_out.data_ptr(), d_status.data_ptr(), self.stream)
+        return d_out, d_status
+
+    def verify(self, d_blobs, d_com, d_prf, n, first_index, n_total):
+        if self.world == 1:
+            return self.setup.verify_blob_proof_batch_dev(d_blobs.data_ptr(), d_com.data_ptr(), d_prf.data_ptr(), n, self.stream)
+        from kateth_amd import dist as kdist
+
+        gather_dev = self.dev if self.args.backend == "nccl" else self.torch.device("cpu")
+        return kdist.verify_blob_proof_batch_sharded(self.setup, d_blobs.data_ptr(), d_com.data_ptr(), d_prf.data_ptr(), n, first_index, n_total,
+                                                     self.rank, self.world, gather_dev, self.stream)
+
+    def gather48(self, d_local, gathered):
+        if self.world == 1:
+            return
+        if self.args.backend == "nccl":
+            self.dist.all_gather_into_tensor(gathered, d_local)  # RCCL over xGMI: 48 B per blob
+        else:  # gloo rehearsal path: stage through the host
+            host = [self.torch.empty(d_local.numel(), dtype=self.torch.uint8) for _ in range(self.world)]
+            self.dist.all_gather(host, d_local.cpu())
+            gathered.copy_(self.torch.cat(host))
+
+    def fence(self):
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    # -- the timed region -----------------------------------------------------------------------------------------
+    def timed(self, step):
+        a = self.args
+        for _ in range(a.warmup):
+            step()
+        self.fence()
+        self.setup.profile_begin()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        self.fence()
+        elapsed = time.perf_counter() - t0
+        prof = self.setup.profile_end()
+        prof["calls"] = a.steps
+        if self.world > 1:
+            t = self.torch.tensor([elapsed], dtype=self.torch.float64, device=self.dev if a.backend == "nccl" else "cpu")
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, prof
+
+    def measure(self, fn, reps):
+        """secondary workloads: (seconds per call, profile) over `reps` calls after one warm-up call"""
+        fn()
+        self.torch.cuda.synchronize()
+        self.setup.profile_begin()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        self.torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        prof = self.setup.profile_end()
+        prof["calls"] = reps
+        return dt, prof
+
+
+def check_golden(out48, n, first_index, what):
+    golden = json.load(open(os.path.join(ROOT, "tests", "golden", "kzg_vectors.json")))
+    for rec in golden["blobs"]:
+        b = rec["index"] - first_index
+        if 0 <= b < n and what in rec:
+            assert out48[48 * b:48 * b + 48].hex() == rec[what], "GPU %s != oracle golden vector (blob %d)" % (what, rec["index"])
+
+
+def verify_cpu_baseline(R, d_blobs, d_com, d_prf, n):
+    """cpu_baseline for verify_blob_kzg_proof_batch: C port of the reference's verify path on the first 32 triples"""
     try:
         from oracle.cport import binding
 
         m = min(32, n)
         hb = d_blobs[: m * BYTES_PER_BLOB].cpu().numpy().tobytes()
-        hc = d_commitments[: m * 48].cpu().numpy().tobytes()
-        hp = d_proofs[: m * 48].cpu().numpy().tobytes()
-        out["verify_blob_kzg_proof_batch"]["cpu_baseline"] = binding.time_verify(os.path.join(ROOT, "tests", "golden", "trusted_setup_4096.json"), hb, hc, hp, m)
+        hc = d_com[: m * 48].cpu().numpy().tobytes()
+        hp = d_prf[: m * 48].cpu().numpy().tobytes()
+        return binding.time_verify(R.setup_path, hb, hc, hp, m)
     except Exception as err:  # noqa: BLE001
-        out["verify_blob_kzg_proof_batch"]["cpu_baseline"] = {"value": None, "error": repr(err)}
+        return {"value": None, "error": repr(err)}
+
+
+def extra_workloads(R, d_blobs, d_com, n):
+    """BASELINE.json configs[2] and configs[3] as secondary numbers of the default run (not `value`):
+    compute_blob_kzg_proof on the same resident blobs, and verify_blob_kzg_proof_batch on 65,536 DISTINCT resident
+    (blob, commitment, proof) triples produced by the engine itself (every triple valid: the batch verifies true)."""
+    torch, setup = R.torch, R.setup
+    out = {}
+    d_prf, d_st = R.prove(d_blobs, d_com, n)
+    torch.cuda.synchronize()
+    assert int(d_st.abs().sum()) == 0
+    check_golden(d_prf.cpu().numpy().tobytes(), n, 0, "proof")
+    dt, prof = R.measure(lambda: R.prove(d_blobs, d_com, n, d_prf, d_st), 3)
+    out["compute_blob_kzg_proof"] = {"workload": "batch=%d blobs resident in HBM (BASELINE configs[2])" % n, "blobs_per_s": n / dt, "ms_per_batch": 1e3 * dt,
+                                     "algorithmic_GBps": n * ALG_BYTES["proof"] / dt / 1e9, "roofline": roofline_object("proof", n, prof, setup.window_bits)}
+    # ---- verify: 65,536 distinct triples
+    nv = 65536
+    vb = R.make_blobs(nv, 0)
+    vc, vs = R.commit(vb, nv)
+    vp, vs2 = R.prove(vb, vc, nv)
+    torch.cuda.synchronize()
+    assert int(vs.abs().sum()) == 0 and int(vs2.abs().sum()) == 0
+    ok = R.verify(vb, vc, vp, nv, 0, nv)
+    assert ok is True, "verify_blob_kzg_proof_batch must accept the engine's own proofs"
+    dt, prof = R.measure(lambda: R.verify(vb, vc, vp, nv, 0, nv), 3)
+    rec = {"workload": "batch=%d distinct (blob, commitment, proof) triples resident in HBM, includes the host pairing (BASELINE configs[3])" % nv,
+           "blobs_per_s": nv / dt, "ms_per_batch": 1e3 * dt, "result": bool(ok), "algorithmic_GBps": nv * ALG_BYTES["verify"] / dt / 1e9,
+           "hbm_frac_of_8TBps": nv * ALG_BYTES["verify"] / dt / 8e12, "roofline": roofline_object("verify", nv, prof, setup.window_bits)}
+    rec["cpu_baseline"] = verify_cpu_baseline(R, vb, vc, vp, nv)
+    # a corrupted proof must flip the result
+    saved = vp[48 * 40000:48 * 40001].clone()
+    vp[48 * 40000:48 * 40001] = vp[0:48]
+    torch.cuda.synchronize()
+    rec["rejects_corrupted_batch"] = R.verify(vb, vc, vp, nv, 0, nv) is False
+    vp[48 * 40000:48 * 40001] = saved
+    out["verify_blob_kzg_proof_batch"] = rec
     # single-item latencies (BASELINE configs[0] shape: one blob, as benches/kzg.rs:35-43 times them)
     lat = {}
-    for name, fn in (
-        ("blob_to_kzg_commitment", lambda: setup.blob_to_commitment_batch_dev(d_blobs.data_ptr(), 1, d_commitments.data_ptr(), d_status.data_ptr(), stream)),
-        ("compute_blob_kzg_proof", lambda: setup.compute_blob_proof_batch_dev(d_blobs.data_ptr(), d_commitments.data_ptr(), 1, d_proofs.data_ptr(), d_status.data_ptr(), stream)),
-        ("verify_blob_kzg_proof", lambda: setup.verify_blob_proof_batch_dev(d_blobs.data_ptr(), d_commitments.data_ptr(), d_proofs.data_ptr(), 1, stream)),
-    ):
+    for name, fn in (("blob_to_kzg_commitment", lambda: R.commit(d_blobs, 1, d_com, d_st)), ("compute_blob_kzg_proof", lambda: R.prove(d_blobs, d_com, 1, d_prf, d_st)),
+                     ("verify_blob_kzg_proof", lambda: R.verify(d_blobs, d_com, d_prf, 1, 0, 1))):
         fn()
         torch.cuda.synchronize()
-        t0 = _t.perf_counter()
+        t0 = time.perf_counter()
         for _ in range(5):
             fn()
             torch.cuda.synchronize()
-        lat[name] = 1e3 * (_t.perf_counter() - t0) / 5
+        lat[name] = 1e3 * (time.perf_counter() - t0) / 5
     out["single_blob_latency_ms"] = lat
-    # a corrupted proof must flip the result
-    vp[48 * 7:48 * 8] = vp[0:48]
-    torch.cuda.synchronize()
-    out["verify_blob_kzg_proof_batch"]["rejects_corrupted_batch"] = (setup.verify_blob_proof_batch_dev(vb.data_ptr(), vc.data_ptr(), vp.data_ptr(), nv, stream) is False)
     return out
 
 
-def main():
-    args = parse()
-    import torch
-    import torch.distributed as dist
+def run_rank(args, rank, local_rank, world):
+    R = Rank(args, rank, local_rank, world)
+    torch, setup = R.torch, R.setup
+    wl = args.workload
+    n = args.batch or DEFAULT_BATCH[wl]
+    first = rank * n
+    d_blobs = R.make_blobs(n, first)
+    d_out = torch.empty(n * 48, dtype=torch.uint8, device=R.dev)
+    d_status = torch.empty(n, dtype=torch.int32, device=R.dev)
+    gathered = torch.empty(world * n * 48, dtype=torch.uint8, device=R.dev) if world > 1 else None
+    verdicts = []
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(args.backend, rank=rank, world_size=world)
-    assert torch.cuda.is_available(), "bench.py needs an MI355X; the engine has no CPU fallback"
-    ndev = torch.cuda.device_count()
-    local_dev = local_rank % max(1, ndev)  # one GPU per rank on a real node; ranks share a card only in the gloo rehearsal
-    torch.cuda.set_device(local_dev)
-    dev = torch.device("cuda", local_dev)
+    if wl == "commit":
+        def step():
+            R.commit(d_blobs, n, d_out, d_status)
+            R.gather48(d_out, gathered)
+    elif wl == "proof":
+        d_com, _ = R.commit(d_blobs, n)
 
-    import kateth_amd
-
-    setup_path = os.path.join(ROOT, "tests", "golden", "trusted_setup_4096.json")
-    t0 = time.time()
-    setup = None
-    tried = []
-    for c in [args.window_bits] + [w for w in (15, 14, 12) if w < args.window_bits]:
-        try:  # the table is sized for 288 GB of HBM; step down if this device cannot hold it
-            setup = kateth_amd.Setup.load_json(setup_path, device=local_dev, window_bits=c)
-            break
-        except kateth_amd.kzg.EngineError as err:
-            tried.append("c=%d: %s" % (c, err))
-            torch.cuda.empty_cache()
-    assert setup is not None, "context creation failed for every window size: %r" % tried
-    t_setup = time.time() - t0
-
-    n = args.batch
-    d_blobs = torch.empty(n * BYTES_PER_BLOB, dtype=torch.uint8, device=dev)
-    d_out = torch.empty(n * 48, dtype=torch.uint8, device=dev)
-    d_status = torch.empty(n, dtype=torch.int32, device=dev)
-    gathered = torch.empty(world * n * 48, dtype=torch.uint8, device=dev) if world > 1 else None
-    stream = torch.cuda.current_stream().cuda_stream
-    setup.synth_blobs_dev(SEED, rank * n, n, d_blobs.data_ptr(), stream)
-
-    def step():
-        setup.blob_to_commitment_batch_dev(d_blobs.data_ptr(), n, d_out.data_ptr(), d_status.data_ptr(), stream)
-        if world > 1:
-            if args.backend == "nccl":
-                dist.all_gather_into_tensor(gathered, d_out)  # RCCL over xGMI: 48 B per blob
-            else:  # gloo rehearsal path: stage through the host
-                host = [torch.empty(n * 48, dtype=torch.uint8) for _ in range(world)]
-                dist.all_gather(host, d_out.cpu())
-                gathered.copy_(torch.cat(host))
-
-    def fence():
-        if world > 1:
-            dist.barrier()
+        def step():
+            R.prove(d_blobs, d_com, n, d_out, d_status)
+            R.gather48(d_out, gathered)
+    else:
+        d_com, st1 = R.commit(d_blobs, n)
+        d_prf, st2 = R.prove(d_blobs, d_com, n)
         torch.cuda.synchronize()
+        assert int(st1.abs().sum()) == 0 and int(st2.abs().sum()) == 0
+        d_status.zero_()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    setup.profile_begin()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    prof = setup.profile_end()
+        def step():
+            verdicts.append(R.verify(d_blobs, d_com, d_prf, n, first, world * n))
 
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, prof = R.timed(step)
     assert int(d_status.abs().sum()) == 0, "synthetic blobs must all be valid"
+    if wl == "verify":
+        assert all(v is True for v in verdicts), "verify_blob_kzg_proof_batch rejected the engine's own proofs"
 
     # ---- correctness spot check of the timed output against the oracle golden vectors
     gpu_out = d_out.cpu().numpy().tobytes() if rank == 0 else b""
-    if rank == 0:
-        golden = json.load(open(os.path.join(ROOT, "tests", "golden", "kzg_vectors.json")))
-        out = gpu_out
-        for rec in golden["blobs"]:
-            b = rec["index"]
-            if b < n:
-                assert out[48 * b:48 * b + 48].hex() == rec["commitment"], "GPU commitment != oracle golden vector"
+    if rank == 0 and wl != "verify":
+        check_golden(gpu_out, n, first, "commitment" if wl == "commit" else "proof")
+    if world > 1 and wl != "verify":  # rank-ordered gather = global blob order
+        assert bytes(gathered[rank * n * 48:(rank + 1) * n * 48].cpu().numpy().tobytes()) == d_out.cpu().numpy().tobytes()
 
-    blobs_per_s = world * n * args.steps / elapsed
     result = {
-        "metric": "blobs/sec for blob_to_kzg_commitment (n=4096 field elements per blob)",
-        "value": blobs_per_s,
+        "metric": METRIC[wl],
+        "value": world * n * args.steps / elapsed,
         "unit": "blobs/s",
         "n_gpus": world,
         "steps": args.steps,
@@ -241,64 +402,72 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "u32 limbs (381-bit Fp / 255-bit Fr Montgomery integer arithmetic; 28/29-bit radix in the hot loops)",
+        "dtype": DTYPE,
         "data": "synthetic: element(b,i)=SHA-256(seed||b||i) mod r, generated on device, resident in HBM",
         "config": {
-            "workload": "blob_to_kzg_commitment batch=%d blobs per GPU (BASELINE configs[1])" % n,
+            "workload": {"commit": "blob_to_kzg_commitment batch=%d blobs per GPU (BASELINE configs[1])",
+                         "proof": "compute_blob_kzg_proof batch=%d blobs per GPU (BASELINE configs[2])",
+                         "verify": "verify_blob_kzg_proof_batch batch=%d (blob, commitment, proof) triples per GPU, host pairing included (BASELINE configs[3])"}[wl] % n
+            + (" -- configs[4] shape: %d blobs over %d GPUs" % (world * n, world) if (wl == "commit" and world * n >= 1 << 20) else ""),
             "blobs_per_gpu": n,
             "window_bits": setup.window_bits,
             "table_gib": setup.table_bytes / 2**30,
-            "parallelism": "blob-sharded x%d, RCCL all-gather of 48-B commitments" % world,
-            "setup_s": t_setup,
+            "parallelism": "blob-sharded x%d, %s" % (world, "RCCL all-gather of 48-B results" if wl != "verify" else "all-gather of 32-B transcript roots + 192-B partial sums, one pairing"),
+            "backend": args.backend if world > 1 else None,
+            "setup_s": R.t_setup,
         },
     }
     if rank == 0:
-        # measured integer-ALU ceiling: dependent Fp Montgomery multiplies with the multiply of the MSM kernel in
-        # use (radix-2^28 limbs by default), 8 waves/SIMD, whole chip.  A mixed add is 10 products (2 of them
-        # squarings, 2 sharing one reduction) plus ~900 other VALU instructions, so valu_frac is a utilisation
-        # estimate, not an exact instruction ratio; DESIGN.md section 5 gives the instruction counts.
-        lanes = 256 * 4 * 64 * 8
-        setup.microbench_fp_mul(lanes, 200)
-        prof["fp_mul_peak_per_s"] = lanes * 2000 / (setup.microbench_fp_mul(lanes, 2000) * 1e-3)
-        k_ms = prof["msm_ms"] / max(1, prof["msm_launches"])
-        alg_bytes = ALG_BYTES_COMMIT * n  # per launch: one launch processes the rank's whole batch
-        achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else None
-        adds_per_blob = prof["adds_per_blob"]
-        result["roofline"] = {
-            "kernel": "k_msm_fixed" if os.environ.get("KATETH_AMD_MSM_RADIX") == "32" else "k_msm_fixed28",
-            "bound": "hbm",
-            "achieved": achieved,
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-            "traffic": pmc_traffic(n, setup.window_bits),
-            "kernel_ms": k_ms,
-            "launches": prof["msm_launches"],
-            "algorithmic_bytes_per_blob": ALG_BYTES_COMMIT,
-            "note": "integer-ALU bound, not HBM bound: see valu_* fields and DESIGN.md section 5",
-            "table_gather_bytes_per_blob": adds_per_blob * 96,
-            # multiply-equivalents per mixed add, weighted by v_mad_u64_u32 count: radix-2^28 kernel 6 products + 2 squarings
-            # (301/392 each) + 2 products sharing one reduction (588/392) = 9.04; 32-bit-limb kernel 10
-            "valu_fp_mul_per_s": (adds_per_blob * (10.0 if os.environ.get("KATETH_AMD_MSM_RADIX") == "32" else 9.04) * n / (k_ms * 1e-3)) if k_ms > 0 else None,
-            "valu_fp_mul_peak_per_s": prof.get("fp_mul_peak_per_s"),
-        }
-        if result["roofline"]["valu_fp_mul_peak_per_s"]:
-            result["roofline"]["valu_frac"] = result["roofline"]["valu_fp_mul_per_s"] / result["roofline"]["valu_fp_mul_peak_per_s"]
-        if not args.no_extra and world == 1:
+        roof = roofline_object(wl, n, prof, setup.window_bits)
+        if wl in ("commit", "proof") and roof and prof["msm_launches"]:
+            # measured integer-ALU ceiling: dependent Fp Montgomery multiplies with the multiply of the MSM kernel
+            # (radix-2^28 limbs), 8 waves/SIMD, whole chip.  DESIGN.md section 5 gives the instruction counts.
+            lanes = 256 * 4 * 64 * 8
+            setup.microbench_fp_mul(lanes, 200)
+            peak = lanes * 2000 / (setup.microbench_fp_mul(lanes, 2000) * 1e-3)
+            msm_ms = prof["msm_ms"] / prof["msm_launches"]
+            blobs_per_launch = n * args.steps / prof["msm_launches"]
+            roof["table_gather_bytes_per_blob"] = prof["adds_per_blob"] * 96
+            # multiply-equivalents per mixed add, weighted by v_mad_u64_u32 count: 6 products + 2 squarings (301/392 each)
+            # + 2 products sharing one reduction (588/392) = 9.04
+            roof["valu_fp_mul_per_s"] = prof["adds_per_blob"] * 9.04 * blobs_per_launch / (msm_ms * 1e-3)
+            roof["valu_fp_mul_peak_per_s"] = peak
+            roof["valu_frac"] = roof["valu_fp_mul_per_s"] / peak
+        result["roofline"] = roof
+        if wl == "commit" and not args.no_extra and world == 1:
             try:
-                result["extra"] = extra_workloads(torch, setup, dev, stream, d_blobs, d_out, n)
+                result["extra"] = extra_workloads(R, d_blobs, d_out, n)
             except Exception as err:  # secondary numbers never hide the headline
                 result["extra"] = {"error": repr(err)}
         if not args.no_cpu_baseline and world == 1:
             try:
-                result["cpu_baseline"] = cpu_baseline(args.cpu_sample, setup_path, gpu_out)
+                if wl == "verify":
+                    result["cpu_baseline"] = verify_cpu_baseline(R, d_blobs, d_com, d_prf, n)
+                else:
+                    commits = gpu_out if wl == "commit" else d_com.cpu().numpy().tobytes()
+                    result["cpu_baseline"] = cpu_baseline(args.cpu_sample, R.setup_path, commits)
+                    if wl == "proof":
+                        result["cpu_baseline"]["note"] = "commitment path of the C port (the proof's second MSM has the same cost); no separate proof port is timed"
             except Exception as err:  # the baseline is reporting only; never hide the GPU number
                 result["cpu_baseline"] = {"value": None, "error": repr(err)}
         print(json.dumps(result), flush=True)
     setup.close()
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        R.dist.barrier()
+        R.dist.destroy_process_group()
+
+
+def main():
+    args = parse()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None:
+        if args.gpus > 1:
+            return launch_ranks(args)  # before any torch / HIP import in this process
+        return run_rank(args, 0, 0, 1)
+    world = int(env_world)
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node equal to --gpus" % (args.gpus, world))
+    run_rank(args, int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), world)
 
 
 if __name__ == "__main__":

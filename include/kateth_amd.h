@@ -13,9 +13,11 @@
  *
  * Plain C: pointers and sizes only.  Nothing unwinds across this boundary.
  * A kzg_ctx is immutable after creation and may be used from several host
- * threads at once (calls serialise on an internal lock around the GPU
- * workspace), matching `&self` + `Arc<Setup>` in the reference
- * (src/kzg/setup.rs:323).
+ * threads at once, matching `&self` + `Arc<Setup>` in the reference
+ * (src/kzg/setup.rs:323): commitment and proof calls serialise on an internal
+ * lock around the shared GPU workspace; every verification call takes its own
+ * pooled session (device scratch + stream) and runs beside the others; the
+ * host-buffer verification calls additionally serialise on the staging arena.
  *
  * Return value of every call: 0 on success, a positive KZG_ERR_* code when an
  * input is rejected the way the reference returns Err, a negative KZG_FAIL_*
@@ -98,6 +100,18 @@ int32_t kzg_blob_to_commitment_batch(const kzg_ctx* ctx, const uint8_t* blobs, u
 int32_t kzg_blob_to_commitment_batch_dev(const kzg_ctx* ctx, const void* d_blobs, uint64_t n, void* d_out48, void* d_status, void* hip_stream);
 
 /*
+ * The same producers with the result as the reference returns it -- a POINT, `Commitment = Proof = P1`
+ * (src/kzg/mod.rs:9-10; Setup::blob_to_commitment / blob_proof / proof, src/kzg/setup.rs:167,177,185) -- instead of its
+ * 48-byte encoding: 96 bytes per item = blst_p1_affine, i.e. x || y, each 6 x uint64 little-endian limbs of the
+ * 2^384-Montgomery residue (infinity = 96 zero bytes, as blst encodes it).  The Rust side rebuilds the `P1` with
+ * blst_p1_from_affine -- no square root on the CPU -- and callers such as benches/kzg.rs:24-32 can keep calling
+ * `.compress()` on it.  Rejected items get 96 zero bytes and their status code.
+ */
+int32_t kzg_blob_to_commitment_batch_affine(const kzg_ctx* ctx, const uint8_t* blobs, uint64_t n, uint8_t* out_affine96, int32_t* status);
+int32_t kzg_compute_blob_proof_batch_affine(const kzg_ctx* ctx, const uint8_t* blobs, const uint8_t* commitments48, uint64_t n, uint8_t* out_affine96, int32_t* status);
+int32_t kzg_compute_proof_batch_affine(const kzg_ctx* ctx, const uint8_t* blobs, const uint8_t* z32, uint64_t n, uint8_t* out_proof_affine96, uint8_t* out_y32, int32_t* status);
+
+/*
  * Replaces Setup::blob_proof + compress for n (blob, commitment) pairs
  * (src/kzg/setup.rs:177-183, src/blob.rs:55-97, src/kzg/poly.rs:10-71).
  *   status : per item 0, KZG_ERR_BLOB_*, or KZG_ERR_EC_* for the commitment
@@ -145,7 +159,8 @@ int32_t kzg_verify_proof(const kzg_ctx* ctx, const uint8_t* proof48, const uint8
  *             x||y, all-zero = infinity);
  *   finish  : on one rank, sums the gathered partials (192 B per rank) and runs
  *             the single two-pairing check.
- * A session owns its device buffers and may not be used concurrently.
+ * A session owns its device buffers and stream and may not be used concurrently; kzg_verify_session_destroy hands it
+ * back to the context's pool (steady-state verification allocates nothing).
  */
 typedef struct kzg_verify_session kzg_verify_session;
 int32_t kzg_verify_phase1_dev(const kzg_ctx* ctx, const void* d_blobs, const void* d_commitments48, const void* d_proofs48, uint64_t n_local,
@@ -153,6 +168,9 @@ int32_t kzg_verify_phase1_dev(const kzg_ctx* ctx, const void* d_blobs, const voi
 int32_t kzg_verify_phase2_dev(kzg_verify_session* session, const uint8_t* roots32, uint64_t world, uint64_t first_index, uint64_t n_total,
                               uint8_t* out192);
 void kzg_verify_session_destroy(kzg_verify_session* session);
+/* introspection (tests, debugging): the Fiat-Shamir challenges z_i (Blob::challenge, src/blob.rs:78-97) and evaluations
+ * y_i (Polynomial::evaluate, src/kzg/poly.rs:10-33) phase 1 computed for items [first, first+count), 32 B big-endian each */
+int32_t kzg_verify_session_zy(kzg_verify_session* session, uint64_t first, uint64_t count, uint8_t* out_z32, uint8_t* out_y32);
 int32_t kzg_verify_batch_finish(const kzg_ctx* ctx, const uint8_t* partials192, uint64_t world, int32_t* ok);
 
 /*
@@ -191,6 +209,14 @@ int32_t kzg_selftest_field_mul(const kzg_ctx* ctx, uint64_t lanes, uint64_t iter
  */
 int32_t kzg_profile_begin(const kzg_ctx* ctx);
 int32_t kzg_profile_end(const kzg_ctx* ctx, double* msm_ms_total, uint64_t* msm_launches);
+/*
+ * The same for every timed kernel class: ms[k] / launches[k] for k < KZG_PROF_KINDS (kzg_profile_kind_name(k) names
+ * the class: the fixed-base MSM, the SHA-256 challenge, the barycentric evaluation, point decoding, the quotient
+ * kernel, the variable-base MSMs of batch verification, lane-sum trees + encoding).  Ends the profiling interval.
+ */
+#define KZG_PROF_KINDS 7
+int32_t kzg_profile_end_kinds(const kzg_ctx* ctx, double* ms, uint64_t* launches);
+const char* kzg_profile_kind_name(int32_t kind);
 /* mixed additions the fixed-base MSM performs per blob: ceil(256/c) * 4096 */
 uint64_t kzg_ctx_adds_per_blob(const kzg_ctx* ctx);
 

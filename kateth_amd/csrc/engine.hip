@@ -75,44 +75,78 @@ extern "C" uint64_t kzg_ctx_adds_per_blob(const kzg_ctx* ctx) { return ctx ? (ui
 
 extern "C" int32_t kzg_profile_begin(const kzg_ctx* ctx) {
   if (!ctx) return fail(KZG_FAIL_ARGUMENT, "null argument");
-  std::lock_guard<std::mutex> guard(ctx->lock);
+  std::lock_guard<std::mutex> guard(ctx->prof_lock);
   ctx->profiling = true;
+  ctx->prof_used = 0;
+  return 0;
+}
+
+static const char* const PROF_NAMES[PROF_KINDS] = {"k_msm_fixed28", "k_challenge*", "k_eval_frac", "k_g1_decompress", "k_poly",
+                                                    "k_var_* (two lincombs)", "k_msm_reduce* + k_g1_compress"};
+extern "C" const char* kzg_profile_kind_name(int32_t kind) { return (kind >= 0 && kind < PROF_KINDS) ? PROF_NAMES[kind] : ""; }
+
+extern "C" int32_t kzg_profile_end_kinds(const kzg_ctx* ctx, double* ms_out, uint64_t* launches) {
+  if (!ctx || !ms_out || !launches) return fail(KZG_FAIL_ARGUMENT, "null argument");
+  std::lock_guard<std::mutex> guard(ctx->prof_lock);
+  HIP_TRY(hipSetDevice(ctx->device));
+  for (int k = 0; k < PROF_KINDS; k++) {
+    ms_out[k] = 0;
+    launches[k] = 0;
+  }
+  for (size_t i = 0; i < ctx->prof_used; i++) {
+    float ms = 0;
+    const ProfEvent& pe = ctx->prof_events[i];
+    HIP_TRY(hipEventSynchronize(pe.e1));
+    HIP_TRY(hipEventElapsedTime(&ms, pe.e0, pe.e1));
+    ms_out[pe.kind] += ms;
+    launches[pe.kind]++;
+  }
+  ctx->profiling = false;
   ctx->prof_used = 0;
   return 0;
 }
 
 extern "C" int32_t kzg_profile_end(const kzg_ctx* ctx, double* msm_ms_total, uint64_t* msm_launches) {
   if (!ctx || !msm_ms_total || !msm_launches) return fail(KZG_FAIL_ARGUMENT, "null argument");
-  std::lock_guard<std::mutex> guard(ctx->lock);
-  HIP_TRY(hipSetDevice(ctx->device));
-  double total = 0;
-  for (size_t i = 0; i < ctx->prof_used; i++) {
-    float ms = 0;
-    HIP_TRY(hipEventSynchronize(ctx->prof_events[i].second));
-    HIP_TRY(hipEventElapsedTime(&ms, ctx->prof_events[i].first, ctx->prof_events[i].second));
-    total += ms;
-  }
-  *msm_ms_total = total;
-  *msm_launches = ctx->prof_used;
-  ctx->profiling = false;
-  ctx->prof_used = 0;
+  double ms[PROF_KINDS];
+  uint64_t cnt[PROF_KINDS];
+  int32_t rc = kzg_profile_end_kinds(ctx, ms, cnt);
+  if (rc) return rc;
+  *msm_ms_total = ms[PROF_MSM_FIXED];
+  *msm_launches = cnt[PROF_MSM_FIXED];
   return 0;
 }
 
-// returns the event pair to record around the next dominant-kernel launch (or nullptrs)
-int32_t prof_next(const kzg_ctx* ctx, hipEvent_t* e0, hipEvent_t* e1) {
+// returns the event pair to record around the next launch of class `kind` (or nullptrs)
+int32_t prof_next(const kzg_ctx* ctx, int kind, hipEvent_t* e0, hipEvent_t* e1) {
   *e0 = *e1 = nullptr;
+  std::lock_guard<std::mutex> guard(ctx->prof_lock);
   if (!ctx->profiling) return 0;
   if (ctx->prof_used == ctx->prof_events.size()) {
     hipEvent_t a, b;
     HIP_TRY(hipEventCreate(&a));
     HIP_TRY(hipEventCreate(&b));
-    ctx->prof_events.emplace_back(a, b);
+    ctx->prof_events.push_back(ProfEvent{kind, a, b});
   }
-  *e0 = ctx->prof_events[ctx->prof_used].first;
-  *e1 = ctx->prof_events[ctx->prof_used].second;
-  ctx->prof_used++;
+  ProfEvent& pe = ctx->prof_events[ctx->prof_used++];
+  pe.kind = kind;
+  *e0 = pe.e0;
+  *e1 = pe.e1;
   return 0;
+}
+
+EnvKnobs read_env_knobs() {
+  {
+    EnvKnobs k;
+    k.trace = getenv("KATETH_AMD_TRACE") != nullptr;
+    if (const char* e = getenv("KATETH_AMD_PROOF_CHUNK")) k.proof_chunk = (uint64_t)atoll(e) > 0 ? (uint64_t)atoll(e) : 0;
+    if (const char* e = getenv("KATETH_AMD_PROOF_OVERLAP")) k.proof_overlap = atoi(e) != 0;
+    if (const char* e = getenv("KATETH_AMD_EVAL_GROUP")) k.eval_group = atoi(e);
+    k.verify_serial = getenv("KATETH_AMD_VERIFY_SERIAL") != nullptr;
+    if (const char* e = getenv("KATETH_AMD_VERIFY_CHUNK")) k.verify_chunk = (uint64_t)atoll(e) > 0 ? (uint64_t)atoll(e) : 0;
+    if (const char* e = getenv("KATETH_AMD_CHALLENGE_SPLIT_MAX")) k.challenge_split_max = (uint64_t)atoll(e) > 0 ? (uint64_t)atoll(e) : 0;
+    return k;
+  }
 }
 
 extern "C" int32_t kzg_ctx_window_bits(const kzg_ctx* ctx) { return ctx ? (int32_t)ctx->geom.c : 0; }
@@ -132,16 +166,33 @@ extern "C" void kzg_ctx_destroy(kzg_ctx* ctx) {
   if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   if (ctx->ws_event) (void)hipEventDestroy(ctx->ws_event);
-  for (auto& pr : ctx->prof_events) {
-    (void)hipEventDestroy(pr.first);
-    (void)hipEventDestroy(pr.second);
+  for (auto& pe : ctx->prof_events) {
+    (void)hipEventDestroy(pe.e0);
+    (void)hipEventDestroy(pe.e1);
   }
+  session_pool_clear(ctx);
+  stage_destroy(ctx);
   delete ctx;
 }
 
 
+// temporary device allocations of ctx_build: freed on every exit path
+struct ScratchAllocs {
+  std::vector<void*> ptrs;
+  template <class T>
+  hipError_t alloc(T** p, size_t bytes) {
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipSuccess) ptrs.push_back(*p);
+    return e;
+  }
+  ~ScratchAllocs() {
+    for (void* p : ptrs) (void)hipFree(p);
+  }
+};
+
 static int32_t ctx_build(kzg_ctx* ctx, const uint8_t* g1_lagrange, const uint8_t* g2_monomial) {
-  TraceTimer tt("ctx_build");
+  TraceTimer tt(ctx->knobs.trace, "ctx_build");
+  ScratchAllocs scratch;
   const MsmGeom g = ctx->geom;
   hipStream_t st = nullptr;
   // ---- G2 monomial points (host): P2::decompress of all 65 (src/kzg/setup.rs:67-72) ----
@@ -184,16 +235,14 @@ static int32_t ctx_build(kzg_ctx* ctx, const uint8_t* g1_lagrange, const uint8_t
   // ---- G1 Lagrange points: decompress, subgroup check, BRP -----------------
   uint8_t* d_in = nullptr;
   int32_t* d_status = nullptr;
-  HIP_TRY(hipMalloc(&d_in, 4096 * 48));
-  HIP_TRY(hipMalloc(&d_status, 4096 * sizeof(int32_t)));
+  HIP_TRY(scratch.alloc(&d_in, 4096 * 48));
+  HIP_TRY(scratch.alloc(&d_status, 4096 * sizeof(int32_t)));
   HIP_TRY(hipMemcpy(d_in, g1_lagrange, 4096 * 48, hipMemcpyHostToDevice));
   HIP_TRY(hipMalloc(&ctx->d_bases_brp, 4096 * 96));
   hipLaunchKernelGGL(k_setup_g1, dim3(64), dim3(64), 0, st, d_in, ctx->d_bases_brp, d_status);
   HIP_TRY(hipGetLastError());
   std::vector<int32_t> h_status(4096);
   HIP_TRY(hipMemcpy(h_status.data(), d_status, 4096 * sizeof(int32_t), hipMemcpyDeviceToHost));
-  HIP_TRY(hipFree(d_in));
-  HIP_TRY(hipFree(d_status));
   for (int i = 0; i < 4096; i++)
     if (h_status[i] != 0)
       return fail(KZG_FAIL_SETUP_G1, "g1_lagrange[" + std::to_string(i) + "] rejected, code " + std::to_string(h_status[i]) +
@@ -211,11 +260,11 @@ static int32_t ctx_build(kzg_ctx* ctx, const uint8_t* g1_lagrange, const uint8_t
   HIP_TRY(hipMalloc(&ctx->d_table, ctx->table_bytes));
   tt.mark("table allocation");
   uint4* d_win_bases = nullptr;
-  HIP_TRY(hipMalloc(&d_win_bases, (size_t)g.W * 4096 * 96));
+  HIP_TRY(scratch.alloc(&d_win_bases, (size_t)g.W * 4096 * 96));
   hipLaunchKernelGGL(k_table_window_bases, dim3(64), dim3(64), 0, st, ctx->d_bases_brp, d_win_bases, g);
   HIP_TRY(hipGetLastError());
   g1_xyzz* d_tmp = nullptr;
-  HIP_TRY(hipMalloc(&d_tmp, (size_t)4096 * g.half * sizeof(g1_xyzz)));
+  HIP_TRY(scratch.alloc(&d_tmp, (size_t)4096 * g.half * sizeof(g1_xyzz)));
   for (uint32_t j = 0; j < g.W; j++) {
     const uint32_t e = (j + 1 < g.W) ? g.half : g.top_entries;
     const uint64_t count = (uint64_t)4096 * e;
@@ -230,8 +279,6 @@ static int32_t ctx_build(kzg_ctx* ctx, const uint8_t* g1_lagrange, const uint8_t
   }
   HIP_TRY(hipDeviceSynchronize());
   tt.mark("table build kernels");
-  HIP_TRY(hipFree(d_tmp));
-  HIP_TRY(hipFree(d_win_bases));
   return 0;
 }
 
@@ -257,7 +304,10 @@ extern "C" int32_t kzg_ctx_create(const uint8_t* g1_lagrange, const uint8_t* g2_
   }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cus = (uint32_t)prop.multiProcessorCount;
-  if (const char* e = getenv("KATETH_AMD_MSM_RADIX")) ctx->msm_radix28 = atoi(e) != 32;
+  ctx->knobs = read_env_knobs();
+#if defined(KZG_TEST_RADIX32)
+  if (const char* e = getenv("KATETH_AMD_MSM_RADIX")) ctx->msm_radix28 = atoi(e) != 32;  // test-only build
+#endif
   int32_t rc = ctx_build(ctx, g1_lagrange, g2_monomial);
   if (rc != 0) {
     std::string keep = g_last_error;
@@ -272,7 +322,8 @@ extern "C" int32_t kzg_ctx_create(const uint8_t* g1_lagrange, const uint8_t* g2_
 // ---------------------------------------------------------------------------
 // blob_to_kzg_commitment
 // ---------------------------------------------------------------------------
-static int32_t commit_dev_locked(const kzg_ctx* ctx, const void* d_blobs, uint64_t n, void* d_out48, int32_t* d_status, hipStream_t st) {
+static int32_t commit_dev_locked(const kzg_ctx* ctx, const void* d_blobs, uint64_t n, void* d_out48, void* d_out_affine96, int32_t* d_status,
+                                 hipStream_t st) {
   if (n == 0) return 0;
   const uint64_t chunk_max = 16384;  // bounds the lane-partial scratch (12 KiB per blob)
   const uint64_t cn = n < chunk_max ? n : chunk_max;
@@ -287,7 +338,9 @@ static int32_t commit_dev_locked(const kzg_ctx* ctx, const void* d_blobs, uint64
   for (uint64_t base = 0; base < n; base += cn) {
     const uint64_t m = (n - base < cn) ? (n - base) : cn;
     rc = msm_pipeline<true>(ctx, reinterpret_cast<const uint8_t*>(d_blobs) + base * (uint64_t)KZG_BYTES_PER_BLOB, m,
-                            reinterpret_cast<uint8_t*>(d_out48) + base * 48, d_status + base, partials, sums, splits, st);
+                            d_out48 ? reinterpret_cast<uint8_t*>(d_out48) + base * 48 : nullptr,
+                            d_out_affine96 ? reinterpret_cast<uint8_t*>(d_out_affine96) + base * 96 : nullptr, d_status + base, partials, sums,
+                            splits, st);
     if (rc) return rc;
   }
   return 0;
@@ -300,7 +353,7 @@ extern "C" int32_t kzg_blob_to_commitment_batch_dev(const kzg_ctx* ctx, const vo
   std::lock_guard<std::mutex> guard(ctx->lock);
   hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
   int32_t rc = ws_acquire(ctx, st);
-  if (rc == 0) rc = commit_dev_locked(ctx, d_blobs, n, d_out48, reinterpret_cast<int32_t*>(d_status), st);
+  if (rc == 0) rc = commit_dev_locked(ctx, d_blobs, n, d_out48, nullptr, reinterpret_cast<int32_t*>(d_status), st);
   if (rc == 0) rc = ws_release(ctx, st);
   return rc;
 }
@@ -310,8 +363,8 @@ extern "C" int32_t kzg_blob_to_commitment_batch_dev(const kzg_ctx* ctx, const vo
 // transfer (~23 GB/s from pageable memory: 22 ms per 4,096 blobs) hides behind the MSM instead of preceding it.  Only the
 // MSM kernel is launched per chunk; the latency-bound tail (lane-sum trees, inversion + encoding) runs once per group of up
 // to 8,192 blobs -- run per 512-blob chunk it cost 24 % (63.8 ms instead of 51.3 ms per 4,096 blobs at c = 12).
-extern "C" int32_t kzg_blob_to_commitment_batch(const kzg_ctx* ctx, const uint8_t* blobs, uint64_t n, uint8_t* out48, int32_t* status) {
-  if (!ctx || (n && (!blobs || !out48 || !status))) return fail(KZG_FAIL_ARGUMENT, "null argument");
+static int32_t commit_host(const kzg_ctx* ctx, const uint8_t* blobs, uint64_t n, uint8_t* out48, uint8_t* out_affine96, int32_t* status) {
+  if (!ctx || (n && (!blobs || (!out48 && !out_affine96) || !status))) return fail(KZG_FAIL_ARGUMENT, "null argument");
   if (n == 0) return 0;
   HIP_TRY(hipSetDevice(ctx->device));
   const uint64_t chunk = n < 512 ? n : 512;
@@ -319,6 +372,7 @@ extern "C" int32_t kzg_blob_to_commitment_batch(const kzg_ctx* ctx, const uint8_
   const uint32_t splits = choose_splits(ctx, chunk);
   uint8_t* stage[2] = {nullptr, nullptr};
   uint8_t* d_out = nullptr;
+  uint8_t* d_aff = nullptr;
   int32_t* d_status = nullptr;
   hipStream_t copy_st = ctx->copy_stream, comp_st = ctx->side_stream;
   hipEvent_t done[2] = {nullptr, nullptr};
@@ -329,12 +383,14 @@ extern "C" int32_t kzg_blob_to_commitment_batch(const kzg_ctx* ctx, const uint8_
       if (done[k]) (void)hipEventDestroy(done[k]);
     }
     if (d_out) (void)hipFree(d_out);
+    if (d_aff) (void)hipFree(d_aff);
     if (d_status) (void)hipFree(d_status);
   };
   std::lock_guard<std::mutex> guard(ctx->lock);  // the workspace holds a whole group's lane sums
   do {
     if (hipMalloc(&stage[0], chunk * (size_t)KZG_BYTES_PER_BLOB) != hipSuccess ||
-        (n > chunk && hipMalloc(&stage[1], chunk * (size_t)KZG_BYTES_PER_BLOB) != hipSuccess) || hipMalloc(&d_out, n * 48) != hipSuccess ||
+        (n > chunk && hipMalloc(&stage[1], chunk * (size_t)KZG_BYTES_PER_BLOB) != hipSuccess) ||
+        (out48 && hipMalloc(&d_out, n * 48) != hipSuccess) || (out_affine96 && hipMalloc(&d_aff, n * 96) != hipSuccess) ||
         hipMalloc(&d_status, n * sizeof(int32_t)) != hipSuccess || hipEventCreateWithFlags(&done[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&done[1], hipEventDisableTiming) != hipSuccess) {
       rc = fail(KZG_FAIL_HIP, "host-buffer commitment: allocation failed");
@@ -371,7 +427,9 @@ extern "C" int32_t kzg_blob_to_commitment_batch(const kzg_ctx* ctx, const uint8_
         rc = msm_launch<true>(ctx, stage[slot], m, d_status + base, partials + (size_t)off * splits * 64, splits, comp_st);
         if (rc == 0 && hipEventRecord(done[slot], comp_st) != hipSuccess) rc = fail(KZG_FAIL_HIP, "event record failed");
       }
-      if (rc == 0) rc = msm_finish(gm, d_out + gbase * 48, d_status + gbase, partials, sums, splits, comp_st);
+      if (rc == 0)
+        rc = msm_finish(ctx, gm, d_out ? d_out + gbase * 48 : nullptr, d_aff ? d_aff + gbase * 96 : nullptr, d_status + gbase, partials, sums, splits,
+                        comp_st);
     }
     if (rc) break;
     rc = ws_release(ctx, comp_st);
@@ -380,13 +438,23 @@ extern "C" int32_t kzg_blob_to_commitment_batch(const kzg_ctx* ctx, const uint8_
       rc = fail(KZG_FAIL_HIP, "stream synchronize failed");
       break;
     }
-    if (hipMemcpy(out48, d_out, n * 48, hipMemcpyDeviceToHost) != hipSuccess ||
+    if ((out48 && hipMemcpy(out48, d_out, n * 48, hipMemcpyDeviceToHost) != hipSuccess) ||
+        (out_affine96 && hipMemcpy(out_affine96, d_aff, n * 96, hipMemcpyDeviceToHost) != hipSuccess) ||
         hipMemcpy(status, d_status, n * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess)
       rc = fail(KZG_FAIL_HIP, "device-to-host copy failed");
   } while (0);
   if (rc) (void)hipDeviceSynchronize();
   cleanup();
   return rc;
+}
+
+extern "C" int32_t kzg_blob_to_commitment_batch(const kzg_ctx* ctx, const uint8_t* blobs, uint64_t n, uint8_t* out48, int32_t* status) {
+  if (n && !out48) return fail(KZG_FAIL_ARGUMENT, "null argument");
+  return commit_host(ctx, blobs, n, out48, nullptr, status);
+}
+extern "C" int32_t kzg_blob_to_commitment_batch_affine(const kzg_ctx* ctx, const uint8_t* blobs, uint64_t n, uint8_t* out_affine96, int32_t* status) {
+  if (n && !out_affine96) return fail(KZG_FAIL_ARGUMENT, "null argument");
+  return commit_host(ctx, blobs, n, nullptr, out_affine96, status);
 }
 
 // ---------------------------------------------------------------------------

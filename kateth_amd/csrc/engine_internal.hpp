@@ -29,11 +29,23 @@ const std::string& last_error_text();
     if (_e != hipSuccess) return fail(KZG_FAIL_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));  \
   } while (0)
 
+// Environment knobs are read ONCE, at kzg_ctx_create, into the context -- never on a call path.
+struct EnvKnobs {
+  bool trace = false;            // KATETH_AMD_TRACE
+  uint64_t proof_chunk = 0;      // KATETH_AMD_PROOF_CHUNK (0 = default)
+  int proof_overlap = -1;        // KATETH_AMD_PROOF_OVERLAP (-1 = default)
+  int eval_group = 0;            // KATETH_AMD_EVAL_GROUP: 16 | 64 (0 = automatic)
+  bool verify_serial = false;    // KATETH_AMD_VERIFY_SERIAL
+  uint64_t verify_chunk = 0;     // KATETH_AMD_VERIFY_CHUNK: blobs per host-buffer staging chunk (0 = default)
+  uint64_t challenge_split_max = 0;  // KATETH_AMD_CHALLENGE_SPLIT_MAX: largest batch hashed by the two-wave SHA-256 kernel (0 = default)
+};
+EnvKnobs read_env_knobs();
+
 struct TraceTimer {  // KATETH_AMD_TRACE=1: host-side wall-clock marks on stderr
   bool on;
   std::chrono::steady_clock::time_point t0;
   const char* what;
-  explicit TraceTimer(const char* w) : on(getenv("KATETH_AMD_TRACE") != nullptr), t0(std::chrono::steady_clock::now()), what(w) {}
+  TraceTimer(bool enabled, const char* w) : on(enabled), t0(std::chrono::steady_clock::now()), what(w) {}
   void mark(const char* label) {
     if (!on) return;
     auto t1 = std::chrono::steady_clock::now();
@@ -42,6 +54,17 @@ struct TraceTimer {  // KATETH_AMD_TRACE=1: host-side wall-clock marks on stderr
   }
 };
 
+constexpr int KZG_STAGE_SLOTS = 16;   // x 512 blobs x 128 KiB = 1 GiB of staging at most
+constexpr int KZG_STAGE_STREAMS = 4;  // per-chunk kernels rotate over these (a chunk's SHA-256 streams are latency-bound: several in flight)
+#define KZG_SESSION_STREAM (reinterpret_cast<hipStream_t>(static_cast<intptr_t>(-1)))  // session_acquire: run on the session's own stream
+enum ProfKind { PROF_MSM_FIXED = 0, PROF_CHALLENGE, PROF_EVAL, PROF_DECODE, PROF_POLY, PROF_VAR_MSM, PROF_REDUCE_COMPRESS, PROF_KINDS };
+static_assert(PROF_KINDS == KZG_PROF_KINDS, "include/kateth_amd.h and ProfKind disagree");
+struct ProfEvent {
+  int kind;
+  hipEvent_t e0, e1;
+};
+
+struct kzg_verify_session;
 struct kzg_ctx {
   int device = 0;
   MsmGeom geom{};
@@ -58,21 +81,49 @@ struct kzg_ctx {
   // true (default): table in 2^392-Montgomery form, k_msm_fixed28 (radix-2^28 limbs, fp28.cuh);
   // KATETH_AMD_MSM_RADIX=32 at context creation: 2^384-Montgomery table, k_msm_fixed (12 x 32-bit limbs)
   bool msm_radix28 = true;
+  EnvKnobs knobs;  // read once at kzg_ctx_create
   // workspace (grown on demand, guarded by lock)
   mutable std::mutex lock;
   mutable void* ws = nullptr;
   mutable size_t ws_bytes = 0;
   mutable hipEvent_t ws_event = nullptr;  // recorded after the last enqueued user of `ws`; the next user's stream waits on it
-  // profiling (kzg_profile_begin/end): event pairs around k_msm_fixed launches
+  // profiling (kzg_profile_begin/end): event pairs around the launches of the kernels named by ProfKind, each pair on the
+  // stream its kernel runs on; own lock (the verify entry points do not take `lock`)
+  mutable std::mutex prof_lock;
   mutable bool profiling = false;
-  mutable std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+  mutable std::vector<ProfEvent> prof_events;
   mutable size_t prof_used = 0;
+  // pooled verify sessions (device scratch + side stream + events), engine_verify.hip
+  mutable std::mutex pool_lock;
+  mutable std::vector<kzg_verify_session*> session_pool;
+  // host-buffer verification pipeline (engine_verify.hip), guarded by stage_lock: a staging arena of up to
+  // KZG_STAGE_SLOTS chunk slots, a copy stream, rotating compute streams and their events; created on first use
+  mutable std::mutex stage_lock;
+  mutable uint8_t* stage = nullptr;
+  mutable size_t stage_bytes = 0;
+  mutable bool stage_ready = false;
+  mutable hipStream_t verify_stream = nullptr, stage_copy_stream = nullptr, stage_streams[KZG_STAGE_STREAMS] = {};
+  mutable hipEvent_t stage_copied[KZG_STAGE_SLOTS] = {}, stage_done[KZG_STAGE_SLOTS] = {}, stage_join[KZG_STAGE_STREAMS] = {};
 };
+void session_pool_clear(const kzg_ctx* ctx);
+void stage_destroy(const kzg_ctx* ctx);
 
 int32_t ws_reserve(const kzg_ctx* ctx, size_t bytes);
 int32_t ws_acquire(const kzg_ctx* ctx, hipStream_t st);
 int32_t ws_release(const kzg_ctx* ctx, hipStream_t st);
-int32_t prof_next(const kzg_ctx* ctx, hipEvent_t* e0, hipEvent_t* e1);
+int32_t prof_next(const kzg_ctx* ctx, int kind, hipEvent_t* e0, hipEvent_t* e1);
+// brackets the launches enqueued on `st` during its lifetime with an event pair (no-op unless profiling)
+struct ProfScope {
+  hipEvent_t e1 = nullptr;
+  hipStream_t st;
+  ProfScope(const kzg_ctx* ctx, int kind, hipStream_t s) : st(s) {
+    hipEvent_t e0 = nullptr;
+    if (ctx->profiling && prof_next(ctx, kind, &e0, &e1) == 0 && e0) (void)hipEventRecord(e0, st);
+  }
+  ~ProfScope() {
+    if (e1) (void)hipEventRecord(e1, st);
+  }
+};
 uint32_t choose_splits(const kzg_ctx* ctx, uint64_t n);
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static inline unsigned blocks_for(uint64_t n, unsigned per) { return (unsigned)((n + per - 1) / per); }
@@ -81,7 +132,9 @@ static inline unsigned blocks_for(uint64_t n, unsigned per) { return (unsigned)(
 // SHA-256 block); beyond that the chip is full and the one-lane-per-blob kernel does less total work.
 static inline void launch_challenge(const kzg_ctx* ctx, hipStream_t st, const uint8_t* blobs, const uint8_t* commitments48, uint64_t n, fr_t* z) {
   if (n == 0) return;
-  const uint64_t split_max = (uint64_t)ctx->num_cus * 4 * 64 / 2;  // 2 waves per 64 blobs, one wave per SIMD: 32,768 on 256 CUs
+  ProfScope ps(ctx, PROF_CHALLENGE, st);
+  uint64_t split_max = (uint64_t)ctx->num_cus * 4 * 64 / 2;  // 2 waves per 64 blobs, one wave per SIMD: 32,768 on 256 CUs
+  if (ctx->knobs.challenge_split_max) split_max = ctx->knobs.challenge_split_max;
   if (n <= split_max)
     hipLaunchKernelGGL(k_challenge_split, dim3(blocks_for(n, 64)), dim3(128), 0, st, blobs, commitments48, n, z);
   else
@@ -90,9 +143,10 @@ static inline void launch_challenge(const kzg_ctx* ctx, hipStream_t st, const ui
 
 // Small batches: challenges of n blobs and decoding of n_a + n_b points in one launch (k_challenge_and_decode).
 constexpr uint64_t KZG_FUSED_PREP_MAX = 16384;  // 512 hash waves + 512 decode waves (verify): still one wave per SIMD on 256 CUs
-static inline void launch_challenge_and_decode(hipStream_t st, const uint8_t* blobs, const uint8_t* commitments48, uint64_t n, fr_t* z,
+static inline void launch_challenge_and_decode(const kzg_ctx* ctx, hipStream_t st, const uint8_t* blobs, const uint8_t* commitments48, uint64_t n, fr_t* z,
                                                const uint8_t* in_a, uint64_t n_a, int32_t* status_a, const uint8_t* in_b, uint64_t n_b,
                                                int32_t* status_b, uint4* affine, uint8_t* inf) {
+  ProfScope ps(ctx, PROF_CHALLENGE, st);
   const uint32_t sha_wgs = (uint32_t)blocks_for(n, 64);
   const uint32_t dec_wgs = (uint32_t)blocks_for(n_a + n_b, 128);
   hipLaunchKernelGGL(k_challenge_and_decode, dim3(sha_wgs + dec_wgs), dim3(128), 0, st, blobs, commitments48, n, z, sha_wgs, in_a, n_a, status_a, in_b,
@@ -104,37 +158,36 @@ static inline void launch_challenge_and_decode(hipStream_t st, const uint8_t* bl
 template <bool BE_BYTES>
 static int32_t msm_launch(const kzg_ctx* ctx, const uint8_t* d_scalars, uint64_t n, int32_t* d_status, g1_xyzz* partials, uint32_t splits,
                           hipStream_t st) {
-  hipEvent_t pe0, pe1;
-  int32_t rc = prof_next(ctx, &pe0, &pe1);
-  if (rc) return rc;
-  if (pe0) HIP_TRY(hipEventRecord(pe0, st));
-  if (ctx->msm_radix28)
-    hipLaunchKernelGGL((k_msm_fixed28<BE_BYTES>), dim3((unsigned)(n * splits)), dim3(64), 0, st, d_scalars, splits, ctx->d_table, ctx->geom,
-                       partials, d_status);
-  else
+  ProfScope ps(ctx, PROF_MSM_FIXED, st);
+#if defined(KZG_TEST_RADIX32)
+  if (!ctx->msm_radix28)  // test-only build (tests/radix32): the 12 x 32-bit-limb kernel as an independent cross-check
     hipLaunchKernelGGL((k_msm_fixed<BE_BYTES, 2>), dim3((unsigned)(n * splits)), dim3(64), 0, st, d_scalars, splits, ctx->d_table, ctx->geom,
                        partials, d_status);
+  else
+#endif
+    hipLaunchKernelGGL((k_msm_fixed28<BE_BYTES>), dim3((unsigned)(n * splits)), dim3(64), 0, st, d_scalars, splits, ctx->d_table, ctx->geom,
+                       partials, d_status);
   HIP_TRY(hipGetLastError());
-  if (pe1) HIP_TRY(hipEventRecord(pe1, st));
   return 0;
 }
 // Lane sums of n blobs -> 48-byte encodings.  Two tree stages: the 64 lane sums of every (blob, split) unit, then the units
 // of a blob -- 6 + log2(splits) levels of latency instead of the splits + 5 a sequential walk over the splits costs (a
 // single blob uses 64 splits).  `partials` must have room for n * splits unit sums after the n * splits * 64 lane sums.
-static inline int32_t msm_finish(uint64_t n, uint8_t* d_out48, const int32_t* d_status, g1_xyzz* partials, g1_xyzz* sums, uint32_t splits,
-                                 hipStream_t st) {
+static inline int32_t msm_finish(const kzg_ctx* ctx, uint64_t n, uint8_t* d_out48, uint8_t* d_out_affine96, const int32_t* d_status, g1_xyzz* partials,
+                                 g1_xyzz* sums, uint32_t splits, hipStream_t st) {
+  ProfScope ps(ctx, PROF_REDUCE_COMPRESS, st);
   g1_xyzz* unit_sums = (splits == 1) ? sums : partials + (size_t)n * splits * 64;
   hipLaunchKernelGGL(k_msm_reduce, dim3((unsigned)(n * splits)), dim3(64), 0, st, partials, n * splits, unit_sums);
   if (splits > 1) hipLaunchKernelGGL(k_msm_reduce_splits, dim3((unsigned)n), dim3(64), 0, st, unit_sums, splits, n, sums);
-  hipLaunchKernelGGL(k_g1_compress, dim3(blocks_for(n, 64)), dim3(64), 0, st, sums, n, d_status, d_out48);
+  hipLaunchKernelGGL(k_g1_compress, dim3(blocks_for(n, 64)), dim3(64), 0, st, sums, n, d_status, d_out48, d_out_affine96);
   HIP_TRY(hipGetLastError());
   return 0;
 }
 // MSM + reduce + compress
 template <bool BE_BYTES>
-static int32_t msm_pipeline(const kzg_ctx* ctx, const uint8_t* d_scalars, uint64_t n, uint8_t* d_out48, int32_t* d_status, g1_xyzz* partials,
-                            g1_xyzz* sums, uint32_t splits, hipStream_t st) {
+static int32_t msm_pipeline(const kzg_ctx* ctx, const uint8_t* d_scalars, uint64_t n, uint8_t* d_out48, uint8_t* d_out_affine96, int32_t* d_status,
+                            g1_xyzz* partials, g1_xyzz* sums, uint32_t splits, hipStream_t st) {
   int32_t rc = msm_launch<BE_BYTES>(ctx, d_scalars, n, d_status, partials, splits, st);
   if (rc) return rc;
-  return msm_finish(n, d_out48, d_status, partials, sums, splits, st);
+  return msm_finish(ctx, n, d_out48, d_out_affine96, d_status, partials, sums, splits, st);
 }

@@ -20,7 +20,7 @@ __global__ __launch_bounds__(256) void k_fr_store_be(const fr_t* __restrict__ pl
 //   d_commitments48 != null : blob proofs (z from the Fiat-Shamir challenge)
 //   d_z32 != null           : proofs at caller-supplied points; y written to d_y32
 static int32_t proof_dev_locked(const kzg_ctx* ctx, const uint8_t* d_blobs, const uint8_t* d_commitments48, const uint8_t* d_z32, uint64_t n,
-                                uint8_t* d_out48, uint8_t* d_y32, int32_t* d_status, hipStream_t st) {
+                                uint8_t* d_out48, uint8_t* d_out_affine96, uint8_t* d_y32, int32_t* d_status, hipStream_t st) {
   if (n == 0) return 0;
   // Chunks of up to 16,384 blobs (quotient scratch: 128 KiB per blob = 2 GiB per chunk).  The per-chunk preparation
   // starts with ~6 ms of pure latency (one SHA-256 stream per blob, 2,050 sequential blocks) during which the GPU is
@@ -29,10 +29,8 @@ static int32_t proof_dev_locked(const kzg_ctx* ctx, const uint8_t* d_blobs, cons
   // when the MSM finished).  So FEW, LARGE chunks win -- measured at n = 16,384, c = 12: 4 x 4,096 serial 244 ms,
   // 4 x 4,096 on two streams 242 ms, 2 x 8,192 224 ms, 8 x 2,048 279 ms (profiles/r01/proof_pipeline_variants.txt).
   // The two-stream pipeline stays selectable (KATETH_AMD_PROOF_OVERLAP=1, KATETH_AMD_PROOF_CHUNK).
-  uint64_t chunk_max = 16384;
-  bool overlap = false;
-  if (const char* e = getenv("KATETH_AMD_PROOF_CHUNK")) chunk_max = (uint64_t)atoll(e) > 0 ? (uint64_t)atoll(e) : chunk_max;
-  if (const char* e = getenv("KATETH_AMD_PROOF_OVERLAP")) overlap = atoi(e) != 0;
+  uint64_t chunk_max = ctx->knobs.proof_chunk ? ctx->knobs.proof_chunk : 16384;
+  bool overlap = ctx->knobs.proof_overlap > 0;
   const uint64_t cn = n < chunk_max ? n : chunk_max;
   const uint64_t nchunks = (n + cn - 1) / cn;
   const uint32_t splits = choose_splits(ctx, cn);
@@ -95,7 +93,7 @@ static int32_t proof_dev_locked(const kzg_ctx* ctx, const uint8_t* d_blobs, cons
       const uint8_t* com = d_commitments48 + base * 48;
       if (m <= KZG_FUSED_PREP_MAX) {
         // commitment check and SHA-256 challenge in one launch: both are long per-lane dependency chains and must not share SIMDs
-        launch_challenge_and_decode(side, blobs, com, m, z, com, m, cstat, (const uint8_t*)nullptr, (uint64_t)0, (int32_t*)nullptr, (uint4*)nullptr,
+        launch_challenge_and_decode(ctx, side, blobs, com, m, z, com, m, cstat, (const uint8_t*)nullptr, (uint64_t)0, (int32_t*)nullptr, (uint4*)nullptr,
                                     (uint8_t*)nullptr);
       } else {
         // chunks above the fused-launch limit: the commitment check (one lane per point) runs beside the SHA-256
@@ -114,8 +112,11 @@ static int32_t proof_dev_locked(const kzg_ctx* ctx, const uint8_t* d_blobs, cons
     } else {
       hipLaunchKernelGGL(k_fr_parse, dim3(blocks_for(m, 64)), dim3(64), 0, side, d_z32 + base * 32, m, z, cstat);
     }
-    hipLaunchKernelGGL(k_poly_root_inverse, dim3(blocks_for(m, 64)), dim3(64), 0, side, z, m, invr);
-    hipLaunchKernelGGL(k_poly<true>, dim3((unsigned)m), dim3(512), 0, side, blobs, z, ctx->d_roots_brp, invr, y, q, d_status + base);
+    {
+      ProfScope ps(ctx, PROF_POLY, side);
+      hipLaunchKernelGGL(k_poly_root_inverse, dim3(blocks_for(m, 64)), dim3(64), 0, side, z, m, invr);
+      hipLaunchKernelGGL(k_poly<true>, dim3((unsigned)m), dim3(512), 0, side, blobs, z, ctx->d_roots_brp, invr, y, q, d_status + base);
+    }
     hipLaunchKernelGGL(k_merge_status, dim3(blocks_for(m, 256)), dim3(256), 0, side, d_status + base, cstat, m);
     (void)hipEventRecord(ev_prep[k], side);
   };
@@ -129,7 +130,8 @@ static int32_t proof_dev_locked(const kzg_ctx* ctx, const uint8_t* d_blobs, cons
       fr_t* y = reinterpret_cast<fr_t*>(ws + o_y[sl]);
       fr_t* q = reinterpret_cast<fr_t*>(ws + o_q[sl]);
       (void)hipStreamWaitEvent(st, ev_prep[k], 0);
-      rc = msm_pipeline<false>(ctx, reinterpret_cast<const uint8_t*>(q), m, d_out48 + base * 48, d_status + base, partials, sums, splits, st);
+      rc = msm_pipeline<false>(ctx, reinterpret_cast<const uint8_t*>(q), m, d_out48 ? d_out48 + base * 48 : nullptr,
+                               d_out_affine96 ? d_out_affine96 + base * 96 : nullptr, d_status + base, partials, sums, splits, st);
       if (rc) break;
       if (d_y32) hipLaunchKernelGGL(k_fr_store_be, dim3(blocks_for(m, 256)), dim3(256), 0, st, y, m, d_status + base, d_y32 + base * 32);
       (void)hipEventRecord(ev_done[k], st);
@@ -149,7 +151,7 @@ extern "C" int32_t kzg_compute_blob_proof_batch_dev(const kzg_ctx* ctx, const vo
   hipStream_t st = (hipStream_t)hip_stream;
   int32_t rc = ws_acquire(ctx, st);
   if (rc == 0)
-    rc = proof_dev_locked(ctx, (const uint8_t*)d_blobs, (const uint8_t*)d_commitments48, nullptr, n, (uint8_t*)d_out48, nullptr,
+    rc = proof_dev_locked(ctx, (const uint8_t*)d_blobs, (const uint8_t*)d_commitments48, nullptr, n, (uint8_t*)d_out48, nullptr, nullptr,
                           (int32_t*)d_status, st);
   if (rc == 0) rc = ws_release(ctx, st);
   return rc;
@@ -157,47 +159,68 @@ extern "C" int32_t kzg_compute_blob_proof_batch_dev(const kzg_ctx* ctx, const vo
 
 // host-buffer wrapper shared by the two proof entry points
 static int32_t proof_host(const kzg_ctx* ctx, const uint8_t* blobs, const uint8_t* side, size_t side_bytes, bool side_is_commitment, uint64_t n,
-                          uint8_t* out48, uint8_t* out_y32, int32_t* status) {
+                          uint8_t* out48, uint8_t* out_affine96, uint8_t* out_y32, int32_t* status) {
   if (n == 0) return 0;
   HIP_TRY(hipSetDevice(ctx->device));
-  uint8_t *d_blobs = nullptr, *d_side = nullptr, *d_out = nullptr, *d_y = nullptr;
+  uint8_t *d_blobs = nullptr, *d_side = nullptr, *d_out = nullptr, *d_aff = nullptr, *d_y = nullptr;
   int32_t* d_status = nullptr;
-  HIP_TRY(hipMalloc(&d_blobs, n * (size_t)KZG_BYTES_PER_BLOB));
-  HIP_TRY(hipMalloc(&d_side, n * side_bytes));
-  HIP_TRY(hipMalloc(&d_out, n * 48));
-  HIP_TRY(hipMalloc(&d_y, n * 32));
-  HIP_TRY(hipMalloc(&d_status, n * sizeof(int32_t)));
-  HIP_TRY(hipMemcpy(d_blobs, blobs, n * (size_t)KZG_BYTES_PER_BLOB, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(d_side, side, n * side_bytes, hipMemcpyHostToDevice));
-  int32_t rc;
-  {
-    std::lock_guard<std::mutex> guard(ctx->lock);
-    rc = proof_dev_locked(ctx, d_blobs, side_is_commitment ? d_side : nullptr, side_is_commitment ? nullptr : d_side, n, d_out,
-                          out_y32 ? d_y : nullptr, d_status, nullptr);
-    if (rc == 0 && hipStreamSynchronize(nullptr) != hipSuccess) rc = fail(KZG_FAIL_HIP, "stream synchronize failed");
-  }
-  if (rc == 0) {
-    HIP_TRY(hipMemcpy(out48, d_out, n * 48, hipMemcpyDeviceToHost));
-    if (out_y32) HIP_TRY(hipMemcpy(out_y32, d_y, n * 32, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(status, d_status, n * sizeof(int32_t), hipMemcpyDeviceToHost));
-  }
-  (void)hipFree(d_blobs);
-  (void)hipFree(d_side);
-  (void)hipFree(d_out);
-  (void)hipFree(d_y);
-  (void)hipFree(d_status);
+  auto cleanup = [&]() {  // every exit path frees every allocation (a failed hipMalloc of the n * 128 KiB buffer is the likely failure)
+    for (void* p : {(void*)d_blobs, (void*)d_side, (void*)d_out, (void*)d_aff, (void*)d_y, (void*)d_status})
+      if (p) (void)hipFree(p);
+  };
+  int32_t rc = 0;
+  do {
+    if (hipMalloc(&d_blobs, n * (size_t)KZG_BYTES_PER_BLOB) != hipSuccess || hipMalloc(&d_side, n * side_bytes) != hipSuccess ||
+        (out48 && hipMalloc(&d_out, n * 48) != hipSuccess) || (out_affine96 && hipMalloc(&d_aff, n * 96) != hipSuccess) ||
+        hipMalloc(&d_y, n * 32) != hipSuccess || hipMalloc(&d_status, n * sizeof(int32_t)) != hipSuccess) {
+      rc = fail(KZG_FAIL_HIP, "host-buffer proof: device allocation failed");
+      break;
+    }
+    if (hipMemcpy(d_blobs, blobs, n * (size_t)KZG_BYTES_PER_BLOB, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d_side, side, n * side_bytes, hipMemcpyHostToDevice) != hipSuccess) {
+      rc = fail(KZG_FAIL_HIP, "host-to-device copy failed");
+      break;
+    }
+    {
+      std::lock_guard<std::mutex> guard(ctx->lock);
+      hipStream_t st = ctx->copy_stream;  // an idle non-blocking stream (the null stream would serialise against every blocking stream of the process)
+      rc = ws_acquire(ctx, st);
+      if (rc == 0)
+        rc = proof_dev_locked(ctx, d_blobs, side_is_commitment ? d_side : nullptr, side_is_commitment ? nullptr : d_side, n, d_out, d_aff,
+                              out_y32 ? d_y : nullptr, d_status, st);
+      if (rc == 0) rc = ws_release(ctx, st);
+      if (rc == 0 && hipStreamSynchronize(st) != hipSuccess) rc = fail(KZG_FAIL_HIP, "stream synchronize failed");
+    }
+    if (rc) break;
+    if ((out48 && hipMemcpy(out48, d_out, n * 48, hipMemcpyDeviceToHost) != hipSuccess) ||
+        (out_affine96 && hipMemcpy(out_affine96, d_aff, n * 96, hipMemcpyDeviceToHost) != hipSuccess) ||
+        (out_y32 && hipMemcpy(out_y32, d_y, n * 32, hipMemcpyDeviceToHost) != hipSuccess) ||
+        hipMemcpy(status, d_status, n * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess)
+      rc = fail(KZG_FAIL_HIP, "device-to-host copy failed");
+  } while (0);
+  if (rc) (void)hipDeviceSynchronize();
+  cleanup();
   return rc;
 }
 
 extern "C" int32_t kzg_compute_blob_proof_batch(const kzg_ctx* ctx, const uint8_t* blobs, const uint8_t* commitments48, uint64_t n,
                                                 uint8_t* out48, int32_t* status) {
   if (!ctx || (n && (!blobs || !commitments48 || !out48 || !status))) return fail(KZG_FAIL_ARGUMENT, "null argument");
-  return proof_host(ctx, blobs, commitments48, 48, true, n, out48, nullptr, status);
+  return proof_host(ctx, blobs, commitments48, 48, true, n, out48, nullptr, nullptr, status);
+}
+extern "C" int32_t kzg_compute_blob_proof_batch_affine(const kzg_ctx* ctx, const uint8_t* blobs, const uint8_t* commitments48, uint64_t n,
+                                                       uint8_t* out_affine96, int32_t* status) {
+  if (!ctx || (n && (!blobs || !commitments48 || !out_affine96 || !status))) return fail(KZG_FAIL_ARGUMENT, "null argument");
+  return proof_host(ctx, blobs, commitments48, 48, true, n, nullptr, out_affine96, nullptr, status);
 }
 
 extern "C" int32_t kzg_compute_proof_batch(const kzg_ctx* ctx, const uint8_t* blobs, const uint8_t* z32, uint64_t n, uint8_t* out_proof48,
                                            uint8_t* out_y32, int32_t* status) {
   if (!ctx || (n && (!blobs || !z32 || !out_proof48 || !out_y32 || !status))) return fail(KZG_FAIL_ARGUMENT, "null argument");
-  return proof_host(ctx, blobs, z32, 32, false, n, out_proof48, out_y32, status);
+  return proof_host(ctx, blobs, z32, 32, false, n, out_proof48, nullptr, out_y32, status);
 }
-
+extern "C" int32_t kzg_compute_proof_batch_affine(const kzg_ctx* ctx, const uint8_t* blobs, const uint8_t* z32, uint64_t n, uint8_t* out_proof_affine96,
+                                                  uint8_t* out_y32, int32_t* status) {
+  if (!ctx || (n && (!blobs || !z32 || !out_proof_affine96 || !out_y32 || !status))) return fail(KZG_FAIL_ARGUMENT, "null argument");
+  return proof_host(ctx, blobs, z32, 32, false, n, nullptr, out_proof_affine96, out_y32, status);
+}

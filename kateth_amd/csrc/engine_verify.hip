@@ -7,30 +7,61 @@
 
 #include "engine_internal.hpp"
 #include "verify_kernels.cuh"
+// A verification session: device scratch for n items, a second stream (point decoding beside the evaluation kernel,
+// lincomb A beside lincomb B) and its fork/join events.  Sessions are POOLED in the context (kzg_ctx::session_pool): a
+// call takes one (growing its buffer if the batch is larger than any before), and kzg_verify_session_destroy hands it
+// back, so steady-state verification allocates nothing and concurrent callers never share a stream or a buffer.
 struct kzg_verify_session {
   const kzg_ctx* ctx = nullptr;
   uint64_t n = 0;
-  hipStream_t st = nullptr;
-  uint8_t* buf = nullptr;  // one device allocation, carved below
+  hipStream_t st = nullptr;    // the caller's stream of the current use
+  hipStream_t side = nullptr;  // owned
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;  // owned
+  uint8_t* buf = nullptr;      // owned: one device allocation of `cap` bytes, carved below
+  size_t cap = 0;
   uint4* aff = nullptr;    // [2n+1] affine points: proofs, commitments, generator
   uint8_t* inf = nullptr;  // [2n+1]
   fr_t* z = nullptr;       // [n] plain
   fr_t* y = nullptr;       // [n] plain
   fr_t* scal = nullptr;    // [2n+1] plain: r_i*z_i (n), r_i (n), -sum r_i*y_i
+  int32_t* stat = nullptr;   // [3n] blob / commitment / proof status
+  uint32_t* leaves = nullptr;  // transcript
+  uint32_t* nodes = nullptr;
+  uint8_t* pts48 = nullptr;  // [2n * 48] device copy of proofs || commitments (host-buffer entry points)
   uint8_t* msm_a = nullptr;  // scratch of the two lincomb MSMs (carved from buf: no allocation in phase 2)
   uint8_t* msm_b = nullptr;
   fr_t* rpow2 = nullptr;     // [64] r^(2^k)
   fr_t* ysum = nullptr;      // per-block partial sums of r_i*y_i
+  std::vector<int32_t> h_stat;   // host read-back
+  std::vector<uint32_t> h_nodes;
 };
 
+static void session_free(kzg_verify_session* s) {
+  if (!s) return;
+  if (s->buf) (void)hipFree(s->buf);
+  if (s->side) (void)hipStreamDestroy(s->side);
+  if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
+  if (s->ev_join) (void)hipEventDestroy(s->ev_join);
+  delete s;
+}
+void session_pool_clear(const kzg_ctx* ctx) {
+  std::lock_guard<std::mutex> guard(ctx->pool_lock);
+  for (kzg_verify_session* s : ctx->session_pool) session_free(s);
+  ctx->session_pool.clear();
+}
+
+// hands the session back to its context's pool (at most 8 are kept)
 extern "C" void kzg_verify_session_destroy(kzg_verify_session* s) {
   if (!s) return;
-  if (s->buf) {
-    (void)hipSetDevice(s->ctx->device);
-    (void)hipStreamSynchronize(s->st);
-    (void)hipFree(s->buf);
-  }
-  delete s;
+  const kzg_ctx* ctx = s->ctx;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(s->st);  // nothing enqueued by this use may still touch the buffers
+  (void)hipStreamSynchronize(s->side);
+  std::lock_guard<std::mutex> guard(ctx->pool_lock);
+  if (ctx->session_pool.size() < 8)
+    ctx->session_pool.push_back(s);
+  else
+    session_free(s);
 }
 
 // Window sizes whose TOP window is full (255 mod c close to c): c = 8 (32 windows,
@@ -213,20 +244,12 @@ static void scan_first_error(const int32_t* st, uint64_t n, int32_t* idx, int32_
     }
 }
 
-extern "C" int32_t kzg_verify_phase1_dev(const kzg_ctx* ctx, const void* d_blobs, const void* d_commitments48, const void* d_proofs48,
-                                         uint64_t n, uint8_t* out_root32, int32_t* err6, kzg_verify_session** session, void* hip_stream) {
-  if (!ctx || !out_root32 || !err6 || !session || (n && (!d_blobs || !d_commitments48 || !d_proofs48)))
-    return fail(KZG_FAIL_ARGUMENT, "null argument");
-  *session = nullptr;
-  TraceTimer tt("phase1");
-  HIP_TRY(hipSetDevice(ctx->device));
-  hipStream_t st = (hipStream_t)hip_stream;
-  kzg_verify_session* s = new (std::nothrow) kzg_verify_session();
-  if (!s) return fail(KZG_FAIL_ARGUMENT, "out of host memory");
-  s->ctx = ctx;
-  s->n = n;
-  s->st = st;
-  for (int k = 0; k < 6; k++) err6[k] = (k % 2 == 0) ? -1 : 0;
+// ---- session set-up -----------------------------------------------------------------------------------------------
+struct SessionLayout {
+  size_t o_aff, o_inf, o_z, o_y, o_scal, o_stat, o_leaves, o_nodes, o_pts, o_msm_a, o_msm_b, o_rpow, o_ysum, total;
+};
+static SessionLayout session_layout(uint64_t n) {
+  SessionLayout L{};
   const uint64_t groups = (n + 255) / 256;
   size_t off = 0;
   auto take = [&](size_t bytes) {
@@ -234,106 +257,316 @@ extern "C" int32_t kzg_verify_phase1_dev(const kzg_ctx* ctx, const void* d_blobs
     off = align_up(off + bytes, 256);
     return o;
   };
-  const size_t o_aff = take((2 * n + 1) * 96), o_inf = take(2 * n + 1), o_z = take(n * 32 + 32), o_y = take(n * 32 + 32),
-               o_scal = take((2 * n + 1) * 32), o_stat = take(3 * n * 4 + 4), o_leaves = take(n * 32 + 32), o_nodes = take(groups * 32 + 32),
-               o_msm_a = take(msm_var_layout(n).total + 256), o_msm_b = take(msm_var_layout(2 * n + 1).total + 256), o_rpow = take(64 * 32),
-               o_ysum = take(((n + 255) / 256 + 1) * 32);
-  if (hipMalloc(&s->buf, off) != hipSuccess) {
-    delete s;
-    return fail(KZG_FAIL_HIP, "hipMalloc(verify session) failed");
+  L.o_aff = take((2 * n + 1) * 96);
+  L.o_inf = take(2 * n + 1);
+  L.o_z = take(n * 32 + 32);
+  L.o_y = take(n * 32 + 32);
+  L.o_scal = take((2 * n + 1) * 32);
+  L.o_stat = take(3 * n * 4 + 4);
+  L.o_leaves = take(n * 32 + 32);
+  L.o_nodes = take(groups * 32 + 32);
+  L.o_pts = take(2 * n * 48 + 48);
+  L.o_msm_a = take(msm_var_layout(n).total + 256);
+  L.o_msm_b = take(msm_var_layout(2 * n + 1).total + 256);
+  L.o_rpow = take(64 * 32);
+  L.o_ysum = take(((n + 255) / 256 + 1) * 32);
+  L.total = off;
+  return L;
+}
+
+// Takes a session from the context's pool (or creates one), sized for n items, and enqueues its initialisation on `st`.
+static int32_t session_acquire(const kzg_ctx* ctx, uint64_t n, hipStream_t st, kzg_verify_session** out) {
+  *out = nullptr;
+  const SessionLayout L = session_layout(n);
+  kzg_verify_session* s = nullptr;
+  {
+    std::lock_guard<std::mutex> guard(ctx->pool_lock);
+    auto& pool = ctx->session_pool;
+    int best = -1;
+    for (int k = 0; k < (int)pool.size(); k++) {  // smallest pooled session that is large enough, else the largest (it is regrown)
+      const bool fits = pool[k]->cap >= L.total;
+      if (best < 0) best = k;
+      else {
+        const bool best_fits = pool[best]->cap >= L.total;
+        if (fits && (!best_fits || pool[k]->cap < pool[best]->cap)) best = k;
+        if (!fits && !best_fits && pool[k]->cap > pool[best]->cap) best = k;
+      }
+    }
+    if (best >= 0) {
+      s = pool[best];
+      pool.erase(pool.begin() + best);
+    }
   }
-  tt.mark("alloc");
-  s->aff = (uint4*)(s->buf + o_aff);
-  s->inf = s->buf + o_inf;
-  s->z = (fr_t*)(s->buf + o_z);
-  s->y = (fr_t*)(s->buf + o_y);
-  s->scal = (fr_t*)(s->buf + o_scal);
-  s->msm_a = s->buf + o_msm_a;
-  s->msm_b = s->buf + o_msm_b;
-  s->rpow2 = (fr_t*)(s->buf + o_rpow);
-  s->ysum = (fr_t*)(s->buf + o_ysum);
-  int32_t* stat = (int32_t*)(s->buf + o_stat);
-  uint32_t* leaves = (uint32_t*)(s->buf + o_leaves);
-  uint32_t* nodes = (uint32_t*)(s->buf + o_nodes);
-  int32_t rc = 0;
-  std::vector<int32_t> h_stat(3 * n);
-  std::vector<uint32_t> h_nodes(groups * 8);
-  do {
-    // generator term
-    if (hipMemcpyAsync(s->aff + (2 * n) * 6, ctx->d_gen_affine, 96, hipMemcpyDeviceToDevice, st) != hipSuccess ||
-        hipMemsetAsync(s->inf, 0, 2 * n + 1, st) != hipSuccess || hipMemsetAsync(stat, 0, 3 * n * 4 + 4, st) != hipSuccess) {
-      rc = fail(KZG_FAIL_HIP, "verify session init failed");
-      break;
+  if (!s) {
+    s = new (std::nothrow) kzg_verify_session();
+    if (!s) return fail(KZG_FAIL_ARGUMENT, "out of host memory");
+    s->ctx = ctx;
+    if (hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) != hipSuccess) {
+      session_free(s);
+      return fail(KZG_FAIL_HIP, "verify session: stream/event creation failed");
     }
-    if (n) {
-      const uint8_t* blobs = (const uint8_t*)d_blobs;
-      const uint8_t* com = (const uint8_t*)d_commitments48;
-      const uint8_t* prf = (const uint8_t*)d_proofs48;
-      // SHA-256 challenge first, alone: its 1,024 long-lived waves (one per SIMD at n = 65,536) must be
-      // spread evenly -- launched next to the decode kernel they were placed around its waves and the
-      // kernel took 3x longer (profiles/r01: 23 ms vs 7.5 ms).  The point decoding then runs on the side
-      // stream concurrently with the evaluation kernel, whose short blocks rebalance dynamically.
-      hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-      if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
-          hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess) {
-        rc = fail(KZG_FAIL_HIP, "event create failed");
-        break;
-      }
-      hipStream_t side = ctx->side_stream;
-      // Small batches (everything together below one wave per SIMD) are latency-bound instead: there hashing and
-      // decoding are ONE launch whose workgroups the dispatcher deals over different CUs (single blob: 12.4 -> 4.9 ms
-      // together with the two-wave SHA-256).
-      const bool small = n <= KZG_FUSED_PREP_MAX;
-      if (small) {
-        launch_challenge_and_decode(st, blobs, com, n, s->z, prf, n, stat + 2 * n, com, n, stat + n, s->aff, s->inf);
-        (void)hipEventRecord(ev_join, st);
-      } else {
-        launch_challenge(ctx, st, blobs, com, n, s->z);
-        (void)hipEventRecord(ev_fork, st);
-        (void)hipStreamWaitEvent(side, ev_fork, 0);
-        hipLaunchKernelGGL(k_g1_decompress, dim3(blocks_for(2 * n, 64)), dim3(64), 0, side, prf, n, stat + 2 * n, com, n, stat + n, s->aff, s->inf);
-        (void)hipEventRecord(ev_join, side);
-      }
-      bool wide_groups = n < 4096;
-      if (const char* e = getenv("KATETH_AMD_EVAL_GROUP")) wide_groups = atoi(e) != 16;  // tests force either shape
-      if (!wide_groups)  // chip full: 16 lanes per blob (four blobs per wave), shorter merge tree
-        hipLaunchKernelGGL(k_eval_frac<16>, dim3(blocks_for(n, 4)), dim3(64), 0, st, blobs, s->z, ctx->d_roots_brp, ctx->d_eval_tab, s->y, stat, n);
-      else  // latency first: the whole wave on one blob
-        hipLaunchKernelGGL(k_eval_frac<64>, dim3((unsigned)n), dim3(64), 0, st, blobs, s->z, ctx->d_roots_brp, ctx->d_eval_tab, s->y, stat, n);
-      // the transcript hashes the input BYTES and (z, y): it does not wait for the decoded points
-      hipLaunchKernelGGL(k_transcript_leaves, dim3(blocks_for(n, 256)), dim3(256), 0, st, com, prf, s->z, s->y, n, leaves);
-      hipLaunchKernelGGL(k_transcript_nodes, dim3(blocks_for(groups, 64)), dim3(64), 0, st, leaves, n, nodes);
-      (void)hipStreamWaitEvent(st, ev_join, 0);
-      (void)hipEventDestroy(ev_fork);
-      (void)hipEventDestroy(ev_join);
-      if (hipGetLastError() != hipSuccess) {
-        rc = fail(KZG_FAIL_HIP, "verify phase 1 launch failed");
-        break;
-      }
-      if (hipMemcpyAsync(h_stat.data(), stat, 3 * n * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
-          hipMemcpyAsync(h_nodes.data(), nodes, groups * 32, hipMemcpyDeviceToHost, st) != hipSuccess) {
-        rc = fail(KZG_FAIL_HIP, "verify phase 1 readback failed");
-        break;
-      }
+  }
+  if (s->cap < L.total) {
+    if (s->buf) (void)hipFree(s->buf);
+    s->buf = nullptr;
+    s->cap = 0;
+    const size_t want = L.total + L.total / 8;
+    if (hipMalloc(&s->buf, want) != hipSuccess) {
+      session_free(s);
+      return fail(KZG_FAIL_HIP, "hipMalloc(verify session) failed");
     }
-    if (hipStreamSynchronize(st) != hipSuccess) {
-      rc = fail(KZG_FAIL_HIP, "verify phase 1 synchronize failed");
-      break;
+    s->cap = want;
+  }
+  if (st == KZG_SESSION_STREAM) st = s->side;
+  s->n = n;
+  s->st = st;
+  s->aff = (uint4*)(s->buf + L.o_aff);
+  s->inf = s->buf + L.o_inf;
+  s->z = (fr_t*)(s->buf + L.o_z);
+  s->y = (fr_t*)(s->buf + L.o_y);
+  s->scal = (fr_t*)(s->buf + L.o_scal);
+  s->stat = (int32_t*)(s->buf + L.o_stat);
+  s->leaves = (uint32_t*)(s->buf + L.o_leaves);
+  s->nodes = (uint32_t*)(s->buf + L.o_nodes);
+  s->pts48 = s->buf + L.o_pts;
+  s->msm_a = s->buf + L.o_msm_a;
+  s->msm_b = s->buf + L.o_msm_b;
+  s->rpow2 = (fr_t*)(s->buf + L.o_rpow);
+  s->ysum = (fr_t*)(s->buf + L.o_ysum);
+  // generator term, cleared flags and statuses
+  if (hipMemcpyAsync(s->aff + (2 * n) * 6, ctx->d_gen_affine, 96, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+      hipMemsetAsync(s->inf, 0, 2 * n + 1, st) != hipSuccess || hipMemsetAsync(s->stat, 0, 3 * n * 4 + 4, st) != hipSuccess) {
+    kzg_verify_session_destroy(s);
+    return fail(KZG_FAIL_HIP, "verify session init failed");
+  }
+  *out = s;
+  return 0;
+}
+
+// Per-item device work of items [base, base + m): Fiat-Shamir challenge z_i and evaluation y_i from blobs resident at
+// `blobs` (m blobs), enqueued on `st`.  `decode_here`: the commitments/proofs of the SAME range are decoded too (fused
+// launch for small m, the session's side stream otherwise); the caller joins ev_join.
+static int32_t phase1_items(kzg_verify_session* s, const uint8_t* blobs, const uint8_t* com, const uint8_t* prf, uint64_t base, uint64_t m,
+                            hipStream_t st, bool decode_here) {
+  const kzg_ctx* ctx = s->ctx;
+  const uint64_t n = s->n;
+  if (m == 0) return 0;
+  fr_t* z = s->z + base;
+  fr_t* y = s->y + base;
+  int32_t* stat_blob = s->stat + base;
+  // SHA-256 challenge first, alone: its long-lived waves (one per SIMD at n = 65,536) must be spread evenly -- launched
+  // next to the decode kernel they were placed around its waves and the kernel took 3x longer (profiles/r01: 23 ms vs
+  // 7.5 ms).  The point decoding then runs on the side stream concurrently with the evaluation kernel, whose short blocks
+  // rebalance dynamically.  Small batches (everything together below one wave per SIMD) are latency-bound instead:
+  // there hashing and decoding are ONE launch whose workgroups the dispatcher deals over different CUs.
+  if (decode_here && m <= KZG_FUSED_PREP_MAX && base == 0 && m == n) {
+    launch_challenge_and_decode(ctx, st, blobs, com, m, z, prf, n, s->stat + 2 * n, com, n, s->stat + n, s->aff, s->inf);
+    (void)hipEventRecord(s->ev_join, st);
+  } else {
+    launch_challenge(ctx, st, blobs, com + base * 48, m, z);
+    if (decode_here) {
+      (void)hipEventRecord(s->ev_fork, st);
+      hipStream_t side = ctx->knobs.verify_serial ? st : s->side;
+      (void)hipStreamWaitEvent(side, s->ev_fork, 0);
+      {
+        ProfScope ps(ctx, PROF_DECODE, side);
+        hipLaunchKernelGGL(k_g1_decompress, dim3(blocks_for(2 * n, 64)), dim3(64), 0, side, prf, n, s->stat + 2 * n, com, n, s->stat + n, s->aff,
+                           s->inf);
+      }
+      (void)hipEventRecord(s->ev_join, side);
     }
-  } while (0);
+  }
+  bool wide_groups = m < 4096;
+  if (ctx->knobs.eval_group) wide_groups = ctx->knobs.eval_group != 16;  // tests force either shape
+  {
+    ProfScope ps(ctx, PROF_EVAL, st);
+    if (!wide_groups)  // chip full: 16 lanes per blob (four blobs per wave), shorter merge tree
+      hipLaunchKernelGGL(k_eval_frac<16>, dim3(blocks_for(m, 4)), dim3(64), 0, st, blobs, z, ctx->d_roots_brp, ctx->d_eval_tab, y, stat_blob, m);
+    else  // latency first: the whole wave on one blob
+      hipLaunchKernelGGL(k_eval_frac<64>, dim3((unsigned)m), dim3(64), 0, st, blobs, z, ctx->d_roots_brp, ctx->d_eval_tab, y, stat_blob, m);
+  }
+  if (hipGetLastError() != hipSuccess) return fail(KZG_FAIL_HIP, "verify phase 1 launch failed");
+  return 0;
+}
+
+// Transcript over all n items (it hashes the input BYTES and (z, y): it does not wait for the decoded points), join of
+// the decode stream, read-back of statuses and node digests, first-error scan, local transcript root.
+static int32_t phase1_finish(kzg_verify_session* s, const uint8_t* com, const uint8_t* prf, uint8_t* out_root32, int32_t* err6, TraceTimer& tt) {
+  const uint64_t n = s->n;
+  hipStream_t st = s->st;
+  const uint64_t groups = (n + 255) / 256;
+  s->h_stat.resize(3 * n);
+  s->h_nodes.resize(groups * 8);
+  hipLaunchKernelGGL(k_transcript_leaves, dim3(blocks_for(n, 256)), dim3(256), 0, st, com, prf, s->z, s->y, n, s->leaves);
+  hipLaunchKernelGGL(k_transcript_nodes, dim3(blocks_for(groups, 64)), dim3(64), 0, st, s->leaves, n, s->nodes);
+  (void)hipStreamWaitEvent(st, s->ev_join, 0);
+  if (hipGetLastError() != hipSuccess) return fail(KZG_FAIL_HIP, "verify phase 1 launch failed");
+  if (hipMemcpyAsync(s->h_stat.data(), s->stat, 3 * n * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipMemcpyAsync(s->h_nodes.data(), s->nodes, groups * 32, hipMemcpyDeviceToHost, st) != hipSuccess)
+    return fail(KZG_FAIL_HIP, "verify phase 1 readback failed");
+  if (hipStreamSynchronize(st) != hipSuccess) return fail(KZG_FAIL_HIP, "verify phase 1 synchronize failed");
+  tt.mark("gpu kernels + readback");
+  scan_first_error(s->h_stat.data(), n, &err6[0], &err6[1]);
+  scan_first_error(s->h_stat.data() + n, n, &err6[2], &err6[3]);
+  scan_first_error(s->h_stat.data() + 2 * n, n, &err6[4], &err6[5]);
+  // local transcript root = SHA-256 over the node digests (big-endian bytes)
+  std::vector<uint8_t> nb(groups * 32);
+  for (uint64_t k = 0; k < groups * 8; k++) store_be32(nb.data() + 4 * k, s->h_nodes[k]);
+  sha256_bytes(out_root32, nb.data(), nb.size());
+  tt.mark("status scan + root hash");
+  return 0;
+}
+
+extern "C" int32_t kzg_verify_phase1_dev(const kzg_ctx* ctx, const void* d_blobs, const void* d_commitments48, const void* d_proofs48,
+                                         uint64_t n, uint8_t* out_root32, int32_t* err6, kzg_verify_session** session, void* hip_stream) {
+  if (!ctx || !out_root32 || !err6 || !session || (n && (!d_blobs || !d_commitments48 || !d_proofs48)))
+    return fail(KZG_FAIL_ARGUMENT, "null argument");
+  *session = nullptr;
+  TraceTimer tt(ctx->knobs.trace, "phase1");
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)hip_stream;
+  for (int k = 0; k < 6; k++) err6[k] = (k % 2 == 0) ? -1 : 0;
+  kzg_verify_session* s = nullptr;
+  int32_t rc = session_acquire(ctx, n, st, &s);
+  if (rc) return rc;
+  tt.mark("session");
+  if (n) {
+    const uint8_t* com = (const uint8_t*)d_commitments48;
+    const uint8_t* prf = (const uint8_t*)d_proofs48;
+    rc = phase1_items(s, (const uint8_t*)d_blobs, com, prf, 0, n, st, true);
+    if (rc == 0) rc = phase1_finish(s, com, prf, out_root32, err6, tt);
+  } else {
+    sha256_bytes(out_root32, nullptr, 0);
+    if (hipStreamSynchronize(st) != hipSuccess) rc = fail(KZG_FAIL_HIP, "verify phase 1 synchronize failed");
+  }
   if (rc) {
     kzg_verify_session_destroy(s);
     return rc;
   }
-  tt.mark("gpu kernels + readback");
-  scan_first_error(h_stat.data(), n, &err6[0], &err6[1]);
-  scan_first_error(h_stat.data() + n, n, &err6[2], &err6[3]);
-  scan_first_error(h_stat.data() + 2 * n, n, &err6[4], &err6[5]);
-  // local transcript root = SHA-256 over the node digests (big-endian bytes)
-  std::vector<uint8_t> nb(groups * 32);
-  for (uint64_t k = 0; k < groups * 8; k++) store_be32(nb.data() + 4 * k, h_nodes[k]);
-  sha256_bytes(out_root32, nb.data(), nb.size());
-  tt.mark("status scan + root hash");
+  *session = s;
+  return 0;
+}
+
+static int32_t stage_init(const kzg_ctx* ctx) {  // caller holds stage_lock
+  if (ctx->stage_ready) return 0;
+  bool ok = hipStreamCreateWithFlags(&ctx->verify_stream, hipStreamNonBlocking) == hipSuccess &&
+            hipStreamCreateWithFlags(&ctx->stage_copy_stream, hipStreamNonBlocking) == hipSuccess;
+  for (int r = 0; r < KZG_STAGE_STREAMS && ok; r++)
+    ok = hipStreamCreateWithFlags(&ctx->stage_streams[r], hipStreamNonBlocking) == hipSuccess &&
+         hipEventCreateWithFlags(&ctx->stage_join[r], hipEventDisableTiming) == hipSuccess;
+  for (int k = 0; k < KZG_STAGE_SLOTS && ok; k++)
+    ok = hipEventCreateWithFlags(&ctx->stage_copied[k], hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&ctx->stage_done[k], hipEventDisableTiming) == hipSuccess;
+  if (!ok) {
+    stage_destroy(ctx);
+    return fail(KZG_FAIL_HIP, "staging pipeline: stream/event creation failed");
+  }
+  ctx->stage_ready = true;
+  return 0;
+}
+void stage_destroy(const kzg_ctx* ctx) {
+  if (ctx->stage) (void)hipFree(ctx->stage);
+  ctx->stage = nullptr;
+  ctx->stage_bytes = 0;
+  if (ctx->verify_stream) (void)hipStreamDestroy(ctx->verify_stream);
+  if (ctx->stage_copy_stream) (void)hipStreamDestroy(ctx->stage_copy_stream);
+  ctx->verify_stream = ctx->stage_copy_stream = nullptr;
+  for (int r = 0; r < KZG_STAGE_STREAMS; r++) {
+    if (ctx->stage_streams[r]) (void)hipStreamDestroy(ctx->stage_streams[r]);
+    if (ctx->stage_join[r]) (void)hipEventDestroy(ctx->stage_join[r]);
+    ctx->stage_streams[r] = nullptr;
+    ctx->stage_join[r] = nullptr;
+  }
+  for (int k = 0; k < KZG_STAGE_SLOTS; k++) {
+    if (ctx->stage_copied[k]) (void)hipEventDestroy(ctx->stage_copied[k]);
+    if (ctx->stage_done[k]) (void)hipEventDestroy(ctx->stage_done[k]);
+    ctx->stage_copied[k] = ctx->stage_done[k] = nullptr;
+  }
+  ctx->stage_ready = false;
+}
+
+// Host-buffer phase 1: the blobs cross PCIe in chunks through the context's staging arena (slots of `chunk` blobs) on the
+// copy stream while the per-blob kernels (challenge + evaluation are per blob) of earlier chunks run on rotating compute
+// streams -- the n * 128 KiB never have to be resident at once and the transfer overlaps the hashing.  Commitments and
+// proofs (96 B per item) are copied whole and decoded once on the session's side stream.
+static int32_t verify_phase1_host(const kzg_ctx* ctx, const uint8_t* blobs, const uint8_t* commitments48, const uint8_t* proofs48, uint64_t n,
+                                  uint8_t* out_root32, int32_t* err6, kzg_verify_session** session) {
+  *session = nullptr;
+  TraceTimer tt(ctx->knobs.trace, "phase1(host buffers)");
+  for (int k = 0; k < 6; k++) err6[k] = (k % 2 == 0) ? -1 : 0;
+  std::lock_guard<std::mutex> guard(ctx->stage_lock);  // the arena and the copy/compute streams below are shared
+  int32_t rc = stage_init(ctx);
+  if (rc) return rc;
+  hipStream_t st = ctx->verify_stream;
+  kzg_verify_session* s = nullptr;
+  rc = session_acquire(ctx, n, st, &s);
+  if (rc) return rc;
+  const uint64_t chunk = ctx->knobs.verify_chunk ? ctx->knobs.verify_chunk : 512;
+  const uint64_t nchunks = (n + chunk - 1) / chunk;
+  const uint64_t slots = nchunks < KZG_STAGE_SLOTS ? nchunks : KZG_STAGE_SLOTS;
+  const size_t slot_bytes = (size_t)chunk * KZG_BYTES_PER_BLOB;
+  do {
+    if (ctx->stage_bytes < slots * slot_bytes) {
+      if (ctx->stage) (void)hipFree(ctx->stage);
+      ctx->stage = nullptr;
+      ctx->stage_bytes = 0;
+      if (hipMalloc(&ctx->stage, slots * slot_bytes) != hipSuccess) {
+        rc = fail(KZG_FAIL_HIP, "hipMalloc(staging arena) failed");
+        break;
+      }
+      ctx->stage_bytes = slots * slot_bytes;
+    }
+    uint8_t* prf = s->pts48;
+    uint8_t* com = s->pts48 + n * 48;
+    if (hipMemcpyAsync(prf, proofs48, n * 48, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(com, commitments48, n * 48, hipMemcpyHostToDevice, st) != hipSuccess) {
+      rc = fail(KZG_FAIL_HIP, "host-to-device copy failed");
+      break;
+    }
+    // all points decoded once, beside the chunk pipeline
+    (void)hipEventRecord(s->ev_fork, st);
+    (void)hipStreamWaitEvent(s->side, s->ev_fork, 0);
+    {
+      ProfScope ps(ctx, PROF_DECODE, s->side);
+      hipLaunchKernelGGL(k_g1_decompress, dim3(blocks_for(2 * n, 64)), dim3(64), 0, s->side, prf, n, s->stat + 2 * n, com, n, s->stat + n, s->aff,
+                         s->inf);
+    }
+    (void)hipEventRecord(s->ev_join, s->side);
+    for (int r = 0; r < KZG_STAGE_STREAMS; r++) (void)hipStreamWaitEvent(ctx->stage_streams[r], s->ev_fork, 0);  // session initialised, points resident
+    for (uint64_t k = 0; k < nchunks && rc == 0; k++) {
+      const uint64_t slot = k % slots;
+      const uint64_t base = k * chunk;
+      const uint64_t m = (n - base < chunk) ? (n - base) : chunk;
+      hipStream_t comp = ctx->stage_streams[k % KZG_STAGE_STREAMS];
+      uint8_t* d_chunk = ctx->stage + slot * slot_bytes;
+      if (k >= slots) (void)hipStreamWaitEvent(ctx->stage_copy_stream, ctx->stage_done[slot], 0);  // the chunk that used this slot has been consumed
+      if (hipMemcpyAsync(d_chunk, blobs + base * (size_t)KZG_BYTES_PER_BLOB, m * (size_t)KZG_BYTES_PER_BLOB, hipMemcpyHostToDevice,
+                         ctx->stage_copy_stream) != hipSuccess) {
+        rc = fail(KZG_FAIL_HIP, "host-to-device copy failed");
+        break;
+      }
+      (void)hipEventRecord(ctx->stage_copied[slot], ctx->stage_copy_stream);
+      (void)hipStreamWaitEvent(comp, ctx->stage_copied[slot], 0);
+      rc = phase1_items(s, d_chunk, com, prf, base, m, comp, false);
+      (void)hipEventRecord(ctx->stage_done[slot], comp);
+    }
+    // join the compute streams into the session's stream
+    for (int r = 0; r < KZG_STAGE_STREAMS; r++) {
+      (void)hipEventRecord(ctx->stage_join[r], ctx->stage_streams[r]);
+      (void)hipStreamWaitEvent(st, ctx->stage_join[r], 0);
+    }
+    if (rc) break;
+    tt.mark("enqueue copies + per-chunk kernels");
+    rc = phase1_finish(s, com, prf, out_root32, err6, tt);
+  } while (0);
+  if (rc) {
+    (void)hipStreamSynchronize(ctx->stage_copy_stream);
+    for (int r = 0; r < KZG_STAGE_STREAMS; r++) (void)hipStreamSynchronize(ctx->stage_streams[r]);
+    kzg_verify_session_destroy(s);
+    return rc;
+  }
   *session = s;
   return 0;
 }
@@ -342,7 +575,7 @@ extern "C" int32_t kzg_verify_phase2_dev(kzg_verify_session* s, const uint8_t* r
                                          uint8_t* out192) {
   if (!s || !roots32 || !out192 || world == 0) return fail(KZG_FAIL_ARGUMENT, "null argument");
   const kzg_ctx* ctx = s->ctx;
-  TraceTimer tt("phase2");
+  TraceTimer tt(ctx->knobs.trace, "phase2");
   HIP_TRY(hipSetDevice(ctx->device));
   hipStream_t st = s->st;
   const uint64_t n = s->n;
@@ -378,15 +611,18 @@ extern "C" int32_t kzg_verify_phase2_dev(kzg_verify_session* s, const uint8_t* r
       if (hipGetLastError() != hipSuccess) { rc = fail(KZG_FAIL_HIP, "verify phase 2 launch failed"); break; }
       // A = sum r_i * proof_i ; B = sum (r_i z_i) proof_i + sum r_i commitment_i - (sum r_i y_i) G
       tt.mark("seed + scalars enqueue");
-      // the two lincombs are independent: A on the side stream, B on the caller's stream
-      hipEvent_t ev = nullptr;
-      if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { rc = fail(KZG_FAIL_HIP, "event create failed"); break; }
-      (void)hipEventRecord(ev, st);
-      (void)hipStreamWaitEvent(ctx->side_stream, ev, 0);
-      (void)hipEventDestroy(ev);
+      // the two lincombs are independent: A on the session's side stream, B on the caller's stream
+      (void)hipEventRecord(s->ev_fork, st);
+      (void)hipStreamWaitEvent(s->side, s->ev_fork, 0);
       MsmVarJob ja, jb;
-      rc = msm_var_launch(ja, s->aff, s->inf, s->scal + n, n, ctx->side_stream, s->msm_a);
-      if (rc == 0) rc = msm_var_launch(jb, s->aff, s->inf, s->scal, 2 * n + 1, st, s->msm_b);
+      {
+        ProfScope psa(ctx, PROF_VAR_MSM, s->side);
+        rc = msm_var_launch(ja, s->aff, s->inf, s->scal + n, n, s->side, s->msm_a);
+      }
+      if (rc == 0) {
+        ProfScope psb(ctx, PROF_VAR_MSM, st);
+        rc = msm_var_launch(jb, s->aff, s->inf, s->scal, 2 * n + 1, st, s->msm_b);
+      }
       int32_t rca = msm_var_finish(ja, Ax);
       int32_t rcb = msm_var_finish(jb, Bx);
       if (rc == 0) rc = rca ? rca : rcb;
@@ -400,6 +636,23 @@ extern "C" int32_t kzg_verify_phase2_dev(kzg_verify_session* s, const uint8_t* r
   }
   host_affine_to_be96(out192, A);
   host_affine_to_be96(out192 + 96, B);
+  return 0;
+}
+
+// introspection: challenge z_i and evaluation y_i of items [first, first + count) of a session after phase 1
+extern "C" int32_t kzg_verify_session_zy(kzg_verify_session* s, uint64_t first, uint64_t count, uint8_t* out_z32, uint8_t* out_y32) {
+  if (!s || !out_z32 || !out_y32 || first + count > s->n) return fail(KZG_FAIL_ARGUMENT, "bad argument");
+  if (count == 0) return 0;
+  HIP_TRY(hipSetDevice(s->ctx->device));
+  std::vector<fr_t> hz(count), hy(count);
+  HIP_TRY(hipStreamSynchronize(s->st));
+  HIP_TRY(hipMemcpy(hz.data(), s->z + first, count * sizeof(fr_t), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(hy.data(), s->y + first, count * sizeof(fr_t), hipMemcpyDeviceToHost));
+  for (uint64_t i = 0; i < count; i++)
+    for (int q = 0; q < 8; q++) {
+      store_be32(out_z32 + 32 * i + 4 * q, hz[i].v[7 - q]);
+      store_be32(out_y32 + 32 * i + 4 * q, hy[i].v[7 - q]);
+    }
   return 0;
 }
 
@@ -417,7 +670,7 @@ extern "C" int32_t kzg_verify_batch_finish(const kzg_ctx* ctx, const uint8_t* pa
     if (!b.inf) xyzz_madd(B, b.x, b.y);
   }
   host::g1_host_affine a, b;
-  TraceTimer tt("finish");
+  TraceTimer tt(ctx->knobs.trace, "finish");
   host_affine_from_xyzz(a, A);
   host_affine_from_xyzz(b, B);
   *ok = host::verify_pairings_fixed(*ctx->pairing, a, b) ? 1 : 0;
@@ -461,23 +714,27 @@ extern "C" int32_t kzg_verify_blob_proof_batch_dev(const kzg_ctx* ctx, const voi
 extern "C" int32_t kzg_verify_blob_proof_batch(const kzg_ctx* ctx, const uint8_t* blobs, const uint8_t* commitments48, const uint8_t* proofs48,
                                                uint64_t n, int32_t* ok) {
   if (!ctx || !ok || (n && (!blobs || !commitments48 || !proofs48))) return fail(KZG_FAIL_ARGUMENT, "null argument");
+  *ok = 0;
   if (n == 0) {
     *ok = 1;
     return 0;
   }
   HIP_TRY(hipSetDevice(ctx->device));
-  uint8_t *d_blobs = nullptr, *d_c = nullptr, *d_p = nullptr;
-  HIP_TRY(hipMalloc(&d_blobs, n * (size_t)KZG_BYTES_PER_BLOB));
-  HIP_TRY(hipMalloc(&d_c, n * 48));
-  HIP_TRY(hipMalloc(&d_p, n * 48));
-  HIP_TRY(hipMemcpy(d_blobs, blobs, n * (size_t)KZG_BYTES_PER_BLOB, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(d_c, commitments48, n * 48, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(d_p, proofs48, n * 48, hipMemcpyHostToDevice));
-  int32_t rc = kzg_verify_blob_proof_batch_dev(ctx, d_blobs, d_c, d_p, n, ok, nullptr);
-  (void)hipFree(d_blobs);
-  (void)hipFree(d_c);
-  (void)hipFree(d_p);
-  return rc;
+  uint8_t root[32];
+  int32_t err6[6];
+  kzg_verify_session* s = nullptr;
+  int32_t rc = verify_phase1_host(ctx, blobs, commitments48, proofs48, n, root, err6, &s);
+  if (rc) return rc;
+  const int32_t code = first_error_code(err6);
+  if (code) {
+    kzg_verify_session_destroy(s);
+    return code;
+  }
+  uint8_t partial[192];
+  rc = kzg_verify_phase2_dev(s, root, 1, 0, n, partial);
+  kzg_verify_session_destroy(s);
+  if (rc) return rc;
+  return kzg_verify_batch_finish(ctx, partial, 1, ok);
 }
 
 // Setup::verify_blob_proof (src/kzg/setup.rs:208-221): a batch of one (the random
@@ -487,52 +744,50 @@ extern "C" int32_t kzg_verify_blob_proof(const kzg_ctx* ctx, const uint8_t* blob
 }
 
 // Setup::verify_proof (src/kzg/setup.rs:96-113).  e(pi, [tau]_2 - z G2) == e(C - y G, G2)
-// is checked in the equivalent fixed-G2 form  e(pi, [tau]_2) == e(C - y G + z pi, G2).
+// is checked in the equivalent fixed-G2 form  e(pi, [tau]_2) == e(C - y G + z pi, G2): a one-item session whose z and y
+// come from the caller instead of the challenge/evaluation kernels (the batch coefficient of item 0 is r^0 = 1).
 // Error order of the reference: proof, commitment, z, y.
 extern "C" int32_t kzg_verify_proof(const kzg_ctx* ctx, const uint8_t* proof48, const uint8_t* commitment48, const uint8_t* z32, const uint8_t* y32,
                                     int32_t* ok) {
   if (!ctx || !proof48 || !commitment48 || !z32 || !y32 || !ok) return fail(KZG_FAIL_ARGUMENT, "null argument");
   *ok = 0;
   HIP_TRY(hipSetDevice(ctx->device));
+  kzg_verify_session* s = nullptr;
   hipStream_t st = nullptr;
-  uint8_t* buf = nullptr;
-  HIP_TRY(hipMalloc(&buf, 4096));
-  uint8_t* d_in = buf;                    // proof48 || commitment48
-  int32_t* d_stat = (int32_t*)(buf + 256);
-  uint4* d_aff = (uint4*)(buf + 512);     // proof, commitment, generator
-  uint8_t* d_inf = buf + 1024;
-  fr_t* d_scal = (fr_t*)(buf + 1280);     // z, 1, -y
+  {
+    // a private stream per call would cost a creation; the session's own stream carries the whole single-item call
+    int32_t rc0 = session_acquire(ctx, 1, KZG_SESSION_STREAM, &s);
+    if (rc0) return rc0;
+    st = s->st;
+  }
   int32_t rc = 0;
   int32_t h_stat[2] = {0, 0};
-  g1_xyzz Bx, Ax;
   do {
+    fr_t zy[2];
+    fr_from_be_bytes_plain(zy[0], z32);
+    fr_from_be_bytes_plain(zy[1], y32);
     uint8_t in[96];
     memcpy(in, proof48, 48);
     memcpy(in + 48, commitment48, 48);
-    if (hipMemcpy(d_in, in, 96, hipMemcpyHostToDevice) != hipSuccess || hipMemset(d_inf, 0, 3) != hipSuccess) { rc = fail(KZG_FAIL_HIP, "copy"); break; }
-    hipLaunchKernelGGL(k_g1_decompress, dim3(1), dim3(64), 0, st, d_in, (uint64_t)2, d_stat, (const uint8_t*)nullptr, (uint64_t)0, (int32_t*)nullptr, d_aff, d_inf);
-    if (hipMemcpy(h_stat, d_stat, 8, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(KZG_FAIL_HIP, "copy"); break; }
+    if (hipMemcpyAsync(s->pts48, in, 96, hipMemcpyHostToDevice, st) != hipSuccess) { rc = fail(KZG_FAIL_HIP, "copy"); break; }
+    hipLaunchKernelGGL(k_g1_decompress, dim3(1), dim3(64), 0, st, s->pts48, (uint64_t)1, s->stat + 2, s->pts48 + 48, (uint64_t)1, s->stat + 1, s->aff,
+                       s->inf);
+    if (hipMemcpyAsync(h_stat, s->stat + 1, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+      rc = fail(KZG_FAIL_HIP, "copy");
+      break;
+    }
+    if (h_stat[1]) { rc = h_stat[1]; break; }  // proof first (src/kzg/setup.rs:103)
     if (h_stat[0]) { rc = h_stat[0]; break; }
-    if (h_stat[1]) { rc = h_stat[1]; break; }
-    fr_t z, y, one, negy;
-    fr_from_be_bytes_plain(z, z32);
-    fr_from_be_bytes_plain(y, y32);
-    if (!fr_is_canonical(z) || !fr_is_canonical(y)) { rc = KZG_ERR_FF_NOT_IN_FIELD; break; }
-    bn_zero(one);
-    one.v[0] = 1;
-    if (bn_is_zero(y)) negy = y; else bn_sub(negy, modulus<FrParams>(), y);
-    fr_t sc[3] = {z, one, negy};
-    if (hipMemcpy(d_scal, sc, sizeof(sc), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(d_aff + 12, ctx->d_gen_affine, 96, hipMemcpyDeviceToDevice) != hipSuccess) { rc = fail(KZG_FAIL_HIP, "copy"); break; }
-    rc = msm_var(ctx, d_aff, d_inf, d_scal, 3, st, Bx);   // z*pi + C - y*G
-    if (rc) break;
-    rc = msm_var(ctx, d_aff, d_inf, d_scal + 1, 1, st, Ax);  // 1*pi
+    if (!fr_is_canonical(zy[0]) || !fr_is_canonical(zy[1])) { rc = KZG_ERR_FF_NOT_IN_FIELD; break; }
+    if (hipMemcpyAsync(s->z, &zy[0], 32, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(s->y, &zy[1], 32, hipMemcpyHostToDevice, st) != hipSuccess) { rc = fail(KZG_FAIL_HIP, "copy"); break; }
   } while (0);
-  (void)hipFree(buf);
+  uint8_t partial[192];
+  if (rc == 0) {
+    const uint8_t root[32] = {0};
+    rc = kzg_verify_phase2_dev(s, root, 1, 0, 1, partial);
+  }
+  kzg_verify_session_destroy(s);
   if (rc) return rc;
-  host::g1_host_affine a, b;
-  host_affine_from_xyzz(a, Ax);
-  host_affine_from_xyzz(b, Bx);
-  *ok = host::verify_pairings_fixed(*ctx->pairing, a, b) ? 1 : 0;
-  return 0;
+  return kzg_verify_batch_finish(ctx, partial, 1, ok);
 }

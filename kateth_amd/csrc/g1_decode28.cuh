@@ -79,10 +79,14 @@ KZG_HD void f28_inv(fp28& r, const fp28& a) {
 
 // blst_p1_compress (src/bls.rs:499) of an XYZZ point given in the 12 x 32-bit-limb format (canonical 2^384-Montgomery):
 // same bytes as g1_compress_xyzz (g1.cuh); the inversion and the five products around it run in the radix-2^28 field.
-KZG_HD_NOINLINE void g1_compress_xyzz28(uint8_t* out48, const g1_xyzz& p) {
+// `out_affine24` (optional): the same point as blst_p1_affine -- x || y, each 12 x 32-bit little-endian limbs of the
+// canonical 2^384-Montgomery residue (the byte image of blst's 6 x 64-bit limbs); infinity = all zero.
+KZG_HD_NOINLINE void g1_compress_xyzz28(uint8_t* out48, uint32_t* out_affine24, const g1_xyzz& p) {
   if (xyzz_is_inf(p)) {
     out48[0] = 0xC0;
     for (int i = 1; i < 48; i++) out48[i] = 0;
+    if (out_affine24)
+      for (int i = 0; i < 24; i++) out_affine24[i] = 0;
     return;
   }
   fp28 k, X, Y, ZZ, ZZZ, t, ti, a;
@@ -103,6 +107,16 @@ KZG_HD_NOINLINE void g1_compress_xyzz28(uint8_t* out48, const g1_xyzz& p) {
   f28_mul(X, X, a);
   f28_mul(a, ti, ZZ);   // 1 / ZZZ
   f28_mul(Y, Y, a);
+  if (out_affine24) {
+    fp_t xm, ym;
+    f28_to_fp(xm, X);
+    f28_to_fp(ym, Y);
+    KZG_UNROLL_FULL
+    for (int i = 0; i < 12; i++) {
+      out_affine24[i] = xm.v[i];
+      out_affine24[12 + i] = ym.v[i];
+    }
+  }
   fp28 one_plain;
   KZG_UNROLL_FULL
   for (int i = 0; i < F28_N; i++) one_plain.l[i] = i == 0 ? 1u : 0u;

@@ -100,6 +100,9 @@ __device__ __forceinline__ void wave_reduce_xyzz(g1_xyzz& acc, g1_xyzz* lds, int
   }
 }
 
+#if defined(KZG_TEST_RADIX32)
+// TEST-ONLY build (tests/radix32, -DKZG_TEST_RADIX32): the round-1 kernel on 12 x 32-bit limbs, kept as an independent
+// cross-check of the radix-2^28 kernel; it is not compiled into the product library.
 // One wave per (blob, split).  BE_BYTES: scalars are raw blob bytes (32-B
 // big-endian, validated here: Blob::from_slice, src/blob.rs:26-37); otherwise
 // canonical little-endian limbs produced on device (quotient polynomial).
@@ -183,7 +186,9 @@ static __global__ __launch_bounds__(64, OCC) void k_msm_fixed(const uint8_t* __r
 }
 
 
-// The same walk with the accumulator in the carry-free radix-2^28 representation (fp28.cuh): 392 v_mad_u64_u32
+#endif  // KZG_TEST_RADIX32
+
+// The fixed-base walk with the accumulator in the carry-free radix-2^28 representation (fp28.cuh): 392 v_mad_u64_u32
 // and no carry instruction per Montgomery product, 9 reductions per mixed add.  The table must hold 2^392-Montgomery
 // coordinates (kzg_ctx::msm_radix28).  The generic add runs inline; the first add of a lane (identity accumulator)
 // and the ~2^-17 of adds whose cheap "P == +-Q?" test fires go through the out-of-line complete adder on a COPY of
@@ -323,21 +328,31 @@ static __global__ __launch_bounds__(64) void k_msm_reduce_splits(const g1_xyzz* 
 }
 
 // One thread per item: XYZZ -> affine -> 48-byte compressed encoding
-// (K3: blst_p1_compress, src/bls.rs:499).  Items whose status is non-zero get 48 zero bytes.
+// (K3: blst_p1_compress, src/bls.rs:499) and/or the 96-byte blst_p1_affine image (so that a caller that wants the
+// reference's `P1` back -- Commitment = Proof = P1, src/kzg/mod.rs:9-10 -- needs no square root).  Items whose status
+// is non-zero get zero bytes.  Either output pointer may be null.
 static __global__ __launch_bounds__(64) void k_g1_compress(const g1_xyzz* __restrict__ sums, uint64_t n, const int32_t* __restrict__ status,
-                                                    uint8_t* __restrict__ out48) {
+                                                    uint8_t* __restrict__ out48, uint8_t* __restrict__ out_affine96) {
   const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= n) return;
-  uint32_t* o = reinterpret_cast<uint32_t*>(out48 + b * 48);
   uint8_t tmp[48];
+  uint32_t aff[24];
   if (status != nullptr && status[b] != 0) {
     for (int q = 0; q < 48; q++) tmp[q] = 0;
+    for (int q = 0; q < 24; q++) aff[q] = 0;
   } else {
     g1_xyzz acc = sums[b];
-    g1_compress_xyzz28(tmp, acc);  // inversion in the radix-2^28 field (g1_decode28.cuh)
+    g1_compress_xyzz28(tmp, out_affine96 ? aff : nullptr, acc);  // inversion in the radix-2^28 field (g1_decode28.cuh)
   }
-  for (int q = 0; q < 12; q++)
-    o[q] = (uint32_t)tmp[4 * q] | ((uint32_t)tmp[4 * q + 1] << 8) | ((uint32_t)tmp[4 * q + 2] << 16) | ((uint32_t)tmp[4 * q + 3] << 24);
+  if (out48) {
+    uint32_t* o = reinterpret_cast<uint32_t*>(out48 + b * 48);
+    for (int q = 0; q < 12; q++)
+      o[q] = (uint32_t)tmp[4 * q] | ((uint32_t)tmp[4 * q + 1] << 8) | ((uint32_t)tmp[4 * q + 2] << 16) | ((uint32_t)tmp[4 * q + 3] << 24);
+  }
+  if (out_affine96) {
+    uint32_t* o = reinterpret_cast<uint32_t*>(out_affine96 + b * 96);
+    for (int q = 0; q < 24; q++) o[q] = aff[q];
+  }
 }
 
 #endif  // __HIPCC__

@@ -103,6 +103,7 @@ def library_path() -> str:
 
 
 _LIB = None
+_ALT_LIBS = {}
 
 _u8p = ctypes.c_void_p
 _i32p = ctypes.POINTER(ctypes.c_int32)
@@ -115,6 +116,9 @@ _SIGNATURES = {
     "kzg_ctx_table_bytes": (ctypes.c_uint64, [ctypes.c_void_p]),
     "kzg_blob_to_commitment_batch": (ctypes.c_int32, [ctypes.c_void_p, _u8p, ctypes.c_uint64, _u8p, _i32p]),
     "kzg_blob_to_commitment_batch_dev": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "kzg_blob_to_commitment_batch_affine": (ctypes.c_int32, [ctypes.c_void_p, _u8p, ctypes.c_uint64, _u8p, _i32p]),
+    "kzg_compute_blob_proof_batch_affine": (ctypes.c_int32, [ctypes.c_void_p, _u8p, _u8p, ctypes.c_uint64, _u8p, _i32p]),
+    "kzg_compute_proof_batch_affine": (ctypes.c_int32, [ctypes.c_void_p, _u8p, _u8p, ctypes.c_uint64, _u8p, _u8p, _i32p]),
     "kzg_compute_blob_proof_batch": (ctypes.c_int32, [ctypes.c_void_p, _u8p, _u8p, ctypes.c_uint64, _u8p, _i32p]),
     "kzg_compute_blob_proof_batch_dev": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "kzg_compute_proof_batch": (ctypes.c_int32, [ctypes.c_void_p, _u8p, _u8p, ctypes.c_uint64, _u8p, _u8p, _i32p]),
@@ -128,10 +132,13 @@ _SIGNATURES = {
     ),
     "kzg_verify_phase2_dev": (ctypes.c_int32, [ctypes.c_void_p, _u8p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, _u8p]),
     "kzg_verify_session_destroy": (None, [ctypes.c_void_p]),
+    "kzg_verify_session_zy": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, _u8p, _u8p]),
     "kzg_verify_batch_finish": (ctypes.c_int32, [ctypes.c_void_p, _u8p, ctypes.c_uint64, _i32p]),
     "kzg_synth_blobs_dev": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p]),
     "kzg_profile_begin": (ctypes.c_int32, [ctypes.c_void_p]),
     "kzg_profile_end": (ctypes.c_int32, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]),
+    "kzg_profile_end_kinds": (ctypes.c_int32, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]),
+    "kzg_profile_kind_name": (ctypes.c_char_p, [ctypes.c_int32]),
     "kzg_ctx_adds_per_blob": (ctypes.c_uint64, [ctypes.c_void_p]),
     "kzg_selftest_field_mul": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]),
     "kzg_microbench_fp_mul": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(ctypes.c_float)]),
@@ -166,13 +173,17 @@ def _ensure_hip_runtime():
     raise ImportError("kateth_amd: no HIP runtime (libamdhip64.so) could be loaded")
 
 
-def load_library():
+def load_library(path: Optional[str] = None):
     """dlopen the HIP engine.  Raises if it has not been built -- by design there
-    is nothing to fall back to."""
+    is nothing to fall back to.  `path`: another build of the same C ABI (the tests'
+    cross-check build under tests/radix32); the default is the product library."""
     global _LIB
-    if _LIB is not None:
+    if path is None and _LIB is not None:
         return _LIB
-    path = library_path()
+    if path is not None and path in _ALT_LIBS:
+        return _ALT_LIBS[path]
+    alt = path is not None
+    path = path or library_path()
     if not os.path.exists(path):
         raise ImportError(
             "kateth_amd: HIP engine %s not found -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -184,7 +195,10 @@ def load_library():
         fn = getattr(lib, name)  # AttributeError if the .so does not export what include/kateth_amd.h declares
         fn.restype = restype
         fn.argtypes = argtypes
-    _LIB = lib
+    if alt:
+        _ALT_LIBS[path] = lib
+    else:
+        _LIB = lib
     return lib
 
 
@@ -211,7 +225,7 @@ class Setup:
 
     # -- construction --------------------------------------------------------
     @classmethod
-    def load_json(cls, path, device: int = 0, window_bits: int = 0) -> "Setup":
+    def load_json(cls, path, device: int = 0, window_bits: int = 0, lib_path: Optional[str] = None) -> "Setup":
         """`Setup::load_json` (src/kzg/setup.rs:46-82)."""
         try:
             with open(path) as fh:
@@ -225,17 +239,18 @@ class Setup:
             g2 = [_unhex(s) for s in raw["g2_monomial"]]
         except (KeyError, ValueError, AttributeError) as err:
             raise LoadSetupError("Serde(%s)" % err)
-        return cls.from_bytes(g1, g2, device=device, window_bits=window_bits)
+        return cls.from_bytes(g1, g2, device=device, window_bits=window_bits, lib_path=lib_path)
 
     @classmethod
-    def from_bytes(cls, g1_lagrange: Sequence[bytes], g2_monomial: Sequence[bytes], device: int = 0, window_bits: int = 0) -> "Setup":
+    def from_bytes(cls, g1_lagrange: Sequence[bytes], g2_monomial: Sequence[bytes], device: int = 0, window_bits: int = 0,
+                   lib_path: Optional[str] = None) -> "Setup":
         if len(g1_lagrange) != cls.G1:
             raise LoadSetupError("InvalidLenG1Lagrange")  # src/kzg/setup.rs:52-54
         if len(g2_monomial) != cls.G2:
             raise LoadSetupError("InvalidLenG2Monomial")  # src/kzg/setup.rs:55-57
         if any(len(p) != 48 for p in g1_lagrange) or any(len(p) != 96 for p in g2_monomial):
             raise LoadSetupError("Bls(ECGroup(InvalidEncoding))")
-        lib = load_library()
+        lib = load_library(lib_path)
         window_bits = window_bits or int(os.environ.get("KATETH_AMD_WINDOW_BITS", "0"))
         cfg = _Config(device, window_bits, 0, 0)
         out = ctypes.c_void_p()
@@ -307,6 +322,39 @@ class Setup:
         status = (ctypes.c_int32 * n)()
         rc = self._lib.kzg_compute_proof_batch(self._h, blobs, zs, n, ctypes.cast(proofs, ctypes.c_void_p), ctypes.cast(ys, ctypes.c_void_p), status)
         self._check(rc, "kzg_compute_proof_batch")
+        return proofs.raw, ys.raw, list(status)
+
+    # -- the same producers returning POINTS (`Commitment = Proof = P1`, src/kzg/mod.rs:9-10) as 96-byte blst_p1_affine images
+    def blob_to_commitment_batch_affine(self, blobs: bytes, n: Optional[int] = None):
+        blobs = _buf(blobs)
+        n = len(blobs) // BYTES_PER_BLOB if n is None else n
+        if len(blobs) != n * BYTES_PER_BLOB:
+            raise BlobError("InvalidLen")
+        out = ctypes.create_string_buffer(96 * n)
+        status = (ctypes.c_int32 * n)()
+        self._check(self._lib.kzg_blob_to_commitment_batch_affine(self._h, blobs, n, ctypes.cast(out, ctypes.c_void_p), status), "kzg_blob_to_commitment_batch_affine")
+        return out.raw, list(status)
+
+    def compute_blob_proof_batch_affine(self, blobs: bytes, commitments: bytes):
+        blobs, commitments = _buf(blobs), _buf(commitments)
+        n = len(commitments) // 48
+        if len(blobs) != n * BYTES_PER_BLOB or len(commitments) != 48 * n:
+            raise BlobError("InvalidLen")
+        out = ctypes.create_string_buffer(96 * n)
+        status = (ctypes.c_int32 * n)()
+        self._check(self._lib.kzg_compute_blob_proof_batch_affine(self._h, blobs, commitments, n, ctypes.cast(out, ctypes.c_void_p), status), "kzg_compute_blob_proof_batch_affine")
+        return out.raw, list(status)
+
+    def compute_proof_batch_affine(self, blobs: bytes, zs: bytes):
+        blobs, zs = _buf(blobs), _buf(zs)
+        n = len(zs) // 32
+        if len(blobs) != n * BYTES_PER_BLOB:
+            raise BlobError("InvalidLen")
+        proofs = ctypes.create_string_buffer(96 * n)
+        ys = ctypes.create_string_buffer(32 * n)
+        status = (ctypes.c_int32 * n)()
+        rc = self._lib.kzg_compute_proof_batch_affine(self._h, blobs, zs, n, ctypes.cast(proofs, ctypes.c_void_p), ctypes.cast(ys, ctypes.c_void_p), status)
+        self._check(rc, "kzg_compute_proof_batch_affine")
         return proofs.raw, ys.raw, list(status)
 
     # -- reference-shaped API ----------------------------------------------------
@@ -424,6 +472,14 @@ class Setup:
         self._check(rc, "kzg_verify_phase2_dev")
         return out.raw
 
+    def verify_session_zy(self, session, first: int, count: int):
+        """(z bytes, y bytes) of items [first, first+count) of a phase-1 session, 32 B big-endian each"""
+        z = ctypes.create_string_buffer(32 * count)
+        y = ctypes.create_string_buffer(32 * count)
+        rc = self._lib.kzg_verify_session_zy(session, first, count, ctypes.cast(z, ctypes.c_void_p), ctypes.cast(y, ctypes.c_void_p))
+        self._check(rc, "kzg_verify_session_zy")
+        return z.raw, y.raw
+
     def verify_session_destroy(self, session):
         self._lib.kzg_verify_session_destroy(session)
 
@@ -440,11 +496,15 @@ class Setup:
     def profile_begin(self):
         self._check(self._lib.kzg_profile_begin(self._h), "kzg_profile_begin")
 
+    PROF_KINDS = 7  # KZG_PROF_KINDS
+
     def profile_end(self) -> dict:
-        ms = ctypes.c_double(0)
-        cnt = ctypes.c_uint64(0)
-        self._check(self._lib.kzg_profile_end(self._h, ctypes.byref(ms), ctypes.byref(cnt)), "kzg_profile_end")
-        return {"msm_ms": ms.value, "msm_launches": cnt.value, "adds_per_blob": self._lib.kzg_ctx_adds_per_blob(self._h)}
+        """HIP-event kernel times since profile_begin: {"msm_ms", "msm_launches", "adds_per_blob", "kinds": {name: (ms, launches)}}."""
+        ms = (ctypes.c_double * self.PROF_KINDS)()
+        cnt = (ctypes.c_uint64 * self.PROF_KINDS)()
+        self._check(self._lib.kzg_profile_end_kinds(self._h, ms, cnt), "kzg_profile_end_kinds")
+        kinds = {self._lib.kzg_profile_kind_name(k).decode(): (ms[k], cnt[k]) for k in range(self.PROF_KINDS)}
+        return {"msm_ms": ms[0], "msm_launches": cnt[0], "adds_per_blob": self._lib.kzg_ctx_adds_per_blob(self._h), "kinds": kinds}
 
     def selftest_field_mul(self, lanes: int, iters: int) -> int:
         bad = ctypes.c_uint64(0)

@@ -396,8 +396,25 @@ extern "C" int32_t hm_g1_sum_compress28(uint8_t* out48, const uint8_t* pts48, in
   }
   uint8_t ref[48];
   g1_compress_xyzz(ref, acc);
-  g1_compress_xyzz28(out48, acc);
+  g1_compress_xyzz28(out48, nullptr, acc);
   return memcmp(ref, out48, 48) == 0 ? 1 : 0;
+}
+
+// the blst_p1_affine image (x || y, 2^384-Montgomery, little-endian limbs; infinity = zeros) of sum of points, as the
+// affine-output entry points of the C ABI produce it
+extern "C" int32_t hm_g1_sum_affine96(uint8_t* out96, uint8_t* out48, const uint8_t* pts48, int n) {
+  g1_xyzz acc;
+  xyzz_set_inf(acc);
+  for (int i = 0; i < n; i++) {
+    fp_t x, y;
+    bool inf;
+    if (g1_uncompress(x, y, inf, pts48 + 48 * i) != 0) return -1;
+    if (!inf) xyzz_madd(acc, x, y);
+  }
+  uint32_t aff[24];
+  g1_compress_xyzz28(out48, aff, acc);
+  memcpy(out96, aff, 96);
+  return 0;
 }
 
 // ---- safegcd inversion (kateth_amd/csrc/modinv30.cuh): plain residue in, plain inverse out ----------------------

@@ -48,6 +48,24 @@ def test_no_torch_types_in_signatures():
     assert 'extern "C"' in text
 
 
+def test_header_compiles_as_c_and_links(lib, tmp_path):
+    """include/kateth_amd.h is a C header: a C translation unit (gcc -std=c99 -pedantic) that takes the address of every
+    declared entry point compiles, and links against the library (resolving every symbol)."""
+    from kateth_amd import kzg
+
+    names = declared_functions()
+    src = tmp_path / "use_header.c"
+    src.write_text('#include "kateth_amd.h"\n#include <stdio.h>\ntypedef void (*fn)(void);\nint main(void) {\n  fn table[] = {%s};\n'
+                   '  kzg_config cfg = {0, 8, 0, 0};\n  printf("%%d %%d\\n", (int)(sizeof table / sizeof table[0]), (int)cfg.window_bits + KZG_BYTES_PER_G1);\n  return table[0] == 0;\n}\n'
+                   % ", ".join("(fn)%s" % n for n in names))
+    exe = str(tmp_path / "use_header")
+    hip = "/opt/rocm/lib/libamdhip64.so"
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-Wno-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", exe, kzg.library_path(), hip,
+                           "-Wl,-rpath," + os.path.dirname(kzg.library_path()), "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.check_output([exe], text=True).split()
+    assert int(out[0]) == len(names) and int(out[1]) == 8 + 48
+
+
 def test_fails_loudly_without_gpu(lib):
     import torch
 

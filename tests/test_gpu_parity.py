@@ -56,10 +56,15 @@ def synth_blob(b, seed=0x4844):
 
 
 def test_native_library_is_loaded(engine):
+    import subprocess
+
     import kateth_amd
 
     assert os.path.exists(kateth_amd.library_path())
     assert engine.window_bits == 8 and engine.table_bytes > 0
+    # the product library carries ONE fixed-base MSM kernel (the 32-bit-limb one lives in the test-only build)
+    syms = subprocess.check_output(["strings", kateth_amd.library_path()], text=True)
+    assert "k_msm_fixed28" in syms and "k_msm_fixedILb" not in syms
 
 
 def test_commitment_known_answers(engine):
@@ -498,6 +503,15 @@ def test_ragged_batch_sizes_agree_with_single_items(engine, torch_cuda):
     assert engine.verify_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr() + 48, n - 1) is False
 
 
+def _engine_with_env(monkeypatch, env, window_bits=8, lib_path=None):
+    """environment knobs are read once, at kzg_ctx_create: a context per setting"""
+    import kateth_amd
+
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    return kateth_amd.Setup.load_json(TRUSTED_SETUP, window_bits=window_bits, lib_path=lib_path)
+
+
 def test_proof_chunking_and_two_stream_pipeline_are_bit_exact(engine, torch_cuda, monkeypatch):
     """the proof path walks large batches in chunks (default 16,384 blobs, so ordinary test batches are one chunk);
     forcing tiny chunks -- serial and with the two-stream pipeline, ragged last chunk included -- must give the same
@@ -520,14 +534,16 @@ def test_proof_chunking_and_two_stream_pipeline_are_bit_exact(engine, torch_cuda
     st = want_st.cpu().tolist()
     assert st[5] == 2 and st[11] == 3 and sum(1 for v in st if v) == 2
     for chunk, overlap in (("8", "0"), ("8", "1"), ("5", "1"), ("16", "0")):
-        monkeypatch.setenv("KATETH_AMD_PROOF_CHUNK", chunk)
-        monkeypatch.setenv("KATETH_AMD_PROOF_OVERLAP", overlap)
-        got_p = torch.zeros(n * 48, dtype=torch.uint8, device="cuda")
-        got_st = torch.full((n,), -7, dtype=torch.int32, device="cuda")
-        engine.compute_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), n, got_p.data_ptr(), got_st.data_ptr())
-        torch.cuda.synchronize()
-        assert got_st.cpu().tolist() == st, (chunk, overlap)
-        assert got_p.cpu().numpy().tobytes() == want_p.cpu().numpy().tobytes(), (chunk, overlap)
+        e2 = _engine_with_env(monkeypatch, {"KATETH_AMD_PROOF_CHUNK": chunk, "KATETH_AMD_PROOF_OVERLAP": overlap})
+        try:
+            got_p = torch.zeros(n * 48, dtype=torch.uint8, device="cuda")
+            got_st = torch.full((n,), -7, dtype=torch.int32, device="cuda")
+            e2.compute_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), n, got_p.data_ptr(), got_st.data_ptr())
+            torch.cuda.synchronize()
+            assert got_st.cpu().tolist() == st, (chunk, overlap)
+            assert got_p.cpu().numpy().tobytes() == want_p.cpu().numpy().tobytes(), (chunk, overlap)
+        finally:
+            e2.close()
 
 
 def test_evaluation_kernel_group_shapes_agree(engine, golden, torch_cuda, monkeypatch):
@@ -551,16 +567,24 @@ def test_evaluation_kernel_group_shapes_agree(engine, golden, torch_cuda, monkey
     bad_blobs[129 * 131072 + 64 * 7: 129 * 131072 + 64 * 7 + 32] = 0xFF  # element 14 of blob 129 is not canonical
     flipped = d_blobs.clone()
     flipped[77 * 131072 + 31] ^= 1  # a valid but different blob 77
+    zy = {}
     for group in ("16", "64"):
-        monkeypatch.setenv("KATETH_AMD_EVAL_GROUP", group)
-        for m in (1, 2, 3, 4, 5, 67, n):
-            assert engine.verify_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), m) is True, (group, m)
-        assert engine.verify_blob_proof_batch_dev(flipped.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n) is False
-        assert engine.verify_blob_proof_batch_dev(flipped.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), 77) is True
-        with pytest.raises(kateth_amd.KzgError) as err:
-            engine.verify_blob_proof_batch_dev(bad_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n)
-        assert isinstance(err.value.inner, kateth_amd.BlobError) and err.value.inner.kind == "InvalidFieldElement"
-        assert engine.verify_blob_proof_batch_dev(bad_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), 129) is True  # the bad blob is item 129
+        e2 = _engine_with_env(monkeypatch, {"KATETH_AMD_EVAL_GROUP": group})
+        try:
+            for m in (1, 2, 3, 4, 5, 67, n):
+                assert e2.verify_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), m) is True, (group, m)
+            assert e2.verify_blob_proof_batch_dev(flipped.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n) is False
+            assert e2.verify_blob_proof_batch_dev(flipped.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), 77) is True
+            with pytest.raises(kateth_amd.KzgError) as err:
+                e2.verify_blob_proof_batch_dev(bad_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n)
+            assert isinstance(err.value.inner, kateth_amd.BlobError) and err.value.inner.kind == "InvalidFieldElement"
+            assert e2.verify_blob_proof_batch_dev(bad_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), 129) is True  # the bad blob is item 129
+            sess, _, _ = e2.verify_phase1_dev(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n)
+            zy[group] = e2.verify_session_zy(sess, 0, n)
+            e2.verify_session_destroy(sess)
+        finally:
+            e2.close()
+    assert zy["16"] == zy["64"]  # both shapes: the same challenges and evaluations, byte for byte
 
 
 def test_radix28_and_radix32_kernels_agree_at_scale(torch_cuda, monkeypatch):
@@ -569,13 +593,16 @@ def test_radix28_and_radix32_kernels_agree_at_scale(torch_cuda, monkeypatch):
     (its cheap "P == +-Q?" filter fires for 2^-17 of all additions) beside the inline path"""
     import kateth_amd
 
+    import __graft_entry__ as g
+
     torch = torch_cuda
     n = 4096
     d_blobs = torch.empty(n * 131072, dtype=torch.uint8, device="cuda")
     outs = []
     for radix in ("28", "32"):
+        # radix 28 = the product library; radix 32 = the test-only build (tests/radix32) that still carries the round-1 kernel
         monkeypatch.setenv("KATETH_AMD_MSM_RADIX", radix)
-        s = kateth_amd.Setup.load_json(TRUSTED_SETUP, window_bits=8)
+        s = kateth_amd.Setup.load_json(TRUSTED_SETUP, window_bits=8, lib_path=g.TEST_LIB_RADIX32 if radix == "32" else None)
         try:
             if not outs:
                 s.synth_blobs_dev(0x5CA1E, 0, n, d_blobs.data_ptr())
@@ -639,12 +666,14 @@ def test_mid_size_batches_take_the_unfused_preparation_path(engine, torch_cuda):
 
 
 def test_radix32_msm_kernel_is_bit_exact(golden, monkeypatch):
-    """KATETH_AMD_MSM_RADIX=32 selects the 12 x 32-bit-limb MSM kernel and the 2^384-Montgomery table; the default is the
-    radix-2^28 kernel (fp28.cuh).  Both must produce the same bytes (the rest of this file runs the default)."""
+    """the test-only build (tests/radix32, -DKZG_TEST_RADIX32) with KATETH_AMD_MSM_RADIX=32 runs the 12 x 32-bit-limb MSM
+    kernel over a 2^384-Montgomery table -- an independent implementation of the same sum; the product library carries only
+    the radix-2^28 kernel (fp28.cuh).  Both must produce the same bytes (the rest of this file runs the product)."""
     import kateth_amd
+    import __graft_entry__ as g
 
     monkeypatch.setenv("KATETH_AMD_MSM_RADIX", "32")
-    s = kateth_amd.Setup.load_json(TRUSTED_SETUP, window_bits=7)
+    s = kateth_amd.Setup.load_json(TRUSTED_SETUP, window_bits=7, lib_path=g.TEST_LIB_RADIX32)
     try:
         recs = golden["blobs"][:3]
         blobs = b"".join(synth_blob(r["index"]) for r in recs) + be32(1) * 4096 + bytes(131072) + be32(R - 1) * 4096
@@ -659,3 +688,348 @@ def test_radix32_msm_kernel_is_bit_exact(golden, monkeypatch):
             assert proofs[48 * k:48 * k + 48].hex() == r["proof"]
     finally:
         s.close()
+
+
+# ---------------------------------------------------------------------------
+# production configurations (BASELINE.json configs[1]-[3]): the windows the library and bench.py really use, and
+# batch verification at 65,536 -- the only size at which the one-lane-per-blob SHA-256 kernel (k_challenge) and the
+# variable-base MSM over 131,073 terms run
+# ---------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def cport_setup():
+    from oracle.cport import binding
+
+    cs = binding.CSetup(binding.load(), TRUSTED_SETUP, subgroup_checks=False, threads=1)
+    yield cs
+    cs.close()
+
+
+@pytest.mark.parametrize("window_bits", [14, 16])
+def test_production_windows_against_golden_and_c_port(window_bits, golden, torch_cuda, cport_setup):
+    """c = 14 (kzg_ctx_create's default) and c = 16 (bench.py's window: 192 GiB table): commitments and proofs of the six
+    golden blobs equal the golden vectors; commitments of 96 synthetic blobs equal the C port of the reference's CPU path
+    (oracle/cport, Pippenger c = 10 -- a different algorithm over the same points); for all 96 the challenge z and the
+    evaluation y the engine derives equal the C port's, and commit -> prove -> verify closes, so the proofs are the
+    unique points that satisfy the pairing equation for the C port's (z, y)."""
+    import kateth_amd
+    from oracle.cport import binding
+
+    torch = torch_cuda
+    torch.cuda.empty_cache()
+    s = kateth_amd.Setup.load_json(TRUSTED_SETUP, window_bits=window_bits)
+    try:
+        assert s.window_bits == window_bits
+        assert s.table_bytes == {14: 4096 * (18 * 8192 + 8) * 96, 16: 4096 * (16 * 32768) * 96}[window_bits]  # 54 GiB / 192 GiB
+        n = 96
+        d_blobs = torch.empty(n * 131072, dtype=torch.uint8, device="cuda")
+        s.synth_blobs_dev(golden["seed"], 0, n, d_blobs.data_ptr())
+        d_c = torch.empty(n * 48, dtype=torch.uint8, device="cuda")
+        d_p = torch.empty(n * 48, dtype=torch.uint8, device="cuda")
+        d_st = torch.empty(n, dtype=torch.int32, device="cuda")
+        s.blob_to_commitment_batch_dev(d_blobs.data_ptr(), n, d_c.data_ptr(), d_st.data_ptr())
+        s.compute_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), n, d_p.data_ptr(), d_st.data_ptr())
+        torch.cuda.synchronize()
+        assert int(d_st.abs().sum()) == 0
+        cs, ps, host = d_c.cpu().numpy().tobytes(), d_p.cpu().numpy().tobytes(), d_blobs.cpu().numpy().tobytes()
+        for rec in golden["blobs"]:
+            b = rec["index"]
+            assert cs[48 * b:48 * b + 48].hex() == rec["commitment"], (window_bits, b)
+            assert ps[48 * b:48 * b + 48].hex() == rec["proof"], (window_bits, b)
+        cport_setup.set_threads(binding.host_cores())
+        _, want = cport_setup.time_commitments_blob_parallel(host, n, 1, binding.host_cores())
+        assert cs == want
+        # z, y of every item against the C port of Blob::challenge / Polynomial::evaluate (batch-inversion variant: same values)
+        rc, z_ref, y_ref, _, _ = cport_setup.verify_batch_prepairing(host, cs, ps, n, batch_inverse=True)
+        assert rc == 0
+        sess, _, err6 = s.verify_phase1_dev(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n)
+        z_gpu, y_gpu = s.verify_session_zy(sess, 0, n)
+        s.verify_session_destroy(sess)
+        assert err6[0] == err6[2] == err6[4] == -1
+        assert z_gpu == z_ref and y_gpu == y_ref
+        for rec in golden["blobs"]:
+            b = rec["index"]
+            assert z_gpu[32 * b:32 * b + 32].hex() == rec["challenge_z"] and y_gpu[32 * b:32 * b + 32].hex() == rec["eval_y"]
+        assert s.verify_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n) is True
+        # the single-blob shape of the same window (64 splits per blob) gives the same bytes
+        assert s.blob_to_commitment(host[:131072]).hex() == golden["blobs"][0]["commitment"]
+    finally:
+        s.close()
+        torch.cuda.empty_cache()
+
+
+def test_verify_batch_65536(engine, golden, torch_cuda):
+    """BASELINE configs[3]: verify_blob_kzg_proof_batch at n = 65,536 (8 GiB of blobs resident).  The batch is valid ->
+    true; one corrupted proof -> false; one non-canonical element in a blob beyond index 32,768 -> InvalidFieldElement
+    with that blob as the first error; challenges and evaluations of this size's kernels (one lane per blob SHA-256,
+    16 lanes per blob evaluation) equal the golden vectors for blobs 0..5 and the small-batch kernels' values for a
+    window of blobs near the end of the batch."""
+    import kateth_amd
+
+    torch = torch_cuda
+    torch.cuda.empty_cache()
+    n = 65536
+    d_blobs = torch.empty(n * 131072, dtype=torch.uint8, device="cuda")
+    engine.synth_blobs_dev(golden["seed"], 0, n, d_blobs.data_ptr())
+    d_c = torch.empty(n * 48, dtype=torch.uint8, device="cuda")
+    d_p = torch.empty(n * 48, dtype=torch.uint8, device="cuda")
+    d_st = torch.empty(n, dtype=torch.int32, device="cuda")
+    engine.blob_to_commitment_batch_dev(d_blobs.data_ptr(), n, d_c.data_ptr(), d_st.data_ptr())
+    engine.compute_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), n, d_p.data_ptr(), d_st.data_ptr())
+    torch.cuda.synchronize()
+    assert int(d_st.abs().sum()) == 0
+    cs, ps = d_c.cpu().numpy().tobytes(), d_p.cpu().numpy().tobytes()
+    for rec in golden["blobs"]:
+        b = rec["index"]
+        assert cs[48 * b:48 * b + 48].hex() == rec["commitment"] and ps[48 * b:48 * b + 48].hex() == rec["proof"]
+    assert engine.verify_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n) is True
+    # z, y out of the 65,536-batch kernels
+    sess, root_full, err6 = engine.verify_phase1_dev(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n)
+    assert err6[0] == err6[2] == err6[4] == -1
+    z_head, y_head = engine.verify_session_zy(sess, 0, 6)
+    first = 65000
+    z_tail, y_tail = engine.verify_session_zy(sess, first, 64)
+    engine.verify_session_destroy(sess)
+    for rec in golden["blobs"]:
+        b = rec["index"]
+        assert z_head[32 * b:32 * b + 32].hex() == rec["challenge_z"] and y_head[32 * b:32 * b + 32].hex() == rec["eval_y"]
+    sess, _, _ = engine.verify_phase1_dev(d_blobs.data_ptr() + first * 131072, d_c.data_ptr() + first * 48, d_p.data_ptr() + first * 48, 64)
+    z_small, y_small = engine.verify_session_zy(sess, 0, 64)
+    engine.verify_session_destroy(sess)
+    assert z_tail == z_small and y_tail == y_small
+    # proofs computed with the one-lane-per-blob hash (a chunk above 32,768) equal the small-batch proofs
+    e2 = _engine_with_env_plain({"KATETH_AMD_PROOF_CHUNK": "65536"})
+    try:
+        d_p2 = torch.empty(n * 48, dtype=torch.uint8, device="cuda")
+        e2.compute_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), n, d_p2.data_ptr(), d_st.data_ptr())
+        torch.cuda.synchronize()
+        assert int(d_st.abs().sum()) == 0
+        assert torch.equal(d_p2, d_p)
+        del d_p2
+    finally:
+        e2.close()
+    # one corrupted proof
+    keep = d_p[48 * 40000:48 * 40001].clone()
+    d_p[48 * 40000:48 * 40001] = d_p[0:48]
+    assert engine.verify_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n) is False
+    d_p[48 * 40000:48 * 40001] = keep
+    # one non-canonical element beyond index 32,768, and a later one: the earlier is the first error
+    bad = 50001
+    keep_b = d_blobs[bad * 131072 + 32 * 77: bad * 131072 + 32 * 78].clone()
+    d_blobs[bad * 131072 + 32 * 77: bad * 131072 + 32 * 78] = 0xFF
+    d_blobs[60000 * 131072: 60000 * 131072 + 32] = 0xFF
+    with pytest.raises(kateth_amd.KzgError) as err:
+        engine.verify_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n)
+    assert isinstance(err.value.inner, kateth_amd.BlobError) and err.value.inner.kind == "InvalidFieldElement"
+    sess, _, err6 = engine.verify_phase1_dev(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n)
+    engine.verify_session_destroy(sess)
+    assert err6[0] == bad and err6[1] == 2 and err6[2] == -1 and err6[4] == -1
+    d_blobs[bad * 131072 + 32 * 77: bad * 131072 + 32 * 78] = keep_b
+    del d_blobs, d_c, d_p
+    torch.cuda.empty_cache()
+
+
+def _engine_with_env_plain(env, window_bits=8):
+    import kateth_amd
+
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return kateth_amd.Setup.load_json(TRUSTED_SETUP, window_bits=window_bits)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def test_affine_outputs_are_the_compressed_points(engine, golden, oracle_setup):
+    """kzg_*_affine: the producers return POINTS (Commitment = Proof = P1, src/kzg/mod.rs:9-10) as 96-byte blst_p1_affine
+    images -- x || y, little-endian limbs of the 2^384-Montgomery residue.  Checked against the oracle's decompression
+    of the golden 48-byte encodings; infinity is 96 zero bytes; a rejected blob gives zeros and its status."""
+    from oracle.pyref import bls
+
+    def image(p48):
+        pt = bls.g1_uncompress(p48)
+        if pt is None:
+            return bytes(96)
+        x, y = pt
+        return (x * (1 << 384) % bls.P).to_bytes(48, "little") + (y * (1 << 384) % bls.P).to_bytes(48, "little")
+
+    recs = golden["blobs"][:3]
+    blobs = b"".join(synth_blob(r["index"]) for r in recs)
+    cs = b"".join(bytes.fromhex(r["commitment"]) for r in recs)
+    bad = bytearray(synth_blob(0))
+    bad[0:32] = be32(R)
+    aff, st = engine.blob_to_commitment_batch_affine(blobs + bytes(131072) + bytes(bad))
+    assert st == [0, 0, 0, 0, 2]
+    for k, r in enumerate(recs):
+        assert aff[96 * k:96 * k + 96] == image(bytes.fromhex(r["commitment"])), k
+    assert aff[288:384] == bytes(96) and aff[384:480] == bytes(96)
+    paff, st = engine.compute_blob_proof_batch_affine(blobs, cs)
+    assert st == [0, 0, 0]
+    for k, r in enumerate(recs):
+        assert paff[96 * k:96 * k + 96] == image(bytes.fromhex(r["proof"])), k
+    zs = b"".join(bytes.fromhex(r["kzg_proof_at"]["z"]) for r in recs)
+    qaff, ys, st = engine.compute_proof_batch_affine(blobs, zs)
+    assert st == [0, 0, 0]
+    for k, r in enumerate(recs):
+        assert qaff[96 * k:96 * k + 96] == image(bytes.fromhex(r["kzg_proof_at"]["proof"])) and ys[32 * k:32 * k + 32].hex() == r["kzg_proof_at"]["y"]
+
+
+def test_host_buffer_verify_pipeline_matches_device_path(engine, torch_cuda):
+    """kzg_verify_blob_proof_batch streams host blobs through the staging arena in chunks (copy of chunk k+1 beside the
+    hash + evaluation of chunk k, rotating compute streams, slot reuse beyond 16 chunks): same decisions and the same first
+    error as the device-pointer entry point, ragged last chunk included; with a tiny chunk size the slot-reuse path runs."""
+    import kateth_amd
+
+    torch = torch_cuda
+    n = 1111
+    d_blobs = torch.empty(n * 131072, dtype=torch.uint8, device="cuda")
+    engine.synth_blobs_dev(0x7E57, 5, n, d_blobs.data_ptr())
+    d_c = torch.empty(n * 48, dtype=torch.uint8, device="cuda")
+    d_p = torch.empty(n * 48, dtype=torch.uint8, device="cuda")
+    d_st = torch.empty(n, dtype=torch.int32, device="cuda")
+    engine.blob_to_commitment_batch_dev(d_blobs.data_ptr(), n, d_c.data_ptr(), d_st.data_ptr())
+    engine.compute_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), n, d_p.data_ptr(), d_st.data_ptr())
+    torch.cuda.synchronize()
+    assert int(d_st.abs().sum()) == 0
+    hb, hc, hp = d_blobs.cpu().numpy().tobytes(), d_c.cpu().numpy().tobytes(), d_p.cpu().numpy().tobytes()
+    blobs = [hb[i * 131072:(i + 1) * 131072] for i in range(n)]
+    cs = [hc[i * 48:(i + 1) * 48] for i in range(n)]
+    ps = [hp[i * 48:(i + 1) * 48] for i in range(n)]
+    small = _engine_with_env_plain({"KATETH_AMD_VERIFY_CHUNK": "37"})  # 31 chunks: more than the 16 staging slots
+    try:
+        for e in (engine, small):
+            for m in (n, 512, 513, 1):
+                assert e.verify_blob_proof_batch(blobs[:m], cs[:m], ps[:m]) is True, m
+            assert e.verify_blob_proof_batch(blobs, cs, ps[:700] + [ps[0]] + ps[701:]) is False
+            badb = bytearray(blobs[1000])
+            badb[32 * 9:32 * 10] = b"\xff" * 32
+            with pytest.raises(kateth_amd.KzgError) as err:
+                e.verify_blob_proof_batch(blobs[:1000] + [bytes(badb)] + blobs[1001:], cs, ps[:3] + [bytes([0xE0]) + bytes(47)] + ps[4:])
+            assert isinstance(err.value.inner, kateth_amd.BlobError)  # the blob error wins over the earlier proof error
+            with pytest.raises(kateth_amd.KzgError) as err:
+                e.verify_blob_proof_batch(blobs, cs, ps[:3] + [bytes([0xE0]) + bytes(47)] + ps[4:])
+            assert err.value.inner.inner.kind == "InvalidEncoding"
+    finally:
+        small.close()
+
+
+def test_concurrent_callers_on_one_context(engine, golden, torch_cuda):
+    """`Setup` is shared behind an Arc and every method takes &self (src/kzg/setup.rs:323): four host threads drive ONE
+    context at the same time, mixing commitments, proofs and verifications (host-buffer and device-pointer forms, each
+    thread on its own stream); every result must equal the serial run's."""
+    import threading
+
+    torch = torch_cuda
+    n = 48
+    d_blobs = torch.empty(n * 131072, dtype=torch.uint8, device="cuda")
+    engine.synth_blobs_dev(golden["seed"], 0, n, d_blobs.data_ptr())
+    d_c = torch.empty(n * 48, dtype=torch.uint8, device="cuda")
+    d_p = torch.empty(n * 48, dtype=torch.uint8, device="cuda")
+    d_st = torch.empty(n, dtype=torch.int32, device="cuda")
+    engine.blob_to_commitment_batch_dev(d_blobs.data_ptr(), n, d_c.data_ptr(), d_st.data_ptr())
+    engine.compute_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), n, d_p.data_ptr(), d_st.data_ptr())
+    torch.cuda.synchronize()
+    hb, hc, hp = d_blobs.cpu().numpy().tobytes(), d_c.cpu().numpy().tobytes(), d_p.cpu().numpy().tobytes()
+    blobs = [hb[i * 131072:(i + 1) * 131072] for i in range(n)]
+    cs = [hc[i * 48:(i + 1) * 48] for i in range(n)]
+    ps = [hp[i * 48:(i + 1) * 48] for i in range(n)]
+    rec0 = golden["blobs"][0]
+    at = rec0["kzg_proof_at"]
+    errors = []
+
+    def worker(tid):
+        try:
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                my_c = torch.empty(n * 48, dtype=torch.uint8, device="cuda")
+                my_p = torch.empty(n * 48, dtype=torch.uint8, device="cuda")
+                my_st = torch.empty(n, dtype=torch.int32, device="cuda")
+                for it in range(6):
+                    k = (tid + it) % 4
+                    if k == 0:
+                        engine.blob_to_commitment_batch_dev(d_blobs.data_ptr(), n, my_c.data_ptr(), my_st.data_ptr(), stream.cuda_stream)
+                        stream.synchronize()
+                        assert my_c.cpu().numpy().tobytes() == hc
+                        out, st = engine.blob_to_commitment_batch(hb[: 5 * 131072])
+                        assert out == hc[: 5 * 48] and st == [0] * 5
+                    elif k == 1:
+                        engine.compute_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), n, my_p.data_ptr(), my_st.data_ptr(), stream.cuda_stream)
+                        stream.synchronize()
+                        assert my_p.cpu().numpy().tobytes() == hp
+                        assert engine.blob_proof(blobs[3], cs[3]) == ps[3]
+                    elif k == 2:
+                        assert engine.verify_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n, stream.cuda_stream) is True
+                        assert engine.verify_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr() + 48, n - 1, stream.cuda_stream) is False
+                        assert engine.verify_proof(bytes.fromhex(at["proof"]), bytes.fromhex(rec0["commitment"]), bytes.fromhex(at["z"]), bytes.fromhex(at["y"])) is True
+                    else:
+                        assert engine.verify_blob_proof_batch(blobs[:9], cs[:9], ps[:9]) is True
+                        assert engine.verify_blob_proof_batch(blobs[:9], cs[:9], ps[1:10]) is False
+                        assert engine.verify_blob_proof(blobs[7], cs[7], ps[7]) is True
+        except BaseException as err:  # noqa: BLE001
+            errors.append((tid, repr(err)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    assert not any(t.is_alive() for t in threads)
+
+
+# ---------------------------------------------------------------------------
+# pins that do not pass through the oracle's MSM / quotient code: the ceremony's G2 points and closed forms
+# ---------------------------------------------------------------------------
+def _blob_of(evals):
+    return b"".join(be32(v) for v in evals)
+
+
+def test_gpu_commitment_against_all_65_ceremony_g2_points(engine, oracle_setup):
+    """p(x) = sum_k rho_k x^k (k = 0..64): the ENGINE's commitment C must satisfy e(C, G2) == e(G1, sum_k rho_k [tau^k]_2)
+    with the trusted setup's own G2 monomial points -- data neither the engine nor the oracle produced (only the oracle's
+    pairing and G2 arithmetic take part in the check, not its MSM)."""
+    import random
+
+    from oracle.pyref import bls
+
+    rnd = random.Random(6565)
+    roots = oracle_setup.roots_of_unity_brp
+    rho = [rnd.randrange(1, R) for _ in range(65)]
+    evals = []
+    for w in roots:
+        acc = 0
+        for c in reversed(rho):
+            acc = (acc * w + c) % R
+        evals.append(acc)
+    c48 = engine.blob_to_commitment(_blob_of(evals))
+    q = None
+    for k, c in enumerate(rho):
+        q = bls.g2_add(q, bls.g2_mul(oracle_setup.g2_monomial[k], c))
+    assert bls.verify_pairings((bls.g1_uncompress(c48), bls.G2_GEN), (bls.G1_GEN, q))
+    assert not bls.verify_pairings((bls.g1_uncompress(c48), bls.G2_GEN), (bls.G1_GEN, bls.g2_add(q, oracle_setup.g2_monomial[33])))
+
+
+def test_gpu_proofs_on_monomials_match_the_closed_form(engine, oracle_setup):
+    """p(x) = x^k: y = z^k and proof = sum_{j<k} z^(k-1-j) [tau^j]_1, with [tau^j]_1 the engine's own commitment of x^j
+    (tied to the ceremony by the test above); the combination uses only the oracle's G1 add / scalar-mul.  z off the
+    domain and on it (src/kzg/poly.rs:50-64)."""
+    from oracle.pyref import bls
+
+    roots = oracle_setup.roots_of_unity_brp
+    k = 7
+    blobs = b"".join(_blob_of([pow(w, j, R) for w in roots]) for j in range(k + 1))
+    cs, st = engine.blob_to_commitment_batch(blobs)
+    assert st == [0] * (k + 1) and cs[:48] == GEN48
+    taus = [bls.g1_uncompress(cs[48 * j:48 * j + 48]) for j in range(k)]
+    xk = blobs[k * 131072:]
+    for z in (0xFEEDFACECAFEBEEF, roots[3000], roots[1]):
+        proof, y = engine.proof(xk, be32(z))
+        assert y == be32(pow(z, k, R))
+        want = None
+        for j in range(k):
+            want = bls.g1_add(want, bls.g1_mul(taus[j], pow(z, k - 1 - j, R)))
+        assert proof == bls.g1_compress(want), hex(z)
+        assert engine.verify_proof(proof, cs[48 * k:48 * k + 48], be32(z), y) is True

@@ -405,6 +405,25 @@ def test_g1_compress_radix28_matches_reference_path(hm):
     assert hm.hm_f28_violations() == 0
 
 
+def test_affine_output_is_the_blst_p1_affine_image(hm):
+    """the 96-byte point form of the *_affine entry points (x || y, 2^384-Montgomery residues as little-endian limbs,
+    infinity = zeros) equals the oracle's affine point; the 48-byte encoding produced beside it is unchanged"""
+    rnd = random.Random(96)
+    out96 = ctypes.create_string_buffer(96)
+    out48 = ctypes.create_string_buffer(48)
+    pts = [bls.g1_mul(bls.G1_GEN, rnd.randrange(1, R)) for _ in range(5)]
+    enc = [bls.g1_compress(p) for p in pts]
+    want = None
+    for k in range(1, 6):
+        want = bls.g1_add(want, pts[k - 1])
+        assert hm.hm_g1_sum_affine96(out96, out48, b"".join(enc[:k]), k) == 0
+        x, y = want
+        assert out96.raw == (x * (1 << 384) % P).to_bytes(48, "little") + (y * (1 << 384) % P).to_bytes(48, "little")
+        assert out48.raw == bls.g1_compress(want)
+    assert hm.hm_g1_sum_affine96(out96, out48, enc[0] + bls.g1_compress(bls.g1_neg(pts[0])), 2) == 0
+    assert out96.raw == bytes(96) and out48.raw == bls.g1_compress(None)
+
+
 def test_safegcd_inversion(hm):
     """modinv30 (Bernstein-Yang divsteps on signed 30-bit limbs) against pow(a, -1, m) for Fp and Fr: edge values,
     values with long runs of zero bits, random values; 0 -> 0"""

@@ -214,3 +214,59 @@ def test_prove_verify_closure_small_batch(oracle_setup):
     assert not oracle_setup.verify_blob_proof(bytes(bad), cs[0], ps[0])
     with pytest.raises(KzgError):
         oracle_setup.verify_blob_proof_batch([bytes(5)], cs[:1], ps[:1])
+
+
+# ---- ceremony pins beyond k = 1 -------------------------------------------------------------
+# The trusted setup's 65 G2 monomial points [tau^k]_2 are data the oracle did not produce.  commit(x^k) must be
+# [tau^k]_1, so  e(commit(x^k), G2) == e(G1, [tau^k]_2)  ties the oracle's MSM, BRP convention, roots of unity, G2
+# decoding and pairing to all of them.
+def _monomial_blob(k, roots):
+    return [pow(w, k, R) for w in roots]
+
+
+def test_ceremony_identity_for_higher_monomials(oracle_setup):
+    roots = oracle_setup.roots_of_unity_brp
+    for k in (2, 3, 17, 64):
+        ck = oblob.commitment(_monomial_blob(k, roots), oracle_setup)
+        assert bls.verify_pairings((ck, bls.G2_GEN), (bls.G1_GEN, oracle_setup.g2_monomial[k])), k
+        assert not bls.verify_pairings((ck, bls.G2_GEN), (bls.G1_GEN, oracle_setup.g2_monomial[k - 1])), k
+
+
+def test_ceremony_identity_random_combination_of_all_65_monomials(oracle_setup):
+    """one commitment against ALL 65 G2 points: p(x) = sum_k rho_k x^k with pseudo-random rho_k;
+    e(commit(p), G2) == e(G1, sum_k rho_k [tau^k]_2).  A wrong [tau^k] relation for any k would break it."""
+    import random
+
+    rnd = random.Random(65)
+    roots = oracle_setup.roots_of_unity_brp
+    rho = [rnd.randrange(1, R) for _ in range(65)]
+    evals = []
+    for w in roots:
+        acc = 0
+        for c in reversed(rho):  # Horner
+            acc = (acc * w + c) % R
+        evals.append(acc)
+    cp = oblob.commitment(evals, oracle_setup)
+    q = None
+    for k, c in enumerate(rho):
+        q = bls.g2_add(q, bls.g2_mul(oracle_setup.g2_monomial[k], c))
+    assert bls.verify_pairings((cp, bls.G2_GEN), (bls.G1_GEN, q))
+    q2 = bls.g2_add(q, oracle_setup.g2_monomial[40])  # coefficient 40 off by one
+    assert not bls.verify_pairings((cp, bls.G2_GEN), (bls.G1_GEN, q2))
+
+
+def test_prove_on_monomials_matches_closed_form(oracle_setup):
+    """p(x) = x^k:  y = z^k  and the quotient is sum_{j<k} z^(k-1-j) x^j, so the proof is
+    sum_j z^(k-1-j) [tau^j]_1 with [tau^j]_1 = commit(x^j) (pinned to the ceremony's G2 side above).
+    Off-domain z and an in-domain z (the reference's special branch, src/kzg/poly.rs:50-64)."""
+    roots = oracle_setup.roots_of_unity_brp
+    k = 5
+    taus = [oblob.commitment(_monomial_blob(j, roots), oracle_setup) for j in range(k)]
+    assert taus[0] == bls.G1_GEN
+    for z in (0x1234567890ABCDEF, roots[77]):
+        y, pi = poly.prove(_monomial_blob(k, roots), z, oracle_setup)
+        assert y == pow(z, k, R)
+        want = None
+        for j in range(k):
+            want = bls.g1_add(want, bls.g1_mul(taus[j], pow(z, k - 1 - j, R)))
+        assert pi == want

@@ -15,10 +15,11 @@ import kateth_amd  # noqa: E402
 SETUP = os.path.join(ROOT, "tests", "golden", "trusted_setup_4096.json")
 batches = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 n = 4096
-os.environ["KATETH_AMD_MSM_RADIX"] = "28"
-s28 = kateth_amd.Setup.load_json(SETUP, window_bits=12)
-os.environ["KATETH_AMD_MSM_RADIX"] = "32"
-s32 = kateth_amd.Setup.load_json(SETUP, window_bits=12)
+import __graft_entry__ as g  # noqa: E402
+
+s28 = kateth_amd.Setup.load_json(SETUP, window_bits=12)  # the product library: radix-2^28 kernel only
+os.environ["KATETH_AMD_MSM_RADIX"] = "32"  # honoured only by the test-only build (tests/radix32, -DKZG_TEST_RADIX32)
+s32 = kateth_amd.Setup.load_json(SETUP, window_bits=12, lib_path=g.TEST_LIB_RADIX32)
 d_blobs = torch.empty(n * 131072, dtype=torch.uint8, device="cuda")
 bufs = [torch.empty(n * 48, dtype=torch.uint8, device="cuda") for _ in range(4)]
 d_st = torch.empty(n, dtype=torch.int32, device="cuda")
