@@ -68,6 +68,9 @@ typedef struct kzg_config {
 
 /* Thread-local text for the last negative return on this thread ("" if none). */
 const char* kzg_last_error(void);
+/* When that return was KZG_FAIL_SETUP_G1 / KZG_FAIL_SETUP_G2: the KZG_ERR_EC_* code of the rejected setup point, so that
+ * the caller can rebuild LoadSetupError::Bls(bls::Error::ECGroup(..)) exactly (src/kzg/setup.rs:59-72); otherwise 0. */
+int32_t kzg_last_error_code(void);
 
 /*
  * Replaces Setup::<4096,65>::load_json after JSON/hex parsing

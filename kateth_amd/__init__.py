@@ -8,6 +8,8 @@ engine on a machine without the built library or without a GPU fails loudly.
 """
 from .kzg import (  # noqa: F401
     BYTES_PER_BLOB,
+    P1,
+    Blob,
     BlobError,
     BlsError,
     ECGroupError,
@@ -20,6 +22,8 @@ from .kzg import (  # noqa: F401
 
 __all__ = [
     "Setup",
+    "Blob",
+    "P1",
     "BlobError",
     "BlsError",
     "ECGroupError",

@@ -10,10 +10,19 @@
 // error plumbing
 // ---------------------------------------------------------------------------
 static thread_local std::string g_last_error;
+static thread_local int32_t g_last_detail = 0;
 extern "C" const char* kzg_last_error(void) { return g_last_error.c_str(); }
+extern "C" int32_t kzg_last_error_code(void) { return g_last_detail; }
 
 int32_t fail(int32_t code, const std::string& msg) {
   g_last_error = msg;
+  g_last_detail = 0;
+  return code;
+}
+// a failure caused by a rejected input: `detail` is the KZG_ERR_* code of that input
+static int32_t fail_detail(int32_t code, int32_t detail, const std::string& msg) {
+  g_last_error = msg;
+  g_last_detail = detail;
   return code;
 }
 const std::string& last_error_text() { return g_last_error; }
@@ -201,7 +210,7 @@ static int32_t ctx_build(kzg_ctx* ctx, const uint8_t* g1_lagrange, const uint8_t
     for (int i = 0; i < KZG_SETUP_G2_POINTS; i++) {
       host::g2_affine q;
       int32_t stq = host::g2_decompress(q, g2_monomial + 96 * i);
-      if (stq != 0) return fail(KZG_FAIL_SETUP_G2, "g2_monomial[" + std::to_string(i) + "] rejected, code " + std::to_string(stq));
+      if (stq != 0) return fail_detail(KZG_FAIL_SETUP_G2, stq, "g2_monomial[" + std::to_string(i) + "] rejected, code " + std::to_string(stq));
       if (i == 1) tau = q;
     }
     ctx->pairing = new host::pairing_ctx();
@@ -245,7 +254,7 @@ static int32_t ctx_build(kzg_ctx* ctx, const uint8_t* g1_lagrange, const uint8_t
   HIP_TRY(hipMemcpy(h_status.data(), d_status, 4096 * sizeof(int32_t), hipMemcpyDeviceToHost));
   for (int i = 0; i < 4096; i++)
     if (h_status[i] != 0)
-      return fail(KZG_FAIL_SETUP_G1, "g1_lagrange[" + std::to_string(i) + "] rejected, code " + std::to_string(h_status[i]) +
+      return fail_detail(KZG_FAIL_SETUP_G1, h_status[i] == 100 ? 0 : h_status[i], "g1_lagrange[" + std::to_string(i) + "] rejected, code " + std::to_string(h_status[i]) +
                                          (h_status[i] == 100 ? " (point at infinity is not supported as a setup base)" : ""));
   tt.mark("G1 decode");
   // ---- roots of unity -------------------------------------------------------
@@ -311,8 +320,10 @@ extern "C" int32_t kzg_ctx_create(const uint8_t* g1_lagrange, const uint8_t* g2_
   int32_t rc = ctx_build(ctx, g1_lagrange, g2_monomial);
   if (rc != 0) {
     std::string keep = g_last_error;
+    const int32_t keep_detail = g_last_detail;
     kzg_ctx_destroy(ctx);
     g_last_error = keep;
+    g_last_detail = keep_detail;
     return rc;
   }
   *out = ctx;

@@ -110,6 +110,7 @@ _i32p = ctypes.POINTER(ctypes.c_int32)
 
 _SIGNATURES = {
     "kzg_last_error": (ctypes.c_char_p, []),
+    "kzg_last_error_code": (ctypes.c_int32, []),
     "kzg_ctx_create": (ctypes.c_int32, [_u8p, _u8p, ctypes.POINTER(_Config), ctypes.POINTER(ctypes.c_void_p)]),
     "kzg_ctx_destroy": (None, [ctypes.c_void_p]),
     "kzg_ctx_window_bits": (ctypes.c_int32, [ctypes.c_void_p]),
@@ -205,12 +206,95 @@ def load_library(path: Optional[str] = None):
 def _buf(data) -> bytes:
     if isinstance(data, (bytes, bytearray, memoryview)):
         return bytes(data)
+    if hasattr(data, "to_bytes") and not isinstance(data, int):  # a Blob
+        return data.to_bytes()
     return bytes(bytearray(data))
 
 
 def _unhex(s: str) -> bytes:
     """`Bytes` deserialiser (src/bytes.rs:30-37): optional 0x prefix."""
     return bytes.fromhex(s[2:] if s.startswith("0x") else s)
+
+
+_R = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001  # Fr modulus
+_P = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB  # Fp modulus
+
+
+class Blob:
+    """`Blob<4096>` (src/blob.rs:18-76): a validated 131,072-byte blob.  Host-side container only -- every computation
+    on it happens in the engine; `from_slice` repeats the reference's parse checks so that the type has its meaning."""
+
+    BYTES = BYTES_PER_BLOB  # Blob::<4096>::BYTES, src/blob.rs:24
+
+    def __init__(self, data: bytes):
+        self._data = data
+
+    @classmethod
+    def from_slice(cls, data) -> "Blob":
+        """src/blob.rs:26-37: InvalidLen unless 131,072 bytes; InvalidFieldElement unless every 32-byte big-endian chunk is < r."""
+        data = _buf(data)
+        if len(data) != cls.BYTES:
+            raise BlobError("InvalidLen")
+        rb = _R.to_bytes(32, "big")
+        for i in range(0, cls.BYTES, 32):
+            if data[i:i + 32] >= rb:  # big-endian: bytewise order is numeric order
+                raise BlobError("InvalidFieldElement")
+        return cls(data)
+
+    def to_bytes(self) -> bytes:
+        """src/blob.rs:39-46"""
+        return self._data
+
+    @classmethod
+    def random(cls, gen) -> "Blob":
+        """src/blob.rs:66-76: each element = SHA-256(512 bytes from `gen`) reduced mod r (`Fr::hash_to`, src/bls.rs:189-205).
+        `gen` is anything with randbytes(n) (random.Random) or a callable n -> bytes."""
+        import hashlib
+
+        fill = gen.randbytes if hasattr(gen, "randbytes") else gen
+        out = bytearray()
+        for _ in range(cls.BYTES // 32):
+            out += (int.from_bytes(hashlib.sha256(fill(512)).digest(), "big") % _R).to_bytes(32, "big")
+        return cls(bytes(out))
+
+    def __bytes__(self):
+        return self._data
+
+    def __len__(self):
+        return len(self._data)
+
+
+class P1:
+    """`bls::P1` as the reference's producers return it (`Commitment = Proof = P1`, src/kzg/mod.rs:9-10): the engine hands
+    the point over as a 96-byte blst_p1_affine image (x || y, little-endian limbs of the 2^384-Montgomery residue; all
+    zero = infinity), which is what a Rust caller feeds to blst_p1_from_affine.  `compress` is the caller-side
+    `Compress::compress` (src/bls.rs:491-503, a blst CPU call in the reference): a change of encoding of a point the GPU
+    already normalised, kept here so the mirror's call sites read like benches/kzg.rs:24-32."""
+
+    COMPRESSED = 48
+
+    def __init__(self, affine96: bytes):
+        assert len(affine96) == 96
+        self.affine = bytes(affine96)
+
+    def is_inf(self) -> bool:
+        return not any(self.affine)
+
+    def compress(self) -> bytes:
+        if self.is_inf():
+            return bytes([0xC0]) + bytes(47)
+        rinv = pow(1 << 384, -1, _P)
+        x = int.from_bytes(self.affine[:48], "little") * rinv % _P
+        y = int.from_bytes(self.affine[48:], "little") * rinv % _P
+        out = bytearray(x.to_bytes(48, "big"))
+        out[0] |= 0x80 | (0x20 if y > (_P - 1) // 2 else 0)
+        return bytes(out)
+
+    def __eq__(self, other):
+        return isinstance(other, P1) and self.affine == other.affine
+
+    def __hash__(self):
+        return hash(self.affine)
 
 
 class Setup:
@@ -255,8 +339,10 @@ class Setup:
         cfg = _Config(device, window_bits, 0, 0)
         out = ctypes.c_void_p()
         rc = lib.kzg_ctx_create(b"".join(g1_lagrange), b"".join(g2_monomial), ctypes.byref(cfg), ctypes.byref(out))
-        if rc in (-4, -5):
-            raise LoadSetupError("Bls: " + lib.kzg_last_error().decode())
+        if rc in (-4, -5):  # LoadSetupError::Bls(bls::Error::ECGroup(..)), src/kzg/setup.rs:59-72
+            code = lib.kzg_last_error_code()
+            kind = str(error_from_status(code)) if code in _STATUS else "ECGroup"
+            raise LoadSetupError("Bls(%s): %s" % (kind, lib.kzg_last_error().decode()))
         if rc != 0:
             raise EngineError("kzg_ctx_create failed (%d): %s" % (rc, lib.kzg_last_error().decode()))
         return cls(out.value, lib)
@@ -358,6 +444,40 @@ class Setup:
         return proofs.raw, ys.raw, list(status)
 
     # -- reference-shaped API ----------------------------------------------------
+    # `Setup::blob_to_commitment / blob_proof / proof` with the reference's return type (a point), for call sites shaped
+    # like benches/kzg.rs:24-32 (`kzg.blob_to_commitment(blob).unwrap().compress(&mut bytes)`)
+    def blob_to_commitment_point(self, blob) -> P1:
+        blob = _buf(blob)
+        if len(blob) != BYTES_PER_BLOB:
+            raise BlobError("InvalidLen")
+        out, status = self.blob_to_commitment_batch_affine(blob, 1)
+        if status[0]:
+            raise error_from_status(status[0])
+        return P1(out)
+
+    def blob_proof_point(self, blob, commitment: bytes) -> P1:
+        blob, commitment = _buf(blob), _buf(commitment)
+        if len(blob) != BYTES_PER_BLOB:
+            raise KzgError(BlobError("InvalidLen"))
+        if len(commitment) != 48:
+            raise KzgError(BlsError(ECGroupError("InvalidEncoding")))
+        out, status = self.compute_blob_proof_batch_affine(blob, commitment)
+        if status[0]:
+            raise _kzg_error(status[0])
+        return P1(out)
+
+    def proof_point(self, blob, point: bytes):
+        """(P1 proof, y32)"""
+        blob, point = _buf(blob), _buf(point)
+        if len(blob) != BYTES_PER_BLOB:
+            raise KzgError(BlobError("InvalidLen"))
+        if len(point) != 32:
+            raise KzgError(BlsError(FiniteFieldError("InvalidEncoding")))
+        proofs, ys, status = self.compute_proof_batch_affine(blob, point)
+        if status[0]:
+            raise _kzg_error(status[0])
+        return P1(proofs), ys
+
     def blob_to_commitment(self, blob: bytes) -> bytes:
         """`Setup::blob_to_commitment` + `compress`: 48-byte commitment or BlobError."""
         blob = _buf(blob)

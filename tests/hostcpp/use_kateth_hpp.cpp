@@ -1,6 +1,7 @@
 // Compile-and-link check of the C++ host mirror (kateth_amd/host/kateth.hpp) against the C ABI.
 // On a machine without a GPU it must fail loudly with KZG_FAIL_NO_DEVICE; with one it runs a tiny round trip.
 #include <cstdio>
+#include <random>
 #include <vector>
 
 #include "../../kateth_amd/host/kateth.hpp"
@@ -23,6 +24,16 @@ int main(int argc, char** argv) {
     kateth::Bytes48 p = setup.blob_proof(blob.data(), blob.size(), c);
     bool ok = setup.verify_blob_proof(blob.data(), blob.size(), c, p);
     std::printf("commitment[0]=%02x proof[0]=%02x verify=%d\n", c[0], p[0], (int)ok);
+    // Blob::random -> commit (point and bytes) -> prove -> verify, the input pipeline of benches/kzg.rs:17-33
+    std::mt19937_64 gen(4844);
+    kateth::Blob rb = kateth::Blob::random(gen);
+    kateth::Blob::from_slice(rb.to_bytes().data(), rb.to_bytes().size());  // every element canonical
+    kateth::Bytes48 rc = setup.blob_to_commitment(rb.to_bytes().data(), kateth::Blob::BYTES);
+    kateth::P1 rcp = setup.blob_to_commitment_point(rb.to_bytes().data(), kateth::Blob::BYTES);
+    kateth::Bytes48 rp = setup.blob_proof(rb.to_bytes().data(), kateth::Blob::BYTES, rc);
+    const bool ok2 = setup.verify_blob_proof(rb.to_bytes().data(), kateth::Blob::BYTES, rc, rp) && !rcp.is_inf() && rcp.compress() == rc;  // benches/kzg.rs:24-26
+    std::printf("random blob: commitment[0]=%02x affine[0]=%02x verify=%d\n", rc[0], rcp.affine[0], (int)ok2);
+    if (!ok2) return 6;
     try {
       setup.blob_to_commitment(blob.data(), blob.size() - 1);
       return 3;

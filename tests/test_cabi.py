@@ -136,6 +136,30 @@ def test_cpp_host_mirror_links_and_fails_loudly_without_gpu(lib, tmp_path):
     assert rc == 42
 
 
+def test_cpp_mirror_p1_compress_and_blob(lib, tmp_path):
+    """kateth::P1::compress (the caller-side `Compress::compress`, src/bls.rs:491-503, on the 96-byte blst_p1_affine image the
+    *_affine entry points return) against the oracle; kateth::Blob::{random, from_slice} (src/blob.rs:26-37,66-76)"""
+    import random
+
+    from kateth_amd import kzg
+    from oracle.pyref import bls
+
+    exe = str(tmp_path / "p1_compress")
+    hip = "/opt/rocm/lib/libamdhip64.so"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", os.path.join(ROOT, "tests", "hostcpp", "p1_compress.cpp"), "-o", exe, kzg.library_path(), hip,
+                           "-Wl,-rpath," + os.path.dirname(kzg.library_path()), "-Wl,-rpath,/opt/rocm/lib"])
+    rnd = random.Random(3)
+    for k in range(6):
+        pt = bls.g1_mul(bls.G1_GEN, rnd.randrange(1, bls.R))
+        if k % 2:
+            pt = bls.g1_neg(pt)
+        x, y = pt
+        img = (x * (1 << 384) % bls.P).to_bytes(48, "little") + (y * (1 << 384) % bls.P).to_bytes(48, "little")
+        assert subprocess.check_output([exe, img.hex()], text=True).strip() == bls.g1_compress(pt).hex()
+    assert subprocess.check_output([exe, bytes(96).hex()], text=True).strip() == bls.g1_compress(None).hex()
+    assert subprocess.check_output([exe, "blob"], text=True).strip() == "131072"
+
+
 @pytest.mark.gpu
 def test_cpp_host_mirror_round_trip_on_gpu(tmp_path):
     import json

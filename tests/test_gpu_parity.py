@@ -1033,3 +1033,62 @@ def test_gpu_proofs_on_monomials_match_the_closed_form(engine, oracle_setup):
             want = bls.g1_add(want, bls.g1_mul(taus[j], pow(z, k - 1 - j, R)))
         assert proof == bls.g1_compress(want), hex(z)
         assert engine.verify_proof(proof, cs[48 * k:48 * k + 48], be32(z), y) is True
+
+
+def test_point_returning_methods_match_the_byte_returning_ones(engine, golden):
+    """`Setup::blob_to_commitment / blob_proof / proof` return points in the reference (src/kzg/setup.rs:167,177,185) and
+    every caller compresses next (benches/kzg.rs:24-32): the mirror's *_point methods + P1.compress give the golden bytes."""
+    import random
+
+    import kateth_amd
+
+    rec = golden["blobs"][1]
+    blob = kateth_amd.Blob.from_slice(synth_blob(rec["index"]))
+    c = engine.blob_to_commitment_point(blob)
+    assert isinstance(c, kateth_amd.P1) and c.compress().hex() == rec["commitment"]
+    p = engine.blob_proof_point(blob, c.compress())
+    assert p.compress().hex() == rec["proof"]
+    q, y = engine.proof_point(blob, bytes.fromhex(rec["kzg_proof_at"]["z"]))
+    assert q.compress().hex() == rec["kzg_proof_at"]["proof"] and y.hex() == rec["kzg_proof_at"]["y"]
+    assert engine.blob_to_commitment_point(bytes(131072)).is_inf()
+    # Blob::random -> commit -> prove -> verify (the bench's input pipeline, benches/kzg.rs:17-33)
+    rb = kateth_amd.Blob.random(random.Random(7))
+    c48 = engine.blob_to_commitment_point(rb).compress()
+    p48 = engine.blob_proof_point(rb, c48).compress()
+    assert engine.verify_blob_proof(rb.to_bytes(), c48, p48) is True
+
+
+def test_load_setup_rejects_bad_points_with_the_reference_error():
+    """Setup::load_json maps a rejected point to LoadSetupError::Bls(ECGroup(..)) (src/kzg/setup.rs:59-72): the engine
+    reports which class through kzg_last_error_code"""
+    import kateth_amd
+    from oracle.pyref import bls
+
+    raw = json.load(open(TRUSTED_SETUP))
+    g1 = [bytes.fromhex(s[2:]) for s in raw["g1_lagrange"]]
+    g2 = [bytes.fromhex(s[2:]) for s in raw["g2_monomial"]]
+    x = 1
+    while True:
+        y = bls._fp_sqrt(x**3 + 4)
+        if y is not None and not bls.g1_in_subgroup((x, y)):
+            break
+        x += 1
+    x2 = 1
+    while bls._fp_sqrt(x2**3 + 4) is not None:
+        x2 += 1
+    cases = [
+        (7, bls.g1_compress((x, y)), "NotInGroup"),
+        (4095, bytes([g1[4095][0] & 0x7F]) + g1[4095][1:], "InvalidEncoding"),
+        (0, bytes([0x80]) + x2.to_bytes(48, "big")[1:], "NotOnCurve"),
+    ]
+    for idx, bad, kind in cases:
+        pts = list(g1)
+        pts[idx] = bad
+        with pytest.raises(kateth_amd.LoadSetupError, match="ECGroupError::" + kind) as e:
+            kateth_amd.Setup.from_bytes(pts, g2, window_bits=6)
+        assert "g1_lagrange[%d]" % idx in str(e.value)
+    q = list(g2)
+    q[3] = bytes([g2[3][0] & 0x7F]) + g2[3][1:]
+    with pytest.raises(kateth_amd.LoadSetupError, match="ECGroupError::InvalidEncoding") as e:
+        kateth_amd.Setup.from_bytes(g1, q, window_bits=6)
+    assert "g2_monomial[3]" in str(e.value)

@@ -1,0 +1,25 @@
+#!/bin/bash
+# Round-2 evidence: rocprofv3 passes over bench.py (one process, --gpus 1).  Kernel trace + stats for the default run
+# (commit + proof + verify at c = 16), then PMC passes -- each in its own run, never combined with tracing -- for the
+# verify workload (SQ counters, FETCH_SIZE, WRITE_SIZE) and for the commit workload.  Summaries land in
+# gpurun_out/r02/prof/*.json|csv; copy the ones to be judged into profiles/r02/.
+set -o pipefail
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/r02/prof
+mkdir -p $OUT
+run() {  # name, rocprof args..., -- bench args
+  local name=$1; shift
+  echo "[profile] $name" >&2
+  rocprofv3 "$@" > $OUT/$name.log 2>&1 || { tail -5 $OUT/$name.log; exit 1; }
+}
+WIN=${WIN:-16}
+run trace_default --kernel-trace --stats --output-format csv -d $OUT/trace_default -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --window-bits $WIN
+run pmc_verify_sq --pmc SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/pmc_verify_sq -- python3 $R/bench.py --workload verify --steps 3 --warmup 1 --no-cpu-baseline --window-bits 12
+run pmc_verify_fetch --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_verify_fetch -- python3 $R/bench.py --workload verify --steps 3 --warmup 1 --no-cpu-baseline --window-bits 12
+run pmc_verify_write --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_verify_write -- python3 $R/bench.py --workload verify --steps 3 --warmup 1 --no-cpu-baseline --window-bits 12
+run pmc_commit_sq --pmc SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/pmc_commit_sq -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra --window-bits $WIN
+run pmc_commit_fetch --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_commit_fetch -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra --window-bits $WIN
+run pmc_commit_write --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_commit_write -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra --window-bits $WIN
+run pmc_proof_sq --pmc SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/pmc_proof_sq -- python3 $R/bench.py --workload proof --steps 3 --warmup 1 --no-cpu-baseline --window-bits 12
+python3 $R/tools/summarize_profiles.py $OUT
