@@ -74,6 +74,7 @@ static MsmGeom make_geom(uint32_t c) {
 
 uint32_t choose_splits(const kzg_ctx* ctx, uint64_t n) {
   // aim for >= 4 waves per SIMD-slot-pair across the chip; splits is a power of two <= 64
+  if (ctx->knobs.msm_splits) return ctx->knobs.msm_splits;
   const uint64_t target = (uint64_t)ctx->num_cus * 8;
   uint32_t s = 1;
   while (s < 64 && n * s < target) s <<= 1;
@@ -153,6 +154,10 @@ EnvKnobs read_env_knobs() {
     if (const char* e = getenv("KATETH_AMD_EVAL_GROUP")) k.eval_group = atoi(e);
     k.verify_serial = getenv("KATETH_AMD_VERIFY_SERIAL") != nullptr;
     if (const char* e = getenv("KATETH_AMD_VERIFY_CHUNK")) k.verify_chunk = (uint64_t)atoll(e) > 0 ? (uint64_t)atoll(e) : 0;
+    if (const char* e = getenv("KATETH_AMD_MSM_SPLITS")) {
+      const int v = atoi(e);
+      if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) k.msm_splits = (uint32_t)v;
+    }
     if (const char* e = getenv("KATETH_AMD_CHALLENGE_SPLIT_MAX")) k.challenge_split_max = (uint64_t)atoll(e) > 0 ? (uint64_t)atoll(e) : 0;
     return k;
   }

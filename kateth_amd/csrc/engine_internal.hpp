@@ -37,6 +37,7 @@ struct EnvKnobs {
   int eval_group = 0;            // KATETH_AMD_EVAL_GROUP: 16 | 64 (0 = automatic)
   bool verify_serial = false;    // KATETH_AMD_VERIFY_SERIAL
   uint64_t verify_chunk = 0;     // KATETH_AMD_VERIFY_CHUNK: blobs per host-buffer staging chunk (0 = default)
+  uint32_t msm_splits = 0;       // KATETH_AMD_MSM_SPLITS: force the (blob, split) decomposition of the fixed-base MSM (power of two <= 64; 0 = automatic)
   uint64_t challenge_split_max = 0;  // KATETH_AMD_CHALLENGE_SPLIT_MAX: largest batch hashed by the two-wave SHA-256 kernel (0 = default)
 };
 EnvKnobs read_env_knobs();
@@ -54,7 +55,7 @@ struct TraceTimer {  // KATETH_AMD_TRACE=1: host-side wall-clock marks on stderr
   }
 };
 
-constexpr int KZG_STAGE_SLOTS = 16;   // x 512 blobs x 128 KiB = 1 GiB of staging at most
+constexpr int KZG_STAGE_SLOTS = 4;    // x up to 4,096 blobs x 128 KiB = 2 GiB of staging at most
 constexpr int KZG_STAGE_STREAMS = 4;  // per-chunk kernels rotate over these (a chunk's SHA-256 streams are latency-bound: several in flight)
 #define KZG_SESSION_STREAM (reinterpret_cast<hipStream_t>(static_cast<intptr_t>(-1)))  // session_acquire: run on the session's own stream
 enum ProfKind { PROF_MSM_FIXED = 0, PROF_CHALLENGE, PROF_EVAL, PROF_DECODE, PROF_POLY, PROF_VAR_MSM, PROF_REDUCE_COMPRESS, PROF_KINDS };

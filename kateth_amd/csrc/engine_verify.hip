@@ -503,7 +503,16 @@ static int32_t verify_phase1_host(const kzg_ctx* ctx, const uint8_t* blobs, cons
   kzg_verify_session* s = nullptr;
   rc = session_acquire(ctx, n, st, &s);
   if (rc) return rc;
-  const uint64_t chunk = ctx->knobs.verify_chunk ? ctx->knobs.verify_chunk : 512;
+  // Chunk size: the SHA-256 kernel of a chunk is latency-bound (~3.7 ms whether it hashes 512 or 16,384 blobs), so chunks
+  // are LARGE -- a quarter of the batch, between 512 and 4,096 blobs (512 MiB, ~9 ms of PCIe) -- and the copy of chunk k+1
+  // hides the hash + evaluation of chunk k (measured with 512-blob chunks on four streams: 63 ms per 16,384 blobs, the
+  // hashes of 32 chunks queue up four at a time; profiles/r02/hostapi_*.json).
+  uint64_t chunk = ctx->knobs.verify_chunk;
+  if (!chunk) {
+    chunk = (n + 3) / 4;
+    chunk = (chunk + 63) / 64 * 64;
+    chunk = chunk < 512 ? 512 : (chunk > 4096 ? 4096 : chunk);
+  }
   const uint64_t nchunks = (n + chunk - 1) / chunk;
   const uint64_t slots = nchunks < KZG_STAGE_SLOTS ? nchunks : KZG_STAGE_SLOTS;
   const size_t slot_bytes = (size_t)chunk * KZG_BYTES_PER_BLOB;
@@ -525,37 +534,47 @@ static int32_t verify_phase1_host(const kzg_ctx* ctx, const uint8_t* blobs, cons
       rc = fail(KZG_FAIL_HIP, "host-to-device copy failed");
       break;
     }
-    // all points decoded once, beside the chunk pipeline
-    (void)hipEventRecord(s->ev_fork, st);
-    (void)hipStreamWaitEvent(s->side, s->ev_fork, 0);
-    {
-      ProfScope ps(ctx, PROF_DECODE, s->side);
-      hipLaunchKernelGGL(k_g1_decompress, dim3(blocks_for(2 * n, 64)), dim3(64), 0, s->side, prf, n, s->stat + 2 * n, com, n, s->stat + n, s->aff,
-                         s->inf);
-    }
-    (void)hipEventRecord(s->ev_join, s->side);
-    for (int r = 0; r < KZG_STAGE_STREAMS; r++) (void)hipStreamWaitEvent(ctx->stage_streams[r], s->ev_fork, 0);  // session initialised, points resident
-    for (uint64_t k = 0; k < nchunks && rc == 0; k++) {
-      const uint64_t slot = k % slots;
-      const uint64_t base = k * chunk;
-      const uint64_t m = (n - base < chunk) ? (n - base) : chunk;
-      hipStream_t comp = ctx->stage_streams[k % KZG_STAGE_STREAMS];
-      uint8_t* d_chunk = ctx->stage + slot * slot_bytes;
-      if (k >= slots) (void)hipStreamWaitEvent(ctx->stage_copy_stream, ctx->stage_done[slot], 0);  // the chunk that used this slot has been consumed
-      if (hipMemcpyAsync(d_chunk, blobs + base * (size_t)KZG_BYTES_PER_BLOB, m * (size_t)KZG_BYTES_PER_BLOB, hipMemcpyHostToDevice,
-                         ctx->stage_copy_stream) != hipSuccess) {
+    if (nchunks == 1) {
+      // a single chunk (small batches, single items): nothing to overlap -- one copy, then the device path's launches
+      // (hash and point decoding fused in one launch: the latency-optimal shape)
+      if (hipMemcpyAsync(ctx->stage, blobs, n * (size_t)KZG_BYTES_PER_BLOB, hipMemcpyHostToDevice, st) != hipSuccess) {
         rc = fail(KZG_FAIL_HIP, "host-to-device copy failed");
         break;
       }
-      (void)hipEventRecord(ctx->stage_copied[slot], ctx->stage_copy_stream);
-      (void)hipStreamWaitEvent(comp, ctx->stage_copied[slot], 0);
-      rc = phase1_items(s, d_chunk, com, prf, base, m, comp, false);
-      (void)hipEventRecord(ctx->stage_done[slot], comp);
-    }
-    // join the compute streams into the session's stream
-    for (int r = 0; r < KZG_STAGE_STREAMS; r++) {
-      (void)hipEventRecord(ctx->stage_join[r], ctx->stage_streams[r]);
-      (void)hipStreamWaitEvent(st, ctx->stage_join[r], 0);
+      rc = phase1_items(s, ctx->stage, com, prf, 0, n, st, true);
+    } else {
+      // all points decoded once, beside the chunk pipeline
+      (void)hipEventRecord(s->ev_fork, st);
+      (void)hipStreamWaitEvent(s->side, s->ev_fork, 0);
+      {
+        ProfScope ps(ctx, PROF_DECODE, s->side);
+        hipLaunchKernelGGL(k_g1_decompress, dim3(blocks_for(2 * n, 64)), dim3(64), 0, s->side, prf, n, s->stat + 2 * n, com, n, s->stat + n, s->aff,
+                           s->inf);
+      }
+      (void)hipEventRecord(s->ev_join, s->side);
+      for (int r = 0; r < KZG_STAGE_STREAMS; r++) (void)hipStreamWaitEvent(ctx->stage_streams[r], s->ev_fork, 0);  // session initialised, points resident
+      for (uint64_t k = 0; k < nchunks && rc == 0; k++) {
+        const uint64_t slot = k % slots;
+        const uint64_t base = k * chunk;
+        const uint64_t m = (n - base < chunk) ? (n - base) : chunk;
+        hipStream_t comp = ctx->stage_streams[k % KZG_STAGE_STREAMS];
+        uint8_t* d_chunk = ctx->stage + slot * slot_bytes;
+        if (k >= slots) (void)hipStreamWaitEvent(ctx->stage_copy_stream, ctx->stage_done[slot], 0);  // the chunk that used this slot has been consumed
+        if (hipMemcpyAsync(d_chunk, blobs + base * (size_t)KZG_BYTES_PER_BLOB, m * (size_t)KZG_BYTES_PER_BLOB, hipMemcpyHostToDevice,
+                           ctx->stage_copy_stream) != hipSuccess) {
+          rc = fail(KZG_FAIL_HIP, "host-to-device copy failed");
+          break;
+        }
+        (void)hipEventRecord(ctx->stage_copied[slot], ctx->stage_copy_stream);
+        (void)hipStreamWaitEvent(comp, ctx->stage_copied[slot], 0);
+        rc = phase1_items(s, d_chunk, com, prf, base, m, comp, false);
+        (void)hipEventRecord(ctx->stage_done[slot], comp);
+      }
+      // join the compute streams into the session's stream
+      for (int r = 0; r < KZG_STAGE_STREAMS; r++) {
+        (void)hipEventRecord(ctx->stage_join[r], ctx->stage_streams[r]);
+        (void)hipStreamWaitEvent(st, ctx->stage_join[r], 0);
+      }
     }
     if (rc) break;
     tt.mark("enqueue copies + per-chunk kernels");

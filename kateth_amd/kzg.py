@@ -560,6 +560,17 @@ class Setup:
             raise _kzg_error(rc)
         return bool(ok.value)
 
+    def verify_blob_proof_batch_host(self, blobs, commitments, proofs, n: int) -> bool:
+        """kzg_verify_blob_proof_batch on n CONTIGUOUS items in host memory: bytes-like objects or raw host addresses
+        (ints, e.g. the data_ptr() of a pinned tensor -- pinned memory crosses PCIe at the full rate)."""
+        ok = ctypes.c_int32(0)
+        args = [a if isinstance(a, int) else _buf(a) for a in (blobs, commitments, proofs)]
+        rc = self._lib.kzg_verify_blob_proof_batch(self._h, args[0], args[1], args[2], n, ctypes.byref(ok))
+        self._check(rc, "kzg_verify_blob_proof_batch")
+        if rc > 0:
+            raise _kzg_error(rc)
+        return bool(ok.value)
+
     # -- device-resident entry points (raw HIP pointers, e.g. torch.Tensor.data_ptr()) ---
     def blob_to_commitment_batch_dev(self, d_blobs: int, n: int, d_out48: int, d_status: int, stream: int = 0):
         rc = self._lib.kzg_blob_to_commitment_batch_dev(self._h, d_blobs, n, d_out48, d_status, stream)

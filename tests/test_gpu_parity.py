@@ -879,7 +879,7 @@ def test_affine_outputs_are_the_compressed_points(engine, golden, oracle_setup):
 
 def test_host_buffer_verify_pipeline_matches_device_path(engine, torch_cuda):
     """kzg_verify_blob_proof_batch streams host blobs through the staging arena in chunks (copy of chunk k+1 beside the
-    hash + evaluation of chunk k, rotating compute streams, slot reuse beyond 16 chunks): same decisions and the same first
+    hash + evaluation of chunk k, rotating compute streams, slot reuse beyond 4 chunks): same decisions and the same first
     error as the device-pointer entry point, ragged last chunk included; with a tiny chunk size the slot-reuse path runs."""
     import kateth_amd
 
@@ -898,7 +898,7 @@ def test_host_buffer_verify_pipeline_matches_device_path(engine, torch_cuda):
     blobs = [hb[i * 131072:(i + 1) * 131072] for i in range(n)]
     cs = [hc[i * 48:(i + 1) * 48] for i in range(n)]
     ps = [hp[i * 48:(i + 1) * 48] for i in range(n)]
-    small = _engine_with_env_plain({"KATETH_AMD_VERIFY_CHUNK": "37"})  # 31 chunks: more than the 16 staging slots
+    small = _engine_with_env_plain({"KATETH_AMD_VERIFY_CHUNK": "37"})  # 31 chunks: more than the 4 staging slots
     try:
         for e in (engine, small):
             for m in (n, 512, 513, 1):

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Host-buffer (PCIe-inclusive) throughput of the batch entry points: the caller's blobs live in host memory, as in
-kateth's byte-slice API; every call allocates, copies in, computes, copies out."""
+kateth's byte-slice API.  Pageable memory (a Python bytes object) and pinned memory (torch pin_memory) are both timed;
+the device-resident rate of the same batch is printed beside them.  usage: gpu_hostapi_bench.py [n] [window_bits]"""
+import ctypes
 import json
 import os
 import sys
@@ -23,8 +25,15 @@ s.synth_blobs_dev(0x4844, 0, n, d_blobs.data_ptr())
 s.blob_to_commitment_batch_dev(d_blobs.data_ptr(), n, d_c.data_ptr(), d_st.data_ptr())
 s.compute_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), n, d_p.data_ptr(), d_st.data_ptr())
 torch.cuda.synchronize()
-blobs = d_blobs.cpu().numpy().tobytes()
-cs, ps = d_c.cpu().numpy().tobytes(), d_p.cpu().numpy().tobytes()
+pin_b = torch.empty(n * 131072, dtype=torch.uint8, pin_memory=True)
+pin_c = torch.empty(n * 48, dtype=torch.uint8, pin_memory=True)
+pin_p = torch.empty(n * 48, dtype=torch.uint8, pin_memory=True)
+pin_b.copy_(d_blobs)
+pin_c.copy_(d_c)
+pin_p.copy_(d_p)
+torch.cuda.synchronize()
+blobs = pin_b.numpy().tobytes()  # pageable copies
+cs, ps = pin_c.numpy().tobytes(), pin_p.numpy().tobytes()
 out = {"n": n, "window_bits": c}
 
 
@@ -36,20 +45,35 @@ def timed(fn, reps=3):
     return (time.perf_counter() - t0) / reps
 
 
-t = timed(lambda: s.blob_to_commitment_batch(blobs, n))
-out["commit_host_ms"], out["commit_host_blobs_per_s"] = 1e3 * t, n / t
-t = timed(lambda: (s.blob_to_commitment_batch_dev(d_blobs.data_ptr(), n, d_c.data_ptr(), d_st.data_ptr()), torch.cuda.synchronize()))
-out["commit_dev_ms"], out["commit_dev_blobs_per_s"] = 1e3 * t, n / t
+def rec(name, t):
+    out[name + "_ms"], out[name + "_blobs_per_s"] = 1e3 * t, n / t
+
+
+rec("commit_host_pageable", timed(lambda: s.blob_to_commitment_batch(blobs, n)))
+rec("commit_dev", timed(lambda: (s.blob_to_commitment_batch_dev(d_blobs.data_ptr(), n, d_c.data_ptr(), d_st.data_ptr()), torch.cuda.synchronize())))
 got, st = s.blob_to_commitment_batch(blobs, n)
 assert got == cs and not any(st)
-t = timed(lambda: s.compute_blob_proof_batch(blobs, cs))
-out["proof_host_ms"], out["proof_host_blobs_per_s"] = 1e3 * t, n / t
-bl = [blobs[i * 131072:(i + 1) * 131072] for i in range(n)]
-cl = [cs[i * 48:(i + 1) * 48] for i in range(n)]
-pl = [ps[i * 48:(i + 1) * 48] for i in range(n)]
-t = timed(lambda: s.verify_blob_proof_batch(bl, cl, pl))
-out["verify_host_ms"], out["verify_host_blobs_per_s"] = 1e3 * t, n / t
-t = timed(lambda: s.verify_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n))
-out["verify_dev_ms"], out["verify_dev_blobs_per_s"] = 1e3 * t, n / t
+rec("proof_host_pageable", timed(lambda: s.compute_blob_proof_batch(blobs, cs)))
+rec("proof_dev", timed(lambda: (s.compute_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), n, d_p.data_ptr(), d_st.data_ptr()), torch.cuda.synchronize())))
+assert s.verify_blob_proof_batch_host(blobs, cs, ps, n) is True
+assert s.verify_blob_proof_batch_host(pin_b.data_ptr(), pin_c.data_ptr(), pin_p.data_ptr(), n) is True
+rec("verify_host_pageable", timed(lambda: s.verify_blob_proof_batch_host(blobs, cs, ps, n)))
+rec("verify_host_pinned", timed(lambda: s.verify_blob_proof_batch_host(pin_b.data_ptr(), pin_c.data_ptr(), pin_p.data_ptr(), n)))
+rec("verify_dev", timed(lambda: s.verify_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n)))
+# raw copy rates for reference
+t = timed(lambda: (d_blobs.copy_(pin_b, non_blocking=True), torch.cuda.synchronize()))
+out["h2d_pinned_GBps"] = n * 131072 / t / 1e9
+src = torch.frombuffer(bytearray(blobs), dtype=torch.uint8)
+t = timed(lambda: (d_blobs.copy_(src), torch.cuda.synchronize()))
+out["h2d_pageable_GBps"] = n * 131072 / t / 1e9
+# single-item host API latencies
+one_b, one_c, one_p = blobs[:131072], cs[:48], ps[:48]
+for name, fn in (("single_commit_ms", lambda: s.blob_to_commitment(one_b)), ("single_proof_ms", lambda: s.blob_proof(one_b, one_c)),
+                 ("single_verify_blob_ms", lambda: s.verify_blob_proof(one_b, one_c, one_p))):
+    fn()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        fn()
+    out[name] = 1e3 * (time.perf_counter() - t0) / 10
 print(json.dumps(out))
 s.close()
