@@ -1092,3 +1092,28 @@ def test_load_setup_rejects_bad_points_with_the_reference_error():
     with pytest.raises(kateth_amd.LoadSetupError, match="ECGroupError::InvalidEncoding") as e:
         kateth_amd.Setup.from_bytes(g1, q, window_bits=6)
     assert "g2_monomial[3]" in str(e.value)
+
+
+@pytest.mark.parametrize("workload", ["commit", "verify"])
+def test_bench_rank_launcher_two_real_engine_ranks_on_one_card(workload):
+    """`python bench.py --gpus 2` starts two rank processes itself (before anything in the launcher touches HIP); here they
+    share the one card and exchange through gloo (RCCL needs a GPU per rank): the REAL engine in every rank -- blob-sharded
+    commitments all-gathered in rank order, and batch verification through dist.verify_blob_proof_batch_sharded (roots +
+    first-error records gathered, global indices for r^i, partial sums gathered, one pairing)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--workload", workload, "--batch", "96", "--window-bits", "8",
+           "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extra"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    rec = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0
+    assert rec["config"]["blobs_per_gpu"] == 96 and rec["config"]["backend"] == "gloo"
+    assert rec["roofline"]["kernel"] == ("k_msm_fixed28" if workload == "commit" else "k_challenge*")
+    # a rendezvous that disagrees with --gpus must fail loudly instead of silently running one rank
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], capture_output=True, text=True, timeout=120,
+                         env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
+    assert bad.returncode != 0 and "WORLD_SIZE=2" in (bad.stdout + bad.stderr)

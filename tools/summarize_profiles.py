@@ -18,8 +18,9 @@ def short(name):
 
 
 def main(out):
-    for f in glob.glob(os.path.join(out, "trace_default", "**", "*kernel_stats.csv"), recursive=True):
-        shutil.copy(f, os.path.join(out, "summary_trace_default_kernel_stats.csv"))
+    for name in ("trace_default", "trace_commit", "trace_proof", "trace_verify"):
+        for f in glob.glob(os.path.join(out, name, "**", "*kernel_stats.csv"), recursive=True):
+            shutil.copy(f, os.path.join(out, "summary_%s_kernel_stats.csv" % name))
     summary = {}
     for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
         if not os.path.isdir(d):
