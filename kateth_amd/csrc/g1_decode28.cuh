@@ -4,8 +4,8 @@
 // implementation that tests/test_hostmath.py compares this one against.
 //
 // Cost per point: square root a^((p+1)/4) by a width-3 sliding window (378 squarings + 108 products; a squaring is
-// 105 + 196 v_mad_u64_u32), subgroup test phi(P) == -[z^2]P with XYZZ doublings that share one reduction between the
-// two products of Y3 -- about 0.75 M VALU instructions against 1.3 M for the 12 x 32-bit-limb path.
+// 105 + 196 v_mad_u64_u32), subgroup test phi(P) == -[z^2]P by a Jacobian ladder over z^2 (127 doublings of 4 S + 3 M and
+// 16 mixed additions of the affine input) -- about 0.65 M VALU instructions against 1.3 M for the 12 x 32-bit-limb path.
 #pragma once
 #include "fp28.cuh"
 
@@ -20,6 +20,8 @@ KZG_F28_TABLE(f28_r2_limb, KZG_FP28_R2)
 KZG_F28_TABLE(f28_b_limb, KZG_FP28_B)
 KZG_F28_TABLE(f28_beta_limb, KZG_FP28_BETA)
 KZG_F28_TABLE(f28_r400_limb, KZG_FP28_R400)
+KZG_F28_TABLE(f28_24p_t8, KZG_FP28_24P_T8)
+KZG_F28_TABLE(f28_32p_t1, KZG_FP28_32P_T1)
 #undef KZG_F28_TABLE
 
 
@@ -132,43 +134,151 @@ KZG_HD_NOINLINE void g1_compress_xyzz28(uint8_t* out48, uint32_t* out_affine24, 
   if (fp_is_lex_larger_plain(yp)) out48[0] |= 0x20;
 }
 
-// out = [|z|] base, |z| = 0xd201000000010000 (the BLS12-381 parameter); base finite or infinity
-KZG_HD_NOINLINE void g1_mul_by_z28(g1_xyzz28& out, const g1_xyzz28& base) {
-  const uint64_t zabs = 0xd201000000010000ull;
-  g1_xyzz28 acc = base;
+// ---- Jacobian ladder for the subgroup test ----------------------------------------------------------------------------
+// 126 of the ~600 k v_mad_u64_u32 of a point decoding were XYZZ doublings (3 S + 4 M + a double product = 3,059 mads
+// each); in Jacobian coordinates a doubling on y^2 = x^3 + 4 is 4 S + 3 M = 2,380 (dbl-2009-l with D = 4 X1 B as a
+// product), needs no special case (the group order is odd: no point has Y = 0), and the ladder adds the AFFINE input
+// point, so no general addition is needed: [z^2]P by one 127-step ladder over z^2 (Hamming weight 17).
+// Invariant of the accumulator:  x: limbs <= 2^28 + 16, value < 26p;  y: limbs <= 2^28 + 16, value < 30p;
+// z: limbs < 2^29, value < 4p.  Every bound below is re-checked at run time in the CPU test build (KZG_FP28_CHECK).
+struct g1_jac28 {
+  fp28 x, y, z;
+  uint32_t inf;
+};
+
+// p = 2p   (A = X^2, B = Y^2, U = X B, C = B^2, E = 3A, F = E^2, X3 = F - 8U, Y3 = 3 A (4U - X3) - 8C, Z3 = 2 Y Z)
+KZG_HD void jac28_dbl(g1_jac28& p) {
+  if (p.inf) return;
+  fp28 A, B, C, U, E, T;
+  f28_sqr(A, p.x);        // 14 * (2^28+16)^2 ; 26^2 = 676 < 2^11
+  f28_sqr(B, p.y);        // 30^2 = 900
+  f28_mul(U, p.x, B);     // 26 * 2
+  f28_sqr(C, B);
+  KZG_UNROLL_FULL
+  for (int i = 0; i < F28_N; i++) E.l[i] = 3u * A.l[i];  // limbs < 3*2^28, value < 6p
+  f28_sqr(E, E);          // F: 14 * 9 * 2^56 ; 36
+  KZG_UNROLL_FULL
+  for (int i = 0; i < F28_N; i++) {
+    const uint32_t s = 8u * U.l[i];                       // limbs <= 8 (2^28 - 1), value < 16p
+    F28_SUBCHK(E.l[i], f28_24p_t8(i), s);
+    p.x.l[i] = E.l[i] + f28_24p_t8(i) - s;                // X3 = F - 8U: limbs < 10*2^28, value < 26p
+  }
+  f28_carry_pass(p.x);    // limbs <= 2^28 + 9
+  KZG_UNROLL_FULL
+  for (int i = 0; i < F28_N; i++) {
+    F28_SUBCHK(4u * U.l[i], f28_32p_t1(i), p.x.l[i]);
+    T.l[i] = 4u * U.l[i] + f28_32p_t1(i) - p.x.l[i];      // 4U - X3: limbs < 2^30 + 2^29, value < 40p
+  }
+  f28_mul(T, A, T);       // 14 * 2^28 * 1.5 * 2^30 = 2^62.4 ; 2 * 40
+  f28_mul(U, p.y, p.z);   // Y Z (old Y): 14 * (2^28+16) * 2^29 ; 30 * 4
+  KZG_UNROLL_FULL
+  for (int i = 0; i < F28_N; i++) {
+    const uint32_t s = 8u * C.l[i];
+    F28_SUBCHK(3u * T.l[i], f28_24p_t8(i), s);
+    p.y.l[i] = 3u * T.l[i] + f28_24p_t8(i) - s;           // Y3: limbs < 12*2^28, value < 30p
+    p.z.l[i] = 2u * U.l[i];                               // Z3: limbs < 2^29, value < 4p
+  }
+  f28_carry_pass(p.y);    // limbs <= 2^28 + 11
+}
+
+// p += (x2, y2), an affine point in N-form; complete (identity, P + P, P + (-P)).
+// U2 = x2 Z^2, S2 = y2 Z^3, H = U2 - X, r = S2 - Y, X3 = r^2 - H^3 - 2 X H^2, Y3 = r (X H^2 - X3) - Y H^3, Z3 = Z H.
+KZG_HD_NOINLINE void jac28_madd(g1_jac28& p, const fp28& x2, const fp28& y2) {
+  if (p.inf) {
+    p.x = x2;
+    p.y = y2;
+    p.z = f28_one();
+    p.inf = 0;
+    return;
+  }
+  fp28 zz, zzz, h, r, hh, hhh, v, t;
+  f28_sqr(zz, p.z);        // 14 * 2^58 ; 16
+  f28_mul(zzz, p.z, zz);   // 8
+  f28_mul(h, x2, zz);      // U2
+  f28_mul(r, y2, zzz);     // S2
+  KZG_UNROLL_FULL
+  for (int i = 0; i < F28_N; i++) {
+    F28_SUBCHK(h.l[i], f28_32p_t1(i), p.x.l[i]);
+    F28_SUBCHK(r.l[i], f28_32p_t1(i), p.y.l[i]);
+    h.l[i] = h.l[i] + f28_32p_t1(i) - p.x.l[i];  // H: limbs < 3*2^28, value < 34p
+    r.l[i] = r.l[i] + f28_32p_t1(i) - p.y.l[i];  // r
+  }
+  if (f28_is_zero(h)) {
+    if (f28_is_zero(r)) {  // the same point: double it
+      g1_jac28 q;
+      q.x = x2;
+      q.y = y2;
+      q.z = f28_one();
+      q.inf = 0;
+      jac28_dbl(q);
+      p = q;
+    } else {
+      p.inf = 1;
+    }
+    return;
+  }
+  f28_sqr(hh, h);          // 14 * 9 * 2^56 ; 34^2 = 1156 < 2^11
+  f28_mul(hhh, h, hh);     // 68
+  f28_mul(v, p.x, hh);     // X H^2: 52
+  f28_sqr(t, r);           // 1156
+  f28_mul(zz, p.z, h);     // Z3: 14 * 2^29 * 3 * 2^28 ; 4 * 34   (zz reused)
+  KZG_UNROLL_FULL
+  for (int i = 0; i < F28_N; i++) {
+    const uint32_t s = hhh.l[i] + 2u * v.l[i];   // limbs <= 3 (2^28 - 1), value < 6p
+    F28_SUBCHK(t.l[i], f28_8p_t3(i), s);
+    p.x.l[i] = t.l[i] + f28_8p_t3(i) - s;        // X3: limbs < 5*2^28, value < 10p
+  }
+  f28_carry_pass(p.x);     // limbs <= 2^28 + 4
+  f28_sub_16p(v, v, p.x);  // X H^2 - X3: limbs < 3*2^28, value < 18p
+  KZG_UNROLL_FULL
+  for (int i = 0; i < F28_N; i++) {
+    F28_SUBCHK(0u, f28_32p_t1(i), p.y.l[i]);
+    t.l[i] = f28_32p_t1(i) - p.y.l[i];           // -Y: limbs < 2^29, value <= 32p
+  }
+  f28_mul2(p.y, r, v, t, hhh);  // 14 * (9 * 2^56 + 2^57) ; 34 * 18 + 32 * 2 = 676
+  p.z = zz;
+}
+
+// [z^2]P for the affine point (x, y) (N-form), z the BLS12-381 parameter: z^2 = 0xac45a4010001a4020000000100000000
+KZG_HD_NOINLINE void g1_mul_by_z2_jac28(g1_jac28& acc, const fp28& x, const fp28& y) {
+  const uint64_t hi = 0xac45a4010001a402ull, lo = 0x0000000100000000ull;
+  acc.x = x;
+  acc.y = y;
+  acc.z = f28_one();
+  acc.inf = 0;
 #pragma unroll 1
-  for (int i = 62; i >= 0; i--) {
-    xyzz28_dbl_inl(acc);  // inline: the accumulator stays in registers over the runs of doublings (126 of them per point)
-    if ((zabs >> i) & 1ull) {
-      g1_xyzz28 mine = acc;  // copy: the out-of-line adder takes addresses
-      xyzz28_add_complete(mine, base);
+  for (int i = 126; i >= 0; i--) {
+    jac28_dbl(acc);  // inline: the accumulator stays in registers over the runs of doublings
+    const uint64_t w = i >= 64 ? hi : lo;
+    if ((w >> (i & 63)) & 1ull) {
+      g1_jac28 mine = acc;  // copy: the out-of-line adder takes addresses
+      jac28_madd(mine, x, y);
       acc = mine;
     }
   }
-  out = acc;
 }
 
 // blst_p1_affine_in_g1 via the endomorphism (see g1_in_subgroup in g1.cuh for the argument):
 // (x, y) in G1  <=>  (beta x, y) == -[z^2](x, y).   x, y: 2^392-Montgomery N-form.
 KZG_HD_NOINLINE bool g1_in_subgroup28(const fp28& x, const fp28& y) {
-  g1_xyzz28 p, q1, q2;
-  p.x = x;
-  p.y = y;
-  p.zz = f28_one();
-  p.zzz = p.zz;
-  p.inf = 0;
-  g1_mul_by_z28(q1, p);
-  g1_mul_by_z28(q2, q1);  // [z^2]P
-  if (q2.inf) return false;
-  fp28 beta, t;
+  g1_jac28 q;
+  g1_mul_by_z2_jac28(q, x, y);
+  if (q.inf) return false;
+  fp28 beta, zz, t;
   KZG_UNROLL_FULL
   for (int i = 0; i < F28_N; i++) beta.l[i] = f28_beta_limb(i);
+  f28_sqr(zz, q.z);
   f28_mul(t, x, beta);
-  f28_mul(t, t, q2.zz);
-  f28_sub_16p(t, t, q2.x);  // beta x ZZ - X
+  f28_mul(t, t, zz);
+  KZG_UNROLL_FULL
+  for (int i = 0; i < F28_N; i++) {
+    F28_SUBCHK(t.l[i], f28_32p_t1(i), q.x.l[i]);
+    t.l[i] = t.l[i] + f28_32p_t1(i) - q.x.l[i];  // beta x Z^2 - X: value < 34p
+  }
   if (!f28_is_zero(t)) return false;
-  f28_mul(t, y, q2.zzz);
-  f28_add(t, t, q2.y);      // y ZZZ + Y
+  f28_mul(zz, q.z, zz);    // Z^3
+  f28_mul(t, y, zz);
+  f28_add(t, t, q.y);      // y Z^3 + Y: value < 32p
   return f28_is_zero(t);
 }
 

@@ -383,6 +383,30 @@ def test_g1_decompress_radix28_matches_reference_path(hm):
             s = bls.g1_mul_unreduced(t, f)
             if s is not None:
                 assert both(bls.g1_compress(s)) == 5
+    # random x: whatever class each falls in (not on curve / outside the subgroup), both decoders must agree
+    for _ in range(300):
+        xr = rnd.randrange(P)
+        code = both(bytes([0x80 | (xr >> 376) | (0x20 if rnd.random() < 0.5 else 0)]) + (xr & ((1 << 376) - 1)).to_bytes(47, "big"))
+        assert code in (4, 5)
+    # points of SMALL prime order q | h (h = 3 * 11^2 * 10177^2 * 859267^2 * 52437899^2): the ladder meets P + P, P + (-P)
+    # and the identity accumulator (order 3: [2]P = -P)
+    h = 0x396C8C005555E1568C00AAAB0000AAAB
+    assert h == 3 * 11**2 * 10177**2 * 859267**2 * 52437899**2
+    seen = set()
+    x = 5
+    while len(seen) < 3 and x < 60:
+        y = bls._fp_sqrt(x**3 + 4)
+        if y is not None and not bls.g1_in_subgroup((x, y)):
+            cof = bls.g1_mul_unreduced((x, y), R)
+            for q in (3, 11, 10177):
+                s_q = bls.g1_mul_unreduced(cof, h // q) if cof is not None else None
+                if s_q is not None:
+                    assert bls.g1_mul_unreduced(s_q, q) is None  # order exactly q
+                    assert both(bls.g1_compress(s_q)) == 5
+                    assert both(bls.g1_compress(bls.g1_neg(s_q))) == 5
+                    seen.add(q)
+        x += 1
+    assert 3 in seen
     assert hm.hm_f28_violations() == 0
 
 
