@@ -3,10 +3,16 @@ reference's own vector layout -- tests/general/deneb/kzg/<handler>/kzg-mainnet/<
 (src/kzg/setup.rs:305-317) with the shapes of src/kzg/spec.rs:20-220 and its
 null-output convention (src/kzg/setup.rs:330-337: malformed input or Err => output must be null).
 
-The vectors are an empty submodule in the reference checkout, so these tests skip
-until a directory is supplied:  KZG_SPEC_TESTS=/path/to/consensus-spec-tests .
-They run against the GPU engine (-m gpu) and, without a GPU, against the CPU oracle."""
+Two vector sets, same layout:
+  * "official": the reference's submodule -- EMPTY in the reference checkout, so these skip until a directory is supplied
+    (KZG_SPEC_TESTS=/path/to/consensus-spec-tests, or tests/golden/consensus-spec-tests);
+  * "generated": tests/golden/spec-layout-vectors -- 114 cases in the official suite's categories (valid inputs, every class
+    of invalid input, wrong lengths, length mismatches, the empty batch) whose outputs were produced by oracle/pyref
+    (tests/golden/make_spec_layout_vectors.py).  They are not the official vectors; they make the runner -- and the
+    engine behind kateth's six functions -- run end to end in that layout.
+They run against the GPU engine (-m gpu) and, without a GPU, against the CPU oracle (a sample: the oracle made them)."""
 import glob
+import gzip
 import os
 
 import pytest
@@ -14,12 +20,22 @@ import yaml
 
 from conftest import TRUSTED_SETUP
 
-SPEC_ROOT = os.environ.get("KZG_SPEC_TESTS", os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "consensus-spec-tests"))
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOTS = {
+    "official": os.environ.get("KZG_SPEC_TESTS", os.path.join(HERE, "golden", "consensus-spec-tests")),
+    "generated": os.path.join(HERE, "golden", "spec-layout-vectors"),
+}
 HANDLERS = ["blob_to_kzg_commitment", "compute_kzg_proof", "compute_blob_kzg_proof", "verify_kzg_proof", "verify_blob_kzg_proof", "verify_blob_kzg_proof_batch"]
 
 
-def cases(handler):
-    return sorted(glob.glob(os.path.join(SPEC_ROOT, "tests", "general", "deneb", "kzg", handler, "kzg-mainnet", "*", "data.yaml")))
+def cases(handler, which="official"):
+    base = os.path.join(ROOTS[which], "tests", "general", "deneb", "kzg", handler, "kzg-mainnet", "*")
+    return sorted(glob.glob(os.path.join(base, "data.yaml")) + glob.glob(os.path.join(base, "data.yaml.gz")))
+
+
+def load_case(path):
+    with (gzip.open(path, "rb") if path.endswith(".gz") else open(path, "rb")) as fh:
+        return yaml.safe_load(fh)
 
 
 def unhex(s):
@@ -97,35 +113,55 @@ class OracleApi:
         return self.s.verify_blob_proof_batch(blobs, cs, ps)
 
 
-def _check(api, handler):
-    files = cases(handler)
+def _check(api, handler, which, sample=False):
+    files = cases(handler, which)
     if not files:
         pytest.skip("consensus-spec-tests vectors not present (empty submodule in the reference checkout); set KZG_SPEC_TESTS")
+    ran = 0
     for f in files:
-        data = yaml.safe_load(open(f))
+        data = load_case(f)
+        if sample and data["output"] is not None and ran >= 2 and "0_blobs" not in f:
+            continue  # CPU oracle pass: every null-output case, two computed ones per handler
+        ran += data["output"] is not None
         got = run_case(api, handler, data)
         assert got == data["output"], f
+    return len(files)
 
 
 @pytest.mark.parametrize("handler", HANDLERS)
-def test_spec_vectors_oracle(handler):
-    if not cases(handler):
+@pytest.mark.parametrize("which", ["official", "generated"])
+def test_spec_vectors_oracle(handler, which):
+    if not cases(handler, which):
         pytest.skip("consensus-spec-tests vectors not present; set KZG_SPEC_TESTS")
-    _check(OracleApi(), handler)
+    _check(OracleApi(), handler, which, sample=(which == "generated"))
+
+
+@pytest.fixture(scope="module")
+def gpu_engine():
+    import kateth_amd
+
+    s = kateth_amd.Setup.load_json(TRUSTED_SETUP, window_bits=8)
+    yield s
+    s.close()
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("handler", HANDLERS)
-def test_spec_vectors_gpu(handler):
-    if not cases(handler):
+@pytest.mark.parametrize("which", ["official", "generated"])
+def test_spec_vectors_gpu(handler, which, gpu_engine):
+    if not cases(handler, which):
         pytest.skip("consensus-spec-tests vectors not present; set KZG_SPEC_TESTS")
-    import kateth_amd
+    assert _check(gpu_engine, handler, which) >= 1
 
-    s = kateth_amd.Setup.load_json(TRUSTED_SETUP, window_bits=8)
-    try:
-        _check(s, handler)
-    finally:
-        s.close()
+
+def test_generated_set_covers_every_handler_and_null_convention():
+    total = 0
+    for h in HANDLERS:
+        files = cases(h, "generated")
+        outs = [load_case(f)["output"] for f in files]
+        assert any(o is None for o in outs) and any(o is not None for o in outs), h
+        total += len(files)
+    assert total >= 100
 
 
 def test_runner_handles_reference_yaml_shapes(tmp_path, oracle_setup):
