@@ -84,14 +84,37 @@ def launch_ranks(args):
                     "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
         out = subprocess.PIPE if rank == 0 else subprocess.DEVNULL
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out))
-    text, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(text.decode())
+    # relay rank 0's stdout; if ANY rank dies, stop the others (their collectives would otherwise wait for the timeout)
+    import threading
+
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    codes = [None] * len(procs)
+    while any(c is None for c in codes):
+        for k, p in enumerate(procs):
+            if codes[k] is None:
+                codes[k] = p.poll()
+        if any(c not in (None, 0) for c in codes):
+            for k, p in enumerate(procs):
+                if codes[k] is None:
+                    p.terminate()  # exactly the PIDs started above
+            for k, p in enumerate(procs):
+                if codes[k] is None:
+                    try:
+                        codes[k] = p.wait(timeout=20)
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                        codes[k] = p.wait()
+            break
+        time.sleep(0.05)
+    reader.join(timeout=10)
+    sys.stdout.write(b"".join(chunks).decode())
     sys.stdout.flush()
     bad = [c for c in codes if c != 0]
     if bad:
         sys.stderr.write("bench.py launcher: rank exit codes %r\n" % codes)
-        sys.exit(bad[0] if bad[0] > 0 else 1)
+        sys.exit(bad[0] if bad[0] and bad[0] > 0 else 1)
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -15,15 +15,24 @@ HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostmath")
 P, R = bls.P, bls.R
 
 
-@pytest.fixture(scope="module")
-def hm():
-    so = os.path.join(HERE, "libhostmath.so")
+def _build(so, extra):
     src = os.path.join(HERE, "shim.cpp")
     hdr_dir = os.path.join(os.path.dirname(HERE), "..", "kateth_amd", "csrc")
-    newest = max(os.path.getmtime(os.path.join(hdr_dir, f)) for f in os.listdir(hdr_dir) if f.endswith(".cuh"))
+    newest = max(os.path.getmtime(os.path.join(hdr_dir, f)) for f in os.listdir(hdr_dir) if f.endswith((".cuh", ".hpp")))
     if not os.path.exists(so) or os.path.getmtime(so) < max(newest, os.path.getmtime(src)):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", src, "-o", so])
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC"] + extra + [src, "-o", so])
     return ctypes.CDLL(so)
+
+
+@pytest.fixture(scope="module", params=["plain", "ubsan"])
+def hm(request):
+    """the host build of the device math, twice: plain, and under UndefinedBehaviorSanitizer (-fno-sanitize-recover: any
+    shift / overflow / alignment / bounds UB in the single-source headers aborts the test process).  GPU sanitizers are
+    not available on the pool; this is the CPU-side run."""
+    if request.param == "plain":
+        return _build(os.path.join(HERE, "libhostmath.so"), [])
+    return _build(os.path.join(HERE, "libhostmath_ubsan.so"),
+                  ["-g", "-fsanitize=undefined,bounds-strict,float-cast-overflow", "-fno-sanitize=vptr", "-fno-sanitize-recover=all", "-static-libubsan"])
 
 
 def _op(lib, fn, op, a, b, nbytes):
