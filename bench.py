@@ -57,8 +57,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", choices=("commit", "proof", "verify"), default="commit")
     ap.add_argument("--batch", type=int, default=0, help="blobs per GPU per step (default: 4096 commit/proof, 65536 verify; configs[4]: 131072 with --gpus 8)")
-    ap.add_argument("--window-bits", type=int, default=int(os.environ.get("KATETH_AMD_WINDOW_BITS", "16")),
-                    help="fixed-base window c (table: c=16 -> 192 GiB of the 288 GB HBM; c=15 -> 102 GiB; c=14 -> 54 GiB, the library default; c=12 -> 16 GiB); falls back to smaller windows if the table cannot be allocated")
+    ap.add_argument("--window-bits", type=int, default=int(os.environ.get("KATETH_AMD_WINDOW_BITS", "22")),
+                    help="index bits per lookup of the fixed-base comb table (22 -> blocks of 22+21+21 points, 103 GB of the 288 GB HBM, 49,152 additions per blob; 16 -> 3.2 GB, 65,536 additions: the library default; 8 -> 25 MB); falls back to smaller classes if the table cannot be allocated")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL, the measured path) or gloo (rehearsal: ranks may share one card, gathers go through the host)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary proof/verify workloads")
@@ -214,7 +214,7 @@ class Rank:
         self.setup_path = os.path.join(ROOT, "tests", "golden", "trusted_setup_4096.json")
         t0 = time.time()
         self.setup, tried = None, []
-        for c in [args.window_bits] + [w for w in (15, 14, 12) if w < args.window_bits]:
+        for c in [args.window_bits] + [w for w in (16, 8) if w < args.window_bits]:
             try:  # the table is sized for 288 GB of HBM; step down if this device cannot hold it
                 self.setup = kateth_amd.Setup.load_json(self.setup_path, device=self.local_dev, window_bits=c)
                 break
@@ -448,6 +448,7 @@ def run_rank(args, rank, local_rank, world):
     if rank == 0:
         roof = roofline_object(wl, n, prof, setup.window_bits)
         if wl in ("commit", "proof") and roof and prof["msm_launches"]:
+            roof["kernel"] = setup.msm_kernel_name
             # measured integer-ALU ceiling: dependent Fp Montgomery multiplies with the multiply of the MSM kernel
             # (radix-2^28 limbs), 8 waves/SIMD, whole chip.  DESIGN.md section 5 gives the instruction counts.
             lanes = 256 * 4 * 64 * 8
@@ -455,6 +456,7 @@ def run_rank(args, rank, local_rank, world):
             peak = lanes * 2000 / (setup.microbench_fp_mul(lanes, 2000) * 1e-3)
             msm_ms = prof["msm_ms"] / prof["msm_launches"]
             blobs_per_launch = n * args.steps / prof["msm_launches"]
+            roof["adds_per_blob"] = prof["adds_per_blob"]
             roof["table_gather_bytes_per_blob"] = prof["adds_per_blob"] * 96
             # multiply-equivalents per mixed add, weighted by v_mad_u64_u32 count: 6 products + 2 squarings (301/392 each)
             # + 2 products sharing one reduction (588/392) = 9.04

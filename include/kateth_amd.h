@@ -61,9 +61,14 @@ typedef struct kzg_ctx kzg_ctx;
 
 typedef struct kzg_config {
   int32_t device;      /* HIP device ordinal this context lives on */
-  int32_t window_bits; /* fixed-base MSM window c in [4,16]; 0 = default.  Table = 4096 * ceil(256/c) * 2^(c-1) * 96 B of HBM */
+  int32_t window_bits; /* index bits per lookup of the fixed-base MSM table, 4..22; 0 = default (16).  The table is a subset-sum
+                        * comb over blocks of t consecutive Lagrange points (msm_comb.cuh): t = 22 -> 103 GB and 49,152 additions
+                        * per blob; 16..21 -> blocks of 16, 3.2 GB, 65,536 additions; 8..15 -> blocks of 8 (25 MB); 4..7 -> blocks
+                        * of 4.  kzg_ctx_window_bits reports the class in use (22, 16, 8 or 4) */
   int32_t flags;       /* reserved, must be 0 */
-  int32_t reserved;
+  int32_t reserved;    /* plane groups G of the comb (tables; 1, 2, 4, 8 or 16); 0 = automatic: 16 for the small classes, 8 for
+                        * class 22 when the device has room for 192 GiB, else 4.  Table = G * 64 * e * 96 B with e = 2^22 (class 22),
+                        * 4 * 2^15 (16), 8 * 2^7 (8), 16 * 2^3 (4); a lane doubles its accumulator 256/G - 1 times per blob */
 } kzg_config;
 
 /* Thread-local text for the last negative return on this thread ("" if none). */
@@ -85,6 +90,8 @@ void kzg_ctx_destroy(kzg_ctx* ctx);
 
 /* introspection for benches / tests */
 int32_t kzg_ctx_window_bits(const kzg_ctx* ctx);
+const char* kzg_ctx_msm_kernel_name(const kzg_ctx* ctx); /* the dominant kernel bench.py names in `roofline` */
+int32_t kzg_ctx_plane_groups(const kzg_ctx* ctx);
 uint64_t kzg_ctx_table_bytes(const kzg_ctx* ctx);
 
 /*
@@ -217,7 +224,7 @@ int32_t kzg_profile_end(const kzg_ctx* ctx, double* msm_ms_total, uint64_t* msm_
  * the class: the fixed-base MSM, the SHA-256 challenge, the barycentric evaluation, point decoding, the quotient
  * kernel, the variable-base MSMs of batch verification, lane-sum trees + encoding).  Ends the profiling interval.
  */
-#define KZG_PROF_KINDS 7
+#define KZG_PROF_KINDS 8
 int32_t kzg_profile_end_kinds(const kzg_ctx* ctx, double* ms, uint64_t* launches);
 const char* kzg_profile_kind_name(int32_t kind);
 /* mixed additions the fixed-base MSM performs per blob: ceil(256/c) * 4096 */

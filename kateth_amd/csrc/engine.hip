@@ -74,14 +74,29 @@ static MsmGeom make_geom(uint32_t c) {
 
 uint32_t choose_splits(const kzg_ctx* ctx, uint64_t n) {
   // aim for >= 4 waves per SIMD-slot-pair across the chip; splits is a power of two <= 64
-  if (ctx->knobs.msm_splits) return ctx->knobs.msm_splits;
   const uint64_t target = (uint64_t)ctx->num_cus * 8;
+  if (ctx->use_comb) {  // a lane must own a whole number of blocks: splits divides (64 * nb) / lpg; k_msm_reduce_splits sums <= 64 units
+    const uint32_t per_lane = (64u * ctx->comb.nb) / ctx->comb.lpg;
+    auto ok = [&](uint32_t v) { return v >= 1 && v <= 64 && per_lane % v == 0; };
+    if (ctx->knobs.msm_splits && ok(ctx->knobs.msm_splits)) return ctx->knobs.msm_splits;
+    uint32_t best = 1;
+    for (uint32_t v = 1; v <= 64 && v <= per_lane; v++) {
+      if (!ok(v)) continue;
+      best = v;
+      if (n * v >= target) break;  // smallest split count that fills the chip, else the largest allowed
+    }
+    return best;
+  }
+  if (ctx->knobs.msm_splits) return ctx->knobs.msm_splits;
   uint32_t s = 1;
   while (s < 64 && n * s < target) s <<= 1;
   return s;
 }
 
-extern "C" uint64_t kzg_ctx_adds_per_blob(const kzg_ctx* ctx) { return ctx ? (uint64_t)ctx->geom.W * 4096u : 0; }
+extern "C" uint64_t kzg_ctx_adds_per_blob(const kzg_ctx* ctx) {
+  if (!ctx) return 0;
+  return ctx->use_comb ? (uint64_t)256u * 64u * ctx->comb.nb : (uint64_t)ctx->geom.W * 4096u;
+}
 
 extern "C" int32_t kzg_profile_begin(const kzg_ctx* ctx) {
   if (!ctx) return fail(KZG_FAIL_ARGUMENT, "null argument");
@@ -92,7 +107,9 @@ extern "C" int32_t kzg_profile_begin(const kzg_ctx* ctx) {
 }
 
 static const char* const PROF_NAMES[PROF_KINDS] = {"k_msm_fixed28", "k_challenge*", "k_eval_frac", "k_g1_decompress", "k_poly",
-                                                    "k_var_* (two lincombs)", "k_msm_reduce* + k_g1_compress"};
+                                                    "k_var_* (two lincombs)", "k_msm_reduce* + k_g1_compress", "k_comb_transpose"};
+extern "C" const char* kzg_ctx_msm_kernel_name(const kzg_ctx* ctx) { return (ctx && !ctx->use_comb) ? (ctx->msm_radix28 ? "k_msm_fixed28" : "k_msm_fixed") : "k_msm_comb28"; }
+extern "C" int32_t kzg_ctx_plane_groups(const kzg_ctx* ctx) { return (ctx && ctx->use_comb) ? (int32_t)ctx->comb.G : 0; }
 extern "C" const char* kzg_profile_kind_name(int32_t kind) { return (kind >= 0 && kind < PROF_KINDS) ? PROF_NAMES[kind] : ""; }
 
 extern "C" int32_t kzg_profile_end_kinds(const kzg_ctx* ctx, double* ms_out, uint64_t* launches) {
@@ -163,7 +180,7 @@ EnvKnobs read_env_knobs() {
   }
 }
 
-extern "C" int32_t kzg_ctx_window_bits(const kzg_ctx* ctx) { return ctx ? (int32_t)ctx->geom.c : 0; }
+extern "C" int32_t kzg_ctx_window_bits(const kzg_ctx* ctx) { return ctx ? (int32_t)ctx->window_class : 0; }
 extern "C" uint64_t kzg_ctx_table_bytes(const kzg_ctx* ctx) { return ctx ? ctx->table_bytes : 0; }
 
 extern "C" void kzg_ctx_destroy(kzg_ctx* ctx) {
@@ -175,6 +192,7 @@ extern "C" void kzg_ctx_destroy(kzg_ctx* ctx) {
   if (ctx->d_roots_brp) (void)hipFree(ctx->d_roots_brp);
   if (ctx->d_eval_tab) (void)hipFree(ctx->d_eval_tab);
   if (ctx->d_gen_affine) (void)hipFree(ctx->d_gen_affine);
+  if (ctx->d_comb_k) (void)hipFree(ctx->d_comb_k);
   delete ctx->pairing;
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
@@ -203,6 +221,67 @@ struct ScratchAllocs {
     for (void* p : ptrs) (void)hipFree(p);
   }
 };
+
+// ---- comb table (msm_comb.cuh): G groups x 64 chunks x ep64 subset sums, built a few chunks at a time through an XYZZ
+// staging buffer and the batch normaliser of the window table ----
+static int32_t comb_build(kzg_ctx* ctx, ScratchAllocs& scratch, TraceTimer& tt) {
+  const CombGeom cg = ctx->comb;
+  hipStream_t st = nullptr;
+  ctx->table_bytes = comb_table_entries(cg) * 96;
+  HIP_TRY(hipMalloc(&ctx->d_table, ctx->table_bytes));
+  tt.mark("table allocation");
+  uint4 *d_B = nullptr, *d_D = nullptr;
+  HIP_TRY(scratch.alloc(&d_B, (size_t)cg.G * 4096 * 96));
+  HIP_TRY(scratch.alloc(&d_D, (size_t)cg.G * 4096 * 96));
+  hipLaunchKernelGGL(k_comb_bases, dim3(64), dim3(64), 0, st, ctx->d_bases_brp, cg, d_B, d_D);
+  HIP_TRY(hipGetLastError());
+  uint32_t min_t = 64;
+  for (uint32_t r = 0; r < cg.nb; r++) min_t = comb_tbits(cg.nb, r) < min_t ? comb_tbits(cg.nb, r) : min_t;
+  const uint32_t sl = (min_t - 1 < 9) ? min_t - 1 : 9;  // segment = 2^sl entries per thread
+  uint32_t nq = 64;                                       // chunks per pass: staging buffer <= ~13 GB
+  while (nq > 1 && (uint64_t)nq * cg.ep64 * sizeof(g1_xyzz) > (13ull << 30)) nq >>= 1;
+  g1_xyzz* d_tmp = nullptr;
+  HIP_TRY(scratch.alloc(&d_tmp, (size_t)nq * cg.ep64 * sizeof(g1_xyzz)));
+  for (uint32_t grp = 0; grp < cg.G; grp++) {
+    for (uint32_t q0 = 0; q0 < 64; q0 += nq) {
+      const uint64_t threads = (uint64_t)nq * (cg.ep64 >> sl);
+      hipLaunchKernelGGL(k_comb_chain, dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, st, d_B, d_D, grp, q0, nq, cg, sl, d_tmp);
+      constexpr int KN = 8;
+      const uint64_t count = (uint64_t)nq * cg.ep64;
+      const uint64_t nthreads = (count + KN - 1) / KN;
+      hipLaunchKernelGGL(k_table_normalize<KN>, dim3((unsigned)((nthreads + 63) / 64)), dim3(64), 0, st, d_tmp, count, ctx->d_table,
+                         (uint64_t)grp * cg.epg + (uint64_t)q0 * cg.ep64, true);
+      HIP_TRY(hipGetLastError());
+    }
+  }
+  // K = [c0] G on the host (255 doublings + additions of the generator, once)
+  {
+    const uint32_t c0[8] = KZG_FR_COMB_C0_PLAIN, gx[12] = KZG_FP_G1X_MONT, gy[12] = KZG_FP_G1Y_MONT;
+    fp_t x, y;
+    for (int q = 0; q < 12; q++) {
+      x.v[q] = gx[q];
+      y.v[q] = gy[q];
+    }
+    g1_xyzz acc;
+    xyzz_set_inf(acc);
+    for (int bit = 255; bit >= 0; bit--) {
+      xyzz_dbl(acc);
+      if ((c0[bit >> 5] >> (bit & 31)) & 1u) xyzz_madd(acc, x, y);
+    }
+    fp_t kx, ky;
+    if (!xyzz_to_affine(kx, ky, acc)) return fail(KZG_FAIL_ARGUMENT, "comb constant is the identity");
+    uint32_t h[24];
+    for (int q = 0; q < 12; q++) {
+      h[q] = kx.v[q];
+      h[12 + q] = ky.v[q];
+    }
+    HIP_TRY(hipMalloc(&ctx->d_comb_k, 96));
+    HIP_TRY(hipMemcpy(ctx->d_comb_k, h, 96, hipMemcpyHostToDevice));
+  }
+  HIP_TRY(hipDeviceSynchronize());
+  tt.mark("comb table build kernels");
+  return 0;
+}
 
 static int32_t ctx_build(kzg_ctx* ctx, const uint8_t* g1_lagrange, const uint8_t* g2_monomial) {
   TraceTimer tt(ctx->knobs.trace, "ctx_build");
@@ -268,7 +347,18 @@ static int32_t ctx_build(kzg_ctx* ctx, const uint8_t* g1_lagrange, const uint8_t
   HIP_TRY(hipMalloc(&ctx->d_eval_tab, (size_t)2048 * EVAL_TAB_DWORDS * sizeof(uint32_t)));
   hipLaunchKernelGGL(k_setup_eval_tab, dim3(32), dim3(64), 0, st, ctx->d_roots_brp, ctx->d_eval_tab);
   HIP_TRY(hipGetLastError());
-  // ---- fixed-base table -----------------------------------------------------
+  if (ctx->use_comb) {
+    int32_t rcc = comb_build(ctx, scratch, tt);
+    if (rcc) return rcc;
+    HIP_TRY(hipDeviceSynchronize());
+    return 0;
+  }
+#if !defined(KZG_TEST_WINDOW_MSM)
+  (void)g;
+  (void)st;
+  return fail(KZG_FAIL_ARGUMENT, "the window-table MSM exists only in the test build");
+#else
+  // ---- fixed-base window table (test build, KATETH_AMD_MSM=window) ---------------
   const uint64_t entries = table_entries(g);
   ctx->table_bytes = entries * 96;
   HIP_TRY(hipMalloc(&ctx->d_table, ctx->table_bytes));
@@ -294,6 +384,7 @@ static int32_t ctx_build(kzg_ctx* ctx, const uint8_t* g1_lagrange, const uint8_t
   HIP_TRY(hipDeviceSynchronize());
   tt.mark("table build kernels");
   return 0;
+#endif
 }
 
 extern "C" int32_t kzg_ctx_create(const uint8_t* g1_lagrange, const uint8_t* g2_monomial, const kzg_config* cfg, kzg_ctx** out) {
@@ -304,13 +395,38 @@ extern "C" int32_t kzg_ctx_create(const uint8_t* g1_lagrange, const uint8_t* g2_
     return fail(KZG_FAIL_NO_DEVICE, "no HIP device visible: the kateth_amd engine has no CPU fallback");
   int device = cfg ? cfg->device : 0;
   if (device < 0 || device >= ndev) return fail(KZG_FAIL_ARGUMENT, "device ordinal out of range");
-  uint32_t c = (cfg && cfg->window_bits) ? (uint32_t)cfg->window_bits : 14u;  // default: 54 GiB table, 77,824 adds per blob
-  if (c < 4 || c > 16) return fail(KZG_FAIL_ARGUMENT, "window_bits must be in [4,16]");
+#if defined(KZG_TEST_WINDOW_MSM)
+  const bool window_mode = getenv("KATETH_AMD_MSM") != nullptr && std::string(getenv("KATETH_AMD_MSM")) == "window";
+#else
+  const bool window_mode = false;
+#endif
+  uint32_t c = (cfg && cfg->window_bits) ? (uint32_t)cfg->window_bits : 16u;  // default: comb with blocks of 16 points, 3.2 GB, 65,536 adds per blob
+  if (c < 4 || c > 22) return fail(KZG_FAIL_ARGUMENT, "window_bits must be in [4,22]");
+  if (window_mode && c > 16) c = 16;
   HIP_TRY(hipSetDevice(device));
   kzg_ctx* ctx = new (std::nothrow) kzg_ctx();
   if (!ctx) return fail(KZG_FAIL_ARGUMENT, "out of host memory");
   ctx->device = device;
-  ctx->geom = make_geom(c);
+  ctx->use_comb = !window_mode;
+  ctx->geom = make_geom(c > 16 ? 16 : c);
+  {
+    // comb geometry: index bits per lookup = points per block.  22: blocks of 22 + 21 + 21 (49,152 adds per blob, 25.8 GB
+    // per plane group); 16..21: 4 x 16; 8..15: 8 x 8; 4..7: 16 x 4 (the small classes keep test contexts cheap)
+    const uint32_t nb = c >= 22 ? 3u : (c >= 16 ? 4u : (c >= 8 ? 8u : 16u));
+    // plane groups G (one table each, H = 256/G planes and H - 1 accumulator doublings per lane): 16 for the small classes
+    // (12.9 GB at blocks of 16); for blocks of 22/21 8 groups = 192 GiB when the device has the room (288 GB parts), else 4
+    uint32_t G = 16;
+    if (nb == 3) {
+      size_t free_b = 0, total_b = 0;
+      G = 4;
+      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > (size_t)8 * 64 * ((size_t)1 << 22) * 96 + ((size_t)40 << 30)) G = 8;
+    }
+    if (cfg && cfg->reserved) G = (uint32_t)cfg->reserved;
+    if (const char* e = getenv("KATETH_AMD_COMB_GROUPS")) G = (uint32_t)atoi(e);
+    if (!(G == 1 || G == 2 || G == 4 || G == 8 || G == 16)) return fail(KZG_FAIL_ARGUMENT, "plane groups must be 1, 2, 4, 8 or 16");
+    ctx->comb = comb_make_geom(nb, G);
+    ctx->window_class = window_mode ? c : (nb == 3 ? 22u : 64u / nb);
+  }
   if (hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess) {
     delete ctx;
@@ -319,8 +435,12 @@ extern "C" int32_t kzg_ctx_create(const uint8_t* g1_lagrange, const uint8_t* g2_
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cus = (uint32_t)prop.multiProcessorCount;
   ctx->knobs = read_env_knobs();
-#if defined(KZG_TEST_RADIX32)
+#if defined(KZG_TEST_WINDOW_MSM)
   if (const char* e = getenv("KATETH_AMD_MSM_RADIX")) ctx->msm_radix28 = atoi(e) != 32;  // test-only build
+  if (!ctx->msm_radix28) {  // the 12 x 32-bit-limb kernel walks round 1's window table
+    ctx->use_comb = false;
+    ctx->window_class = ctx->geom.c;
+  }
 #endif
   int32_t rc = ctx_build(ctx, g1_lagrange, g2_monomial);
   if (rc != 0) {
@@ -344,19 +464,21 @@ static int32_t commit_dev_locked(const kzg_ctx* ctx, const void* d_blobs, uint64
   const uint64_t chunk_max = 16384;  // bounds the lane-partial scratch (12 KiB per blob)
   const uint64_t cn = n < chunk_max ? n : chunk_max;
   const uint32_t splits = choose_splits(ctx, cn);
-  const size_t partial_bytes = (size_t)cn * splits * 65 * sizeof(g1_xyzz);  // 64 lane sums + 1 unit sum per (blob, split)
-  const size_t need = partial_bytes + (size_t)cn * sizeof(g1_xyzz);
+  const size_t partial_bytes = align_up((size_t)cn * splits * 65 * sizeof(g1_xyzz), 256);  // 64 lane sums + 1 unit sum per (blob, split)
+  const size_t sums_bytes = align_up((size_t)cn * sizeof(g1_xyzz), 256);
+  const size_t need = partial_bytes + sums_bytes + msm_scratch_bytes(ctx, cn);
   int32_t rc = ws_reserve(ctx, need);
   if (rc) return rc;
   g1_xyzz* partials = reinterpret_cast<g1_xyzz*>(ctx->ws);
   g1_xyzz* sums = reinterpret_cast<g1_xyzz*>(reinterpret_cast<uint8_t*>(ctx->ws) + partial_bytes);
+  void* msm_scratch = reinterpret_cast<uint8_t*>(ctx->ws) + partial_bytes + sums_bytes;
   HIP_TRY(hipMemsetAsync(d_status, 0, n * sizeof(int32_t), st));
   for (uint64_t base = 0; base < n; base += cn) {
     const uint64_t m = (n - base < cn) ? (n - base) : cn;
     rc = msm_pipeline<true>(ctx, reinterpret_cast<const uint8_t*>(d_blobs) + base * (uint64_t)KZG_BYTES_PER_BLOB, m,
                             d_out48 ? reinterpret_cast<uint8_t*>(d_out48) + base * 48 : nullptr,
                             d_out_affine96 ? reinterpret_cast<uint8_t*>(d_out_affine96) + base * 96 : nullptr, d_status + base, partials, sums,
-                            splits, st);
+                            splits, msm_scratch, st);
     if (rc) return rc;
   }
   return 0;
@@ -412,11 +534,13 @@ static int32_t commit_host(const kzg_ctx* ctx, const uint8_t* blobs, uint64_t n,
       rc = fail(KZG_FAIL_HIP, "host-buffer commitment: allocation failed");
       break;
     }
-    const size_t partial_bytes = (size_t)group * splits * 65 * sizeof(g1_xyzz);
-    rc = ws_reserve(ctx, partial_bytes + (size_t)group * sizeof(g1_xyzz));
+    const size_t partial_bytes = align_up((size_t)group * splits * 65 * sizeof(g1_xyzz), 256);
+    const size_t sums_bytes = align_up((size_t)group * sizeof(g1_xyzz), 256);
+    rc = ws_reserve(ctx, partial_bytes + sums_bytes + 2 * msm_scratch_bytes(ctx, chunk));
     if (rc) break;
     g1_xyzz* partials = reinterpret_cast<g1_xyzz*>(ctx->ws);
     g1_xyzz* sums = reinterpret_cast<g1_xyzz*>(reinterpret_cast<uint8_t*>(ctx->ws) + partial_bytes);
+    uint8_t* msm_scratch = reinterpret_cast<uint8_t*>(ctx->ws) + partial_bytes + sums_bytes;  // one per staging slot
     rc = ws_acquire(ctx, comp_st);
     if (rc) break;
     if (hipMemsetAsync(d_status, 0, n * sizeof(int32_t), comp_st) != hipSuccess) {
@@ -440,7 +564,8 @@ static int32_t commit_host(const kzg_ctx* ctx, const uint8_t* blobs, uint64_t n,
           rc = fail(KZG_FAIL_HIP, "host-to-device copy failed");
           break;
         }
-        rc = msm_launch<true>(ctx, stage[slot], m, d_status + base, partials + (size_t)off * splits * 64, splits, comp_st);
+        rc = msm_launch<true>(ctx, stage[slot], m, d_status + base, partials + (size_t)off * splits * 64, splits,
+                              msm_scratch + (size_t)slot * msm_scratch_bytes(ctx, chunk), comp_st);
         if (rc == 0 && hipEventRecord(done[slot], comp_st) != hipSuccess) rc = fail(KZG_FAIL_HIP, "event record failed");
       }
       if (rc == 0)

@@ -16,6 +16,7 @@
 #include "../../include/kateth_amd.h"
 #include "blob_kernels.cuh"
 #include "msm_fixed.cuh"
+#include "msm_comb.cuh"
 #include "pairing.hpp"
 
 using namespace kzg;
@@ -58,7 +59,7 @@ struct TraceTimer {  // KATETH_AMD_TRACE=1: host-side wall-clock marks on stderr
 constexpr int KZG_STAGE_SLOTS = 4;    // x up to 4,096 blobs x 128 KiB = 2 GiB of staging at most
 constexpr int KZG_STAGE_STREAMS = 4;  // per-chunk kernels rotate over these (a chunk's SHA-256 streams are latency-bound: several in flight)
 #define KZG_SESSION_STREAM (reinterpret_cast<hipStream_t>(static_cast<intptr_t>(-1)))  // session_acquire: run on the session's own stream
-enum ProfKind { PROF_MSM_FIXED = 0, PROF_CHALLENGE, PROF_EVAL, PROF_DECODE, PROF_POLY, PROF_VAR_MSM, PROF_REDUCE_COMPRESS, PROF_KINDS };
+enum ProfKind { PROF_MSM_FIXED = 0, PROF_CHALLENGE, PROF_EVAL, PROF_DECODE, PROF_POLY, PROF_VAR_MSM, PROF_REDUCE_COMPRESS, PROF_TRANSPOSE, PROF_KINDS };
 static_assert(PROF_KINDS == KZG_PROF_KINDS, "include/kateth_amd.h and ProfKind disagree");
 struct ProfEvent {
   int kind;
@@ -69,7 +70,11 @@ struct kzg_verify_session;
 struct kzg_ctx {
   int device = 0;
   MsmGeom geom{};
-  uint4* d_table = nullptr;      // fixed-base table, table_entries(geom) * 96 B
+  uint4* d_table = nullptr;      // fixed-base table: comb (msm_comb.cuh) comb_table_entries(comb) * 96 B, or window table_entries(geom) * 96 B
+  bool use_comb = true;          // subset-sum comb MSM; false only in the TEST build (KATETH_AMD_MSM=window / KATETH_AMD_MSM_RADIX=32 there)
+  CombGeom comb{};
+  uint4* d_comb_k = nullptr;     // the comb's constant term K = [(2^256-1)/2] G, affine, canonical 2^384-Montgomery (96 B)
+  uint32_t window_class = 0;     // what kzg_ctx_window_bits reports
   uint4* d_bases_brp = nullptr;  // 4096 affine Lagrange points, BRP order
   fr_t* d_roots_brp = nullptr;   // 4096 roots of unity, Montgomery, BRP order
   uint32_t* d_eval_tab = nullptr;  // 2048 x {w R, w R^2, w^2 R} in radix-2^29 limbs (k_eval_frac, verify_kernels.cuh)
@@ -79,8 +84,8 @@ struct kzg_ctx {
   uint32_t num_cus = 256;
   hipStream_t side_stream = nullptr;  // non-blocking stream for work that overlaps the caller's stream
   hipStream_t copy_stream = nullptr;  // non-blocking stream for the chunked host-to-device copies of the host-buffer entry points
-  // true (default): table in 2^392-Montgomery form, k_msm_fixed28 (radix-2^28 limbs, fp28.cuh);
-  // KATETH_AMD_MSM_RADIX=32 at context creation: 2^384-Montgomery table, k_msm_fixed (12 x 32-bit limbs)
+  // window-table test build only: true = k_msm_fixed28 (2^392-Montgomery table), false (KATETH_AMD_MSM_RADIX=32) = k_msm_fixed
+  // on 12 x 32-bit limbs (2^384-Montgomery table)
   bool msm_radix28 = true;
   EnvKnobs knobs;  // read once at kzg_ctx_create
   // workspace (grown on demand, guarded by lock)
@@ -154,22 +159,39 @@ static inline void launch_challenge_and_decode(const kzg_ctx* ctx, hipStream_t s
                      n_b, status_b, affine, inf);
 }
 
-// The fixed-base MSM kernel alone over `n` scalar vectors on the device: 64 lane sums per (blob, split) unit into
-// partials[unit * 64 + lane].
+// Scratch the fixed-base MSM needs besides the lane sums: the comb's bit-plane masks (the blob transposed, 128 KiB per blob).
+static inline size_t msm_scratch_bytes(const kzg_ctx* ctx, uint64_t n) { return ctx->use_comb ? (size_t)n * KZG_BYTES_PER_BLOB : 0; }
+
+// The fixed-base MSM alone over `n` scalar vectors on the device: 64 lane sums per (blob, split) unit into
+// partials[unit * 64 + lane].  `scratch`: msm_scratch_bytes(ctx, n) bytes.
 template <bool BE_BYTES>
 static int32_t msm_launch(const kzg_ctx* ctx, const uint8_t* d_scalars, uint64_t n, int32_t* d_status, g1_xyzz* partials, uint32_t splits,
-                          hipStream_t st) {
+                          void* scratch, hipStream_t st) {
+  if (ctx->use_comb) {
+    uint64_t* masks = reinterpret_cast<uint64_t*>(scratch);
+    {
+      ProfScope ps(ctx, PROF_TRANSPOSE, st);
+      hipLaunchKernelGGL((k_comb_transpose<BE_BYTES>), dim3((unsigned)(n * 64)), dim3(64), 0, st, d_scalars, n, masks, d_status);
+    }
+    ProfScope ps(ctx, PROF_MSM_FIXED, st);
+    hipLaunchKernelGGL(k_msm_comb28, dim3((unsigned)(n * splits)), dim3(64), 0, st, masks, splits, ctx->d_table, ctx->comb, partials);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
+#if defined(KZG_TEST_WINDOW_MSM)
+  // test-only build (tests/window_msm): round 1's window-table kernels as independent cross-checks of the comb
   ProfScope ps(ctx, PROF_MSM_FIXED, st);
-#if defined(KZG_TEST_RADIX32)
-  if (!ctx->msm_radix28)  // test-only build (tests/radix32): the 12 x 32-bit-limb kernel as an independent cross-check
+  if (!ctx->msm_radix28)
     hipLaunchKernelGGL((k_msm_fixed<BE_BYTES, 2>), dim3((unsigned)(n * splits)), dim3(64), 0, st, d_scalars, splits, ctx->d_table, ctx->geom,
                        partials, d_status);
   else
-#endif
     hipLaunchKernelGGL((k_msm_fixed28<BE_BYTES>), dim3((unsigned)(n * splits)), dim3(64), 0, st, d_scalars, splits, ctx->d_table, ctx->geom,
                        partials, d_status);
   HIP_TRY(hipGetLastError());
   return 0;
+#else
+  return fail(KZG_FAIL_ARGUMENT, "the window-table MSM exists only in the test build");
+#endif
 }
 // Lane sums of n blobs -> 48-byte encodings.  Two tree stages: the 64 lane sums of every (blob, split) unit, then the units
 // of a blob -- 6 + log2(splits) levels of latency instead of the splits + 5 a sequential walk over the splits costs (a
@@ -180,15 +202,15 @@ static inline int32_t msm_finish(const kzg_ctx* ctx, uint64_t n, uint8_t* d_out4
   g1_xyzz* unit_sums = (splits == 1) ? sums : partials + (size_t)n * splits * 64;
   hipLaunchKernelGGL(k_msm_reduce, dim3((unsigned)(n * splits)), dim3(64), 0, st, partials, n * splits, unit_sums);
   if (splits > 1) hipLaunchKernelGGL(k_msm_reduce_splits, dim3((unsigned)n), dim3(64), 0, st, unit_sums, splits, n, sums);
-  hipLaunchKernelGGL(k_g1_compress, dim3(blocks_for(n, 64)), dim3(64), 0, st, sums, n, d_status, d_out48, d_out_affine96);
+  hipLaunchKernelGGL(k_g1_compress, dim3(blocks_for(n, 64)), dim3(64), 0, st, sums, n, d_status, d_out48, d_out_affine96, ctx->use_comb ? ctx->d_comb_k : (const uint4*)nullptr);
   HIP_TRY(hipGetLastError());
   return 0;
 }
 // MSM + reduce + compress
 template <bool BE_BYTES>
 static int32_t msm_pipeline(const kzg_ctx* ctx, const uint8_t* d_scalars, uint64_t n, uint8_t* d_out48, uint8_t* d_out_affine96, int32_t* d_status,
-                            g1_xyzz* partials, g1_xyzz* sums, uint32_t splits, hipStream_t st) {
-  int32_t rc = msm_launch<BE_BYTES>(ctx, d_scalars, n, d_status, partials, splits, st);
+                            g1_xyzz* partials, g1_xyzz* sums, uint32_t splits, void* scratch, hipStream_t st) {
+  int32_t rc = msm_launch<BE_BYTES>(ctx, d_scalars, n, d_status, partials, splits, scratch, st);
   if (rc) return rc;
   return msm_finish(ctx, n, d_out48, d_out_affine96, d_status, partials, sums, splits, st);
 }

@@ -50,6 +50,7 @@ static int32_t proof_dev_locked(const kzg_ctx* ctx, const uint8_t* d_blobs, cons
   }
   const size_t o_part = take(cn * splits * 65 * sizeof(g1_xyzz));  // 64 lane sums + 1 unit sum per (blob, split)
   const size_t o_sum = take(cn * sizeof(g1_xyzz));
+  const size_t o_msm = take(msm_scratch_bytes(ctx, cn));
   int32_t rc = ws_reserve(ctx, off);
   if (rc) return rc;
   uint8_t* ws = reinterpret_cast<uint8_t*>(ctx->ws);
@@ -131,7 +132,7 @@ static int32_t proof_dev_locked(const kzg_ctx* ctx, const uint8_t* d_blobs, cons
       fr_t* q = reinterpret_cast<fr_t*>(ws + o_q[sl]);
       (void)hipStreamWaitEvent(st, ev_prep[k], 0);
       rc = msm_pipeline<false>(ctx, reinterpret_cast<const uint8_t*>(q), m, d_out48 ? d_out48 + base * 48 : nullptr,
-                               d_out_affine96 ? d_out_affine96 + base * 96 : nullptr, d_status + base, partials, sums, splits, st);
+                               d_out_affine96 ? d_out_affine96 + base * 96 : nullptr, d_status + base, partials, sums, splits, ws + o_msm, st);
       if (rc) break;
       if (d_y32) hipLaunchKernelGGL(k_fr_store_be, dim3(blocks_for(m, 256)), dim3(256), 0, st, y, m, d_status + base, d_y32 + base * 32);
       (void)hipEventRecord(ev_done[k], st);

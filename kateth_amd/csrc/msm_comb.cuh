@@ -1,0 +1,293 @@
+// Fixed-base 4096-point G1 MSM as a SUBSET-SUM COMB (kernel K2 of SURVEY.md section 2b): replaces
+// P1::lincomb_pippenger(setup.g1_lagrange_brp, scalars) (src/bls.rs:416-437, called from src/blob.rs:48-53 and
+// src/kzg/poly.rs:68).
+//
+// Round 1 took the windowed method to its fixed-base limit (msm_fixed.cuh: every signed c-bit multiple of every window
+// base, 192 GiB at c = 16, 65,536 additions per blob).  A table entry there serves ONE point; here an entry serves a BLOCK
+// of t points, which is t times more memory-efficient per index bit:
+//   * scalars are recoded to signed bits:  2e = sum_k s_k 2^k + (2^256 - 1),  s_k = 2 b_k - 1 = +-1  (k = 0..255), so
+//       sum_i e_i L_i = sum_k 2^k sum_i s_{i,k} (L_i / 2)  +  [(2^256 - 1)/2] sum_i L_i ,
+//     and sum_i L_i is the G1 generator (the Lagrange basis sums to 1): the last term is the constant point K = [c0]G;
+//   * the 4096 points are cut into blocks of t consecutive points (per 64 points: 22 + 21 + 21, or 4 x 16, 8 x 8, 16 x 4);
+//     for a block the table holds every sign combination  S[m] = sum_p s_p(m) (L_p / 2)  with the top sign fixed to -1
+//     (S[~m] = -S[m]: a negation is free), 2^(t-1) affine entries;
+//   * bit plane k of a blob is then ONE table lookup + mixed addition per block: 256 planes x 192 blocks = 49,152
+//     additions per blob at t = 22/21 instead of 65,536 -- with a 25.8 GB table instead of 192 GiB;
+//   * the planes are combined by Horner's rule inside a lane (one doubling of the lane's accumulator per plane).  To keep
+//     that overhead small the planes are cut into G groups of H = 256/G, each with its OWN table built on 2^(H g) L_i/2,
+//     so a lane only walks H planes (H - 1 doublings against H x blocks-per-lane additions) and the lane sums of a
+//     blob add up without any scaling: G = 4 -> 103 GB, 63 doublings per 768 additions.
+// The bit planes come from a transposition kernel (k_comb_transpose: the blob as a 64 x 256 array of 64-bit masks, one
+// mask = bit k of 64 consecutive scalars; it also performs Blob::from_slice's canonicity check, src/blob.rs:26-37).
+//
+// Work decomposition: one wave per (blob, split); lane = (plane group, block owner).  The hot loop is the radix-2^28
+// mixed addition of msm_fixed.cuh (xyzz28_madd_fast, fp28.cuh) with the next table entry gathered while the current
+// addition runs, and the mask of the step after that already in flight.
+#pragma once
+#include "msm_fixed.cuh"
+
+namespace kzg {
+
+struct CombGeom {
+  uint32_t nb;    // blocks per 64 points: 3 (22 + 21 + 21 points), 4 (16 each), 8 (8 each), 16 (4 each)
+  uint32_t G;     // plane groups = tables; H = 256 / G planes each
+  uint32_t H;
+  uint32_t lpg;   // lanes per group = 64 / G
+  uint32_t ep64;  // table entries per 64 points (one group): sum over the blocks of 2^(t-1)
+  uint32_t epg;   // entries per group = 64 * ep64
+};
+
+KZG_HD uint32_t comb_tbits(uint32_t nb, uint32_t r) { return nb == 3u ? (r == 0u ? 22u : 21u) : 64u / nb; }
+KZG_HD uint32_t comb_point_off(uint32_t nb, uint32_t r) { return nb == 3u ? (r == 0u ? 0u : (r == 1u ? 22u : 43u)) : r * (64u / nb); }
+KZG_HD uint32_t comb_entry_off(uint32_t nb, uint32_t r) {
+  return nb == 3u ? (r == 0u ? 0u : (r == 1u ? (1u << 21) : (1u << 21) + (1u << 20))) : r << (64u / nb - 1u);
+}
+KZG_HD CombGeom comb_make_geom(uint32_t nb, uint32_t G) {
+  CombGeom g;
+  g.nb = nb;
+  g.G = G;
+  g.H = 256u / G;
+  g.lpg = 64u / G;
+  g.ep64 = nb == 3u ? (1u << 22) : nb << (64u / nb - 1u);
+  g.epg = 64u * g.ep64;
+  return g;
+}
+KZG_HD uint64_t comb_table_entries(const CombGeom& g) { return (uint64_t)g.G * g.epg; }
+// largest `splits` the geometry supports: a lane must own a whole number of blocks
+KZG_HD uint32_t comb_max_splits(const CombGeom& g) { return (64u * g.nb) / g.lpg; }
+
+#if defined(__HIPCC__)
+
+// 64 x 64 bit-matrix transposition across the lanes of a wave: lane i holds row i (bit j = column j); afterwards lane j
+// holds column j.  Six butterfly stages, two cross-lane permutes each.
+__device__ __forceinline__ uint64_t wave_transpose64(uint64_t x, int lane) {
+  constexpr uint64_t LO[6] = {0x00000000FFFFFFFFull, 0x0000FFFF0000FFFFull, 0x00FF00FF00FF00FFull,
+                              0x0F0F0F0F0F0F0F0Full, 0x3333333333333333ull, 0x5555555555555555ull};
+#pragma unroll
+  for (int s = 0; s < 6; s++) {
+    const int d = 32 >> s;
+    const uint64_t lo = LO[s];
+    const uint64_t y = __shfl_xor(x, d, 64);
+    x = (lane & d) ? ((x & ~lo) | ((y >> d) & lo)) : ((x & lo) | ((y << d) & ~lo));
+  }
+  return x;
+}
+
+// One wave per (blob, 64-point chunk q): masks[(blob * 64 + q) * 256 + k] = bit k of scalars 64q .. 64q+63 (bit p of the
+// mask = point 64q + p).  BE_BYTES: raw blob bytes, validated here (Blob::from_slice, src/blob.rs:26-37); a
+// non-canonical element is treated as 0 and the blob's status is set.
+template <bool BE_BYTES>
+static __global__ __launch_bounds__(64) void k_comb_transpose(const uint8_t* __restrict__ scalars, uint64_t n, uint64_t* __restrict__ masks,
+                                                              int32_t* __restrict__ status) {
+  const int lane = threadIdx.x;
+  const uint64_t unit = blockIdx.x;
+  const uint64_t blob = unit >> 6;
+  const uint32_t q = (uint32_t)(unit & 63u);
+  if (blob >= n) return;
+  uint32_t sc[8];
+  load_scalar<BE_BYTES>(sc, scalars + blob * (uint64_t)KZG_BYTES_PER_BLOB_ + (uint64_t)(q * 64u + (uint32_t)lane) * 32u);
+  bool bad = false;
+  if (BE_BYTES) {
+    fr_t v;
+#pragma unroll
+    for (int w = 0; w < 8; w++) v.v[w] = sc[w];
+    if (!fr_is_canonical(v)) {
+      bad = true;
+#pragma unroll
+      for (int w = 0; w < 8; w++) sc[w] = 0;
+    }
+  }
+  uint64_t* out = masks + unit * 256u;
+#pragma unroll
+  for (int w = 0; w < 4; w++) {
+    const uint64_t row = ((uint64_t)sc[2 * w + 1] << 32) | sc[2 * w];
+    out[64 * w + lane] = wave_transpose64(row, lane);
+  }
+  if (BE_BYTES) {
+    if (__any(bad) && lane == 0) atomicOr(&status[blob], KZG_ERR_BLOB_INVALID_FIELD_ELEMENT);
+  }
+}
+
+// lane-walker of k_msm_comb28: position = (plane h counting down, block counter s, chunk q, block-in-chunk r)
+struct CombWalker {
+  uint32_t h, s, q, r;
+};
+
+// One wave per (blob, split).  lane = (group, owner): group grp = lane / lpg walks planes [grp H, grp H + H) of its own
+// table; owner = split * lpg + lane % lpg owns blocks [owner * bpo, owner * bpo + bpo) of the 64 nb blocks.
+static __global__ __launch_bounds__(64, 2) void k_msm_comb28(const uint64_t* __restrict__ masks, uint32_t splits, const uint4* __restrict__ table,
+                                                             CombGeom g, g1_xyzz* __restrict__ partials) {
+  const int lane = threadIdx.x;
+  const uint64_t unit = blockIdx.x;
+  const uint64_t blob = unit / splits;
+  const uint32_t split = (uint32_t)(unit % splits);
+  const uint32_t grp = (uint32_t)lane / g.lpg;
+  const uint32_t owner = split * g.lpg + (uint32_t)lane % g.lpg;
+  const uint32_t bpo = (64u * g.nb) / (splits * g.lpg);
+  const uint32_t b0 = owner * bpo;
+  const uint64_t* mrow = masks + blob * (64u * 256u);
+  const uint32_t kbase = grp * g.H;
+  const uint4* tgrp = table + (uint64_t)grp * g.epg * 6u;
+  const uint32_t total = g.H * bpo;
+  const uint32_t nb = g.nb;
+
+  g1_xyzz28 acc;
+  xyzz28_set_inf(acc);
+
+  CombWalker w;  // next mask to load
+  w.h = g.H - 1u;
+  w.s = 0;
+  w.q = b0 / nb;
+  w.r = b0 % nb;
+  auto advance = [&]() {
+    w.s++;
+    w.r++;
+    if (w.r == nb) {
+      w.r = 0;
+      w.q++;
+    }
+    if (w.s == bpo) {
+      w.s = 0;
+      w.h--;
+      w.q = b0 / nb;
+      w.r = b0 % nb;
+    }
+  };
+  // pipeline registers: m1 = mask of step t+1 with its walker position p1; (nx, ny) = table entry of step t
+  uint64_t m1 = mrow[w.q * 256u + kbase + w.h];
+  CombWalker p1 = w;
+  advance();
+  fp_t nx, ny;
+  bool nneg = false, ndbl = false;
+  uint32_t nidx = 0;
+  auto gather = [&]() {  // entry of the step at p1 from its mask m1
+    const uint32_t tb = comb_tbits(nb, p1.r);
+    const uint32_t pat = (uint32_t)(m1 >> comb_point_off(nb, p1.r)) & ((1u << tb) - 1u);
+    nneg = (pat >> (tb - 1u)) != 0u;  // top sign +1: the table holds the mirrored pattern, negated
+    const uint32_t m = nneg ? (~pat & ((1u << (tb - 1u)) - 1u)) : pat;
+    nidx = p1.q * g.ep64 + comb_entry_off(nb, p1.r) + m;
+    ndbl = (p1.s == 0u) && (p1.h != g.H - 1u);
+    load_affine96(nx, ny, tgrp, nidx);
+  };
+  gather();
+  if (total > 1u) {
+    m1 = mrow[w.q * 256u + kbase + w.h];
+    p1 = w;
+    advance();
+  }
+
+#pragma unroll 1
+  for (uint32_t t = 0; t < total; t++) {
+    fp28 cx, cy;
+    f28_load_entry(cx, cy, nx, ny, nneg);
+    const bool cneg = nneg, cdbl = ndbl;
+    const uint32_t cidx = nidx;
+    if (t + 1u < total) {
+      gather();
+      if (t + 2u < total) {
+        m1 = mrow[w.q * 256u + kbase + w.h];
+        p1 = w;
+        advance();
+      }
+    }
+    if (cdbl && !acc.inf) {  // Horner step between two planes: out of line, on a copy (63 times per lane at G = 4)
+      g1_xyzz28 tmp = acc;
+      xyzz28_dbl(tmp);
+      acc = tmp;
+    }
+    bool done = false;
+    if (!acc.inf) done = xyzz28_madd_fast(acc, cx, cy);
+    if (!done) {
+      g1_xyzz28 tmp = acc;
+      fp_t rx, ry;
+      load_affine96(rx, ry, tgrp, cidx);
+      fp28 sx, sy;  // separate objects: the call takes their address
+      f28_load_entry(sx, sy, rx, ry, cneg);
+      xyzz28_madd_complete(tmp, sx, sy);
+      acc = tmp;
+    }
+  }
+  g1_xyzz out;
+  xyzz28_to_xyzz(out, acc);  // back to canonical 2^384-Montgomery limbs for k_msm_reduce
+  partials[unit * 64 + lane] = out;
+}
+
+// ---- table build -------------------------------------------------------------------------------------------------
+// thread i: B[g][i] = 2^(H g) * [1/2] L_i and D[g][i] = 2 B[g][i], affine, canonical 2^384-Montgomery (12 x 32 limbs)
+static __global__ __launch_bounds__(64) void k_comb_bases(const uint4* __restrict__ bases_brp, CombGeom g, uint4* __restrict__ B, uint4* __restrict__ D) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 4096) return;
+  fp_t x, y;
+  load_affine96(x, y, bases_brp, i);
+  const uint32_t half[8] = KZG_FR_HALF_PLAIN;  // 1/2 mod r = (r + 1) / 2
+  g1_xyzz acc;
+  xyzz_set_inf(acc);
+  for (int bit = 254; bit >= 0; bit--) {
+    xyzz_dbl(acc);
+    if ((half[bit >> 5] >> (bit & 31)) & 1u) {
+      g1_xyzz mine = acc;
+      xyzz_madd(mine, x, y);
+      acc = mine;
+    }
+  }
+  for (uint32_t grp = 0; grp < g.G; grp++) {
+    fp_t ax, ay;
+    xyzz_to_affine(ax, ay, acc);
+    store_affine96(B, (uint64_t)grp * 4096u + i, ax, ay);
+    xyzz_from_affine(acc, ax, ay);
+    g1_xyzz d2 = acc;
+    xyzz_dbl(d2);
+    fp_t dx, dy;
+    xyzz_to_affine(dx, dy, d2);
+    store_affine96(D, (uint64_t)grp * 4096u + i, dx, dy);
+    if (grp + 1 < g.G)
+      for (uint32_t k = 0; k < g.H; k++) xyzz_dbl(acc);
+  }
+}
+
+// Subset sums of group `grp` for chunks [q_first, q_first + nq): one thread per segment of 2^sl consecutive entries of a
+// block.  The segment's first entry is formed from the block's t points; the rest follows a Gray code over the low sl
+// bits (one mixed addition of +-2B_p per entry).  tmp[(q - q_first) * ep64 + entry] in XYZZ; k_table_normalize writes the table.
+static __global__ __launch_bounds__(64) void k_comb_chain(const uint4* __restrict__ B, const uint4* __restrict__ D, uint32_t grp, uint32_t q_first,
+                                                          uint32_t nq, CombGeom g, uint32_t sl, g1_xyzz* __restrict__ tmp) {
+  const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t segs_per_chunk = g.ep64 >> sl;
+  if (tid >= (uint64_t)nq * segs_per_chunk) return;
+  const uint32_t qi = (uint32_t)(tid / segs_per_chunk);
+  const uint32_t e_start = (uint32_t)(tid % segs_per_chunk) << sl;
+  uint32_t r = 0;
+  while (r + 1 < g.nb && comb_entry_off(g.nb, r + 1) <= e_start) r++;
+  const uint32_t tb = comb_tbits(g.nb, r);
+  const uint32_t m_start = e_start - comb_entry_off(g.nb, r);
+  const uint32_t i0 = (q_first + qi) * 64u + comb_point_off(g.nb, r);
+  const uint4* Bg = B + (uint64_t)grp * 4096u * 6u;
+  const uint4* Dg = D + (uint64_t)grp * 4096u * 6u;
+  g1_xyzz acc;
+  xyzz_set_inf(acc);
+  for (uint32_t p = 0; p < tb; p++) {
+    fp_t x, y;
+    load_affine96(x, y, Bg, i0 + p);
+    if (!((m_start >> p) & 1u)) fp_neg(y, y);  // sign -1 (always so for p = t-1)
+    g1_xyzz mine = acc;
+    xyzz_madd(mine, x, y);
+    acc = mine;
+  }
+  g1_xyzz* o = tmp + (uint64_t)qi * g.ep64 + comb_entry_off(g.nb, r);
+  o[m_start] = acc;
+  uint32_t gray = 0;
+#pragma unroll 1
+  for (uint32_t j = 1; j < (1u << sl); j++) {
+    const uint32_t p = (uint32_t)__builtin_ctz(j);
+    gray ^= 1u << p;
+    fp_t x, y;
+    load_affine96(x, y, Dg, i0 + p);
+    if (!((gray >> p) & 1u)) fp_neg(y, y);  // the sign went from +1 to -1: subtract 2B_p
+    g1_xyzz mine = acc;
+    xyzz_madd(mine, x, y);
+    acc = mine;
+    o[m_start | gray] = acc;
+  }
+}
+
+#endif  // __HIPCC__
+}  // namespace kzg

@@ -100,9 +100,10 @@ __device__ __forceinline__ void wave_reduce_xyzz(g1_xyzz& acc, g1_xyzz* lds, int
   }
 }
 
-#if defined(KZG_TEST_RADIX32)
-// TEST-ONLY build (tests/radix32, -DKZG_TEST_RADIX32): the round-1 kernel on 12 x 32-bit limbs, kept as an independent
-// cross-check of the radix-2^28 kernel; it is not compiled into the product library.
+#if defined(KZG_TEST_WINDOW_MSM)
+// TEST-ONLY build (tests/window_msm, -DKZG_TEST_WINDOW_MSM): round 1's window-table MSM kernels (12 x 32-bit limbs, and
+// the radix-2^28 one below), kept as independent cross-checks of the comb kernel (msm_comb.cuh); they are not compiled
+// into the product library.
 // One wave per (blob, split).  BE_BYTES: scalars are raw blob bytes (32-B
 // big-endian, validated here: Blob::from_slice, src/blob.rs:26-37); otherwise
 // canonical little-endian limbs produced on device (quotient polynomial).
@@ -185,8 +186,6 @@ static __global__ __launch_bounds__(64, OCC) void k_msm_fixed(const uint8_t* __r
   }
 }
 
-
-#endif  // KZG_TEST_RADIX32
 
 // The fixed-base walk with the accumulator in the carry-free radix-2^28 representation (fp28.cuh): 392 v_mad_u64_u32
 // and no carry instruction per Montgomery product, 9 reductions per mixed add.  The table must hold 2^392-Montgomery
@@ -282,6 +281,8 @@ static __global__ __launch_bounds__(64, 2) void k_msm_fixed28(const uint8_t* __r
   }
 }
 
+#endif  // KZG_TEST_WINDOW_MSM
+
 // One wave per (blob, split) unit: sums the unit's 64 lane partials (6-level tree through LDS).
 static __global__ __launch_bounds__(64) void k_msm_reduce(const g1_xyzz* __restrict__ partials, uint64_t units, g1_xyzz* __restrict__ unit_sums) {
   __shared__ g1_xyzz28 lds[32];
@@ -331,8 +332,9 @@ static __global__ __launch_bounds__(64) void k_msm_reduce_splits(const g1_xyzz* 
 // (K3: blst_p1_compress, src/bls.rs:499) and/or the 96-byte blst_p1_affine image (so that a caller that wants the
 // reference's `P1` back -- Commitment = Proof = P1, src/kzg/mod.rs:9-10 -- needs no square root).  Items whose status
 // is non-zero get zero bytes.  Either output pointer may be null.
+// `comb_k` (nullable): the comb MSM's constant term K (affine, 2^384-Montgomery), added to every sum first (msm_comb.cuh).
 static __global__ __launch_bounds__(64) void k_g1_compress(const g1_xyzz* __restrict__ sums, uint64_t n, const int32_t* __restrict__ status,
-                                                    uint8_t* __restrict__ out48, uint8_t* __restrict__ out_affine96) {
+                                                    uint8_t* __restrict__ out48, uint8_t* __restrict__ out_affine96, const uint4* __restrict__ comb_k) {
   const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= n) return;
   uint8_t tmp[48];
@@ -342,6 +344,13 @@ static __global__ __launch_bounds__(64) void k_g1_compress(const g1_xyzz* __rest
     for (int q = 0; q < 24; q++) aff[q] = 0;
   } else {
     g1_xyzz acc = sums[b];
+    if (comb_k != nullptr) {
+      fp_t kx, ky;
+      load_affine96(kx, ky, comb_k, 0);
+      g1_xyzz mine = acc;  // copy: keeps the complete adder's operands addressable
+      xyzz_madd(mine, kx, ky);
+      acc = mine;
+    }
     g1_compress_xyzz28(tmp, out_affine96 ? aff : nullptr, acc);  // inversion in the radix-2^28 field (g1_decode28.cuh)
   }
   if (out48) {

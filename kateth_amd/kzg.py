@@ -114,6 +114,8 @@ _SIGNATURES = {
     "kzg_ctx_create": (ctypes.c_int32, [_u8p, _u8p, ctypes.POINTER(_Config), ctypes.POINTER(ctypes.c_void_p)]),
     "kzg_ctx_destroy": (None, [ctypes.c_void_p]),
     "kzg_ctx_window_bits": (ctypes.c_int32, [ctypes.c_void_p]),
+    "kzg_ctx_msm_kernel_name": (ctypes.c_char_p, [ctypes.c_void_p]),
+    "kzg_ctx_plane_groups": (ctypes.c_int32, [ctypes.c_void_p]),
     "kzg_ctx_table_bytes": (ctypes.c_uint64, [ctypes.c_void_p]),
     "kzg_blob_to_commitment_batch": (ctypes.c_int32, [ctypes.c_void_p, _u8p, ctypes.c_uint64, _u8p, _i32p]),
     "kzg_blob_to_commitment_batch_dev": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
@@ -365,6 +367,14 @@ class Setup:
     @property
     def window_bits(self) -> int:
         return self._lib.kzg_ctx_window_bits(self._h)
+
+    @property
+    def plane_groups(self) -> int:
+        return self._lib.kzg_ctx_plane_groups(self._h)
+
+    @property
+    def msm_kernel_name(self) -> str:
+        return self._lib.kzg_ctx_msm_kernel_name(self._h).decode()
 
     @property
     def table_bytes(self) -> int:
@@ -627,7 +637,7 @@ class Setup:
     def profile_begin(self):
         self._check(self._lib.kzg_profile_begin(self._h), "kzg_profile_begin")
 
-    PROF_KINDS = 7  # KZG_PROF_KINDS
+    PROF_KINDS = 8  # KZG_PROF_KINDS
 
     def profile_end(self) -> dict:
         """HIP-event kernel times since profile_begin: {"msm_ms", "msm_launches", "adds_per_blob", "kinds": {name: (ms, launches)}}."""
@@ -635,6 +645,7 @@ class Setup:
         cnt = (ctypes.c_uint64 * self.PROF_KINDS)()
         self._check(self._lib.kzg_profile_end_kinds(self._h, ms, cnt), "kzg_profile_end_kinds")
         kinds = {self._lib.kzg_profile_kind_name(k).decode(): (ms[k], cnt[k]) for k in range(self.PROF_KINDS)}
+        kinds[self.msm_kernel_name] = kinds.pop(self._lib.kzg_profile_kind_name(0).decode())  # the fixed-base MSM kernel this context runs
         return {"msm_ms": ms[0], "msm_launches": cnt[0], "adds_per_blob": self._lib.kzg_ctx_adds_per_blob(self._h), "kinds": kinds}
 
     def selftest_field_mul(self, lanes: int, iters: int) -> int:

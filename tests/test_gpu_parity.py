@@ -64,7 +64,7 @@ def test_native_library_is_loaded(engine):
     assert engine.window_bits == 8 and engine.table_bytes > 0
     # the product library carries ONE fixed-base MSM kernel (the 32-bit-limb one lives in the test-only build)
     syms = subprocess.check_output(["strings", kateth_amd.library_path()], text=True)
-    assert "k_msm_fixed28" in syms and "k_msm_fixedILb" not in syms
+    assert "k_msm_comb28" in syms and "k_msm_fixedILb" not in syms
 
 
 def test_commitment_known_answers(engine):
@@ -170,7 +170,7 @@ def test_commitment_linearity_at_batch_size(engine, torch_cuda):
 
 
 def test_window_sizes_agree(golden):
-    """the production window (default) and a tiny window give identical bytes."""
+    """two small table classes (blocks of 4 and of 8 points) give identical bytes."""
     import kateth_amd
 
     blobs = b"".join(synth_blob(rec["index"]) for rec in golden["blobs"][:2])
@@ -587,23 +587,27 @@ def test_evaluation_kernel_group_shapes_agree(engine, golden, torch_cuda, monkey
     assert zy["16"] == zy["64"]  # both shapes: the same challenges and evaluations, byte for byte
 
 
-def test_radix28_and_radix32_kernels_agree_at_scale(torch_cuda, monkeypatch):
-    """4,096 random blobs through both MSM kernels (12 x 32-bit limbs vs carry-free radix 2^28) must give identical
-    commitments: 5e8 mixed additions, i.e. a few thousand trips through the radix-2^28 kernel's out-of-line complete adder
-    (its cheap "P == +-Q?" filter fires for 2^-17 of all additions) beside the inline path"""
+def test_comb_and_window_table_kernels_agree_at_scale(torch_cuda, monkeypatch):
+    """4,096 random blobs through three independent fixed-base MSMs must give identical commitments: the product's
+    subset-sum comb (msm_comb.cuh), and -- from the TEST-ONLY build (tests/window_msm, -DKZG_TEST_WINDOW_MSM) -- round 1's
+    window-table kernels on radix-2^28 limbs and on 12 x 32-bit limbs.  Different tables, different recodings (signed bits
+    vs signed windows), different field representations: 2e8 - 5e8 mixed additions each, including the few thousand that
+    take the out-of-line complete adder."""
     import kateth_amd
-
     import __graft_entry__ as g
 
     torch = torch_cuda
     n = 4096
     d_blobs = torch.empty(n * 131072, dtype=torch.uint8, device="cuda")
     outs = []
-    for radix in ("28", "32"):
-        # radix 28 = the product library; radix 32 = the test-only build (tests/radix32) that still carries the round-1 kernel
-        monkeypatch.setenv("KATETH_AMD_MSM_RADIX", radix)
-        s = kateth_amd.Setup.load_json(TRUSTED_SETUP, window_bits=8, lib_path=g.TEST_LIB_RADIX32 if radix == "32" else None)
+    for env, lib in (({}, None), ({"KATETH_AMD_MSM": "window"}, g.TEST_LIB_WINDOW_MSM), ({"KATETH_AMD_MSM_RADIX": "32"}, g.TEST_LIB_WINDOW_MSM)):
+        for k in ("KATETH_AMD_MSM", "KATETH_AMD_MSM_RADIX"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        s = kateth_amd.Setup.load_json(TRUSTED_SETUP, window_bits=8, lib_path=lib)
         try:
+            assert s.msm_kernel_name == {0: "k_msm_comb28", 1: "k_msm_fixed28", 2: "k_msm_fixed"}[len(outs)]
             if not outs:
                 s.synth_blobs_dev(0x5CA1E, 0, n, d_blobs.data_ptr())
             d_c = torch.empty(n * 48, dtype=torch.uint8, device="cuda")
@@ -614,8 +618,35 @@ def test_radix28_and_radix32_kernels_agree_at_scale(torch_cuda, monkeypatch):
             outs.append(d_c.cpu().numpy().tobytes())
         finally:
             s.close()
-    assert outs[0] == outs[1]
+    assert outs[0] == outs[1] == outs[2]
     assert len(set(outs[0][48 * i:48 * i + 48] for i in range(n))) == n  # all distinct: nothing degenerate was compared
+
+
+def test_comb_geometries_agree(golden, torch_cuda, monkeypatch):
+    """every comb geometry -- blocks of 4, 8, 16 points and 1 to 16 plane groups, whole-blob waves and every split the
+    geometry allows (a single blob uses the largest) -- gives the golden commitments and proofs"""
+    import kateth_amd
+
+    recs = golden["blobs"][:3]
+    blobs = b"".join(synth_blob(r["index"]) for r in recs)
+    cs = b"".join(bytes.fromhex(r["commitment"]) for r in recs)
+    for wb, groups in ((4, 16), (4, 1), (8, 2), (8, 4), (8, 8), (8, 16), (16, 4)):
+        monkeypatch.setenv("KATETH_AMD_COMB_GROUPS", str(groups))
+        for splits in (None, 1, 2, 4):
+            if splits is None:
+                monkeypatch.delenv("KATETH_AMD_MSM_SPLITS", raising=False)
+            else:
+                monkeypatch.setenv("KATETH_AMD_MSM_SPLITS", str(splits))
+            s = kateth_amd.Setup.load_json(TRUSTED_SETUP, window_bits=wb)
+            try:
+                assert s.plane_groups == groups and s.window_bits == wb
+                out, st = s.blob_to_commitment_batch(blobs)
+                assert st == [0, 0, 0] and out == cs, (wb, groups, splits)
+                assert s.blob_to_commitment(blobs[:131072]) == cs[:48]
+                proofs, st = s.compute_blob_proof_batch(blobs[:131072], cs[:48])
+                assert st == [0] and proofs.hex() == recs[0]["proof"], (wb, groups, splits)
+            finally:
+                s.close()
 
 
 def test_host_buffer_commitment_pipeline_matches_device_path(engine, torch_cuda):
@@ -666,14 +697,14 @@ def test_mid_size_batches_take_the_unfused_preparation_path(engine, torch_cuda):
 
 
 def test_radix32_msm_kernel_is_bit_exact(golden, monkeypatch):
-    """the test-only build (tests/radix32, -DKZG_TEST_RADIX32) with KATETH_AMD_MSM_RADIX=32 runs the 12 x 32-bit-limb MSM
-    kernel over a 2^384-Montgomery table -- an independent implementation of the same sum; the product library carries only
-    the radix-2^28 kernel (fp28.cuh).  Both must produce the same bytes (the rest of this file runs the product)."""
+    """the test-only build (tests/window_msm, -DKZG_TEST_WINDOW_MSM) with KATETH_AMD_MSM_RADIX=32 runs round 1's 12 x 32-bit-limb
+    window-table MSM kernel over a 2^384-Montgomery table -- an independent implementation of the same sum; the product
+    library carries only the comb kernel (msm_comb.cuh).  Same bytes (the rest of this file runs the product)."""
     import kateth_amd
     import __graft_entry__ as g
 
     monkeypatch.setenv("KATETH_AMD_MSM_RADIX", "32")
-    s = kateth_amd.Setup.load_json(TRUSTED_SETUP, window_bits=7, lib_path=g.TEST_LIB_RADIX32)
+    s = kateth_amd.Setup.load_json(TRUSTED_SETUP, window_bits=7, lib_path=g.TEST_LIB_WINDOW_MSM)
     try:
         recs = golden["blobs"][:3]
         blobs = b"".join(synth_blob(r["index"]) for r in recs) + be32(1) * 4096 + bytes(131072) + be32(R - 1) * 4096
@@ -704,9 +735,10 @@ def cport_setup():
     cs.close()
 
 
-@pytest.mark.parametrize("window_bits", [14, 16])
+@pytest.mark.parametrize("window_bits", [16, 22])
 def test_production_windows_against_golden_and_c_port(window_bits, golden, torch_cuda, cport_setup):
-    """c = 14 (kzg_ctx_create's default) and c = 16 (bench.py's window: 192 GiB table): commitments and proofs of the six
+    """the table classes the library and bench.py really use -- 16 (kzg_ctx_create's default: comb blocks of 16 points, 16 plane
+    groups, 12.9 GB) and 22 (bench.py: blocks of 22 + 21 + 21, 8 plane groups, 192 GiB): commitments and proofs of the six
     golden blobs equal the golden vectors; commitments of 96 synthetic blobs equal the C port of the reference's CPU path
     (oracle/cport, Pippenger c = 10 -- a different algorithm over the same points); for all 96 the challenge z and the
     evaluation y the engine derives equal the C port's, and commit -> prove -> verify closes, so the proofs are the
@@ -719,7 +751,8 @@ def test_production_windows_against_golden_and_c_port(window_bits, golden, torch
     s = kateth_amd.Setup.load_json(TRUSTED_SETUP, window_bits=window_bits)
     try:
         assert s.window_bits == window_bits
-        assert s.table_bytes == {14: 4096 * (18 * 8192 + 8) * 96, 16: 4096 * (16 * 32768) * 96}[window_bits]  # 54 GiB / 192 GiB
+        assert s.plane_groups == {16: 16, 22: 8}[window_bits]
+        assert s.table_bytes == s.plane_groups * 64 * {16: 4 << 15, 22: 1 << 22}[window_bits] * 96  # 12.9 GB / 192 GiB
         n = 96
         d_blobs = torch.empty(n * 131072, dtype=torch.uint8, device="cuda")
         s.synth_blobs_dev(golden["seed"], 0, n, d_blobs.data_ptr())
@@ -1112,7 +1145,7 @@ def test_bench_rank_launcher_two_real_engine_ranks_on_one_card(workload):
     rec = json.loads(out.stdout.strip().splitlines()[-1])
     assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0
     assert rec["config"]["blobs_per_gpu"] == 96 and rec["config"]["backend"] == "gloo"
-    assert rec["roofline"]["kernel"] == ("k_msm_fixed28" if workload == "commit" else "k_challenge*")
+    assert rec["roofline"]["kernel"] == ("k_msm_comb28" if workload == "commit" else "k_challenge*")
     # a rendezvous that disagrees with --gpus must fail loudly instead of silently running one rank
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], capture_output=True, text=True, timeout=120,
                          env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))

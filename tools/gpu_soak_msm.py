@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Soak: commitments (and proofs) of many random batches through the radix-2^28 MSM kernel against the 12 x 32-bit-limb
-kernel, byte for byte.  Every batch of 4,096 blobs at c = 12 is 3.7e8 mixed additions, ~2,800 of which take the
-radix-2^28 kernel's out-of-line complete adder (false alarms of its cheap P == +-Q filter)."""
+"""Soak: commitments (and proofs) of many random batches through the product's comb MSM kernel against round 1's window-table
+kernel on 12 x 32-bit limbs (test-only build), byte for byte.  Every batch of 4,096 blobs is 2-3.7e8 mixed additions per
+engine, a few thousand of which take the out-of-line complete adder (false alarms of the cheap P == +-Q filter)."""
 import os
 import sys
 import time
@@ -17,9 +17,9 @@ batches = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 n = 4096
 import __graft_entry__ as g  # noqa: E402
 
-s28 = kateth_amd.Setup.load_json(SETUP, window_bits=12)  # the product library: radix-2^28 kernel only
-os.environ["KATETH_AMD_MSM_RADIX"] = "32"  # honoured only by the test-only build (tests/radix32, -DKZG_TEST_RADIX32)
-s32 = kateth_amd.Setup.load_json(SETUP, window_bits=12, lib_path=g.TEST_LIB_RADIX32)
+s28 = kateth_amd.Setup.load_json(SETUP, window_bits=16)  # the product library: comb kernel (blocks of 16 points)
+os.environ["KATETH_AMD_MSM_RADIX"] = "32"  # honoured only by the test-only build (tests/window_msm, -DKZG_TEST_WINDOW_MSM)
+s32 = kateth_amd.Setup.load_json(SETUP, window_bits=12, lib_path=g.TEST_LIB_WINDOW_MSM)
 d_blobs = torch.empty(n * 131072, dtype=torch.uint8, device="cuda")
 bufs = [torch.empty(n * 48, dtype=torch.uint8, device="cuda") for _ in range(4)]
 d_st = torch.empty(n, dtype=torch.int32, device="cuda")
