@@ -171,7 +171,7 @@ static int32_t msm_launch(const kzg_ctx* ctx, const uint8_t* d_scalars, uint64_t
     uint64_t* masks = reinterpret_cast<uint64_t*>(scratch);
     {
       ProfScope ps(ctx, PROF_TRANSPOSE, st);
-      hipLaunchKernelGGL((k_comb_transpose<BE_BYTES>), dim3((unsigned)(n * 64)), dim3(64), 0, st, d_scalars, n, masks, d_status);
+      hipLaunchKernelGGL((k_comb_transpose<BE_BYTES>), dim3((unsigned)(n * 8)), dim3(512), 0, st, d_scalars, n, masks, d_status);
     }
     ProfScope ps(ctx, PROF_MSM_FIXED, st);
     hipLaunchKernelGGL(k_msm_comb28, dim3((unsigned)(n * splits)), dim3(64), 0, st, masks, splits, ctx->d_table, ctx->comb, partials);

@@ -17,7 +17,7 @@
 //     that overhead small the planes are cut into G groups of H = 256/G, each with its OWN table built on 2^(H g) L_i/2,
 //     so a lane only walks H planes (H - 1 doublings against H x blocks-per-lane additions) and the lane sums of a
 //     blob add up without any scaling: G = 4 -> 103 GB, 63 doublings per 768 additions.
-// The bit planes come from a transposition kernel (k_comb_transpose: the blob as a 64 x 256 array of 64-bit masks, one
+// The bit planes come from a transposition kernel (k_comb_transpose: the blob as a 256 x 64 array of 64-bit masks, one
 // mask = bit k of 64 consecutive scalars; it also performs Blob::from_slice's canonicity check, src/blob.rs:26-37).
 //
 // Work decomposition: one wave per (blob, split); lane = (plane group, block owner).  The hot loop is the radix-2^28
@@ -73,19 +73,23 @@ __device__ __forceinline__ uint64_t wave_transpose64(uint64_t x, int lane) {
   return x;
 }
 
-// One wave per (blob, 64-point chunk q): masks[(blob * 64 + q) * 256 + k] = bit k of scalars 64q .. 64q+63 (bit p of the
-// mask = point 64q + p).  BE_BYTES: raw blob bytes, validated here (Blob::from_slice, src/blob.rs:26-37); a
-// non-canonical element is treated as 0 and the blob's status is set.
+// One 512-thread workgroup per (blob, 8 chunks): wave v transposes chunk q = 8 * (block % 8) + v (64 consecutive scalars);
+// masks[(blob * 256 + k) * 64 + q] = bit k of scalars 64q .. 64q+63 (bit p of the mask = point 64q + p).  The [plane][chunk]
+// layout is what the MSM reads contiguously (a lane's chunks of one plane are adjacent, the lanes of a plane group cover
+// a whole 512-byte row); the eight waves exchange through LDS so that every row segment is written as one 64-byte piece.
+// BE_BYTES: raw blob bytes, validated here (Blob::from_slice, src/blob.rs:26-37); a non-canonical element is treated as
+// 0 and the blob's status is set.
 template <bool BE_BYTES>
-static __global__ __launch_bounds__(64) void k_comb_transpose(const uint8_t* __restrict__ scalars, uint64_t n, uint64_t* __restrict__ masks,
-                                                              int32_t* __restrict__ status) {
-  const int lane = threadIdx.x;
-  const uint64_t unit = blockIdx.x;
-  const uint64_t blob = unit >> 6;
-  const uint32_t q = (uint32_t)(unit & 63u);
+static __global__ __launch_bounds__(512) void k_comb_transpose(const uint8_t* __restrict__ scalars, uint64_t n, uint64_t* __restrict__ masks,
+                                                               int32_t* __restrict__ status) {
+  __shared__ uint64_t tile[256][8];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wv = tid >> 6;
+  const uint64_t blob = blockIdx.x >> 3;
+  const uint32_t q0 = (uint32_t)(blockIdx.x & 7u) * 8u;
   if (blob >= n) return;
   uint32_t sc[8];
-  load_scalar<BE_BYTES>(sc, scalars + blob * (uint64_t)KZG_BYTES_PER_BLOB_ + (uint64_t)(q * 64u + (uint32_t)lane) * 32u);
+  load_scalar<BE_BYTES>(sc, scalars + blob * (uint64_t)KZG_BYTES_PER_BLOB_ + (uint64_t)((q0 + (uint32_t)wv) * 64u + (uint32_t)lane) * 32u);
   bool bad = false;
   if (BE_BYTES) {
     fr_t v;
@@ -97,11 +101,18 @@ static __global__ __launch_bounds__(64) void k_comb_transpose(const uint8_t* __r
       for (int w = 0; w < 8; w++) sc[w] = 0;
     }
   }
-  uint64_t* out = masks + unit * 256u;
 #pragma unroll
   for (int w = 0; w < 4; w++) {
     const uint64_t row = ((uint64_t)sc[2 * w + 1] << 32) | sc[2 * w];
-    out[64 * w + lane] = wave_transpose64(row, lane);
+    tile[64 * w + lane][wv] = wave_transpose64(row, lane);
+  }
+  __syncthreads();
+  {
+    const int k = tid >> 1, part = tid & 1;  // 256 planes x two 32-byte halves of the 64-byte row segment
+    uint4* dst = reinterpret_cast<uint4*>(masks + (blob * 256u + (uint64_t)k) * 64u + q0 + 4u * (uint32_t)part);
+    const uint4* src = reinterpret_cast<const uint4*>(&tile[k][4 * part]);
+    dst[0] = src[0];
+    dst[1] = src[1];
   }
   if (BE_BYTES) {
     if (__any(bad) && lane == 0) atomicOr(&status[blob], KZG_ERR_BLOB_INVALID_FIELD_ELEMENT);
@@ -125,7 +136,7 @@ static __global__ __launch_bounds__(64, 2) void k_msm_comb28(const uint64_t* __r
   const uint32_t owner = split * g.lpg + (uint32_t)lane % g.lpg;
   const uint32_t bpo = (64u * g.nb) / (splits * g.lpg);
   const uint32_t b0 = owner * bpo;
-  const uint64_t* mrow = masks + blob * (64u * 256u);
+  const uint64_t* mrow = masks + blob * (64u * 256u);  // [plane][chunk]
   const uint32_t kbase = grp * g.H;
   const uint4* tgrp = table + (uint64_t)grp * g.epg * 6u;
   const uint32_t total = g.H * bpo;
@@ -154,7 +165,7 @@ static __global__ __launch_bounds__(64, 2) void k_msm_comb28(const uint64_t* __r
     }
   };
   // pipeline registers: m1 = mask of step t+1 with its walker position p1; (nx, ny) = table entry of step t
-  uint64_t m1 = mrow[w.q * 256u + kbase + w.h];
+  uint64_t m1 = mrow[(kbase + w.h) * 64u + w.q];
   CombWalker p1 = w;
   advance();
   fp_t nx, ny;
@@ -171,7 +182,7 @@ static __global__ __launch_bounds__(64, 2) void k_msm_comb28(const uint64_t* __r
   };
   gather();
   if (total > 1u) {
-    m1 = mrow[w.q * 256u + kbase + w.h];
+    m1 = mrow[(kbase + w.h) * 64u + w.q];
     p1 = w;
     advance();
   }
@@ -185,7 +196,7 @@ static __global__ __launch_bounds__(64, 2) void k_msm_comb28(const uint64_t* __r
     if (t + 1u < total) {
       gather();
       if (t + 2u < total) {
-        m1 = mrow[w.q * 256u + kbase + w.h];
+        m1 = mrow[(kbase + w.h) * 64u + w.q];
         p1 = w;
         advance();
       }

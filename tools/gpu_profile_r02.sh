@@ -13,7 +13,7 @@ run() {  # name, rocprof args..., -- bench args
   echo "[profile] $name" >&2
   rocprofv3 "$@" > $OUT/$name.log 2>&1 || { tail -5 $OUT/$name.log; exit 1; }
 }
-WIN=${WIN:-16}
+WIN=${WIN:-22}
 run trace_default --kernel-trace --stats --output-format csv -d $OUT/trace_default -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --window-bits $WIN
 run trace_commit --kernel-trace --stats --output-format csv -d $OUT/trace_commit -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extra --window-bits $WIN
 run trace_proof --kernel-trace --stats --output-format csv -d $OUT/trace_proof -- python3 $R/bench.py --workload proof --steps 5 --warmup 1 --no-cpu-baseline --window-bits $WIN

@@ -32,7 +32,7 @@ def main(out):
                 a[0] += float(row["Counter_Value"])
                 a[1] += 1
         summary[os.path.basename(d)] = {k: {c: {"per_launch": v[0] / v[1], "launches": v[1]} for c, v in cs.items()} for k, cs in acc.items()
-                                        if re.search(r"msm_fixed|challenge|eval_frac|decompress|var_|poly|reduce|compress|transcript|batch_", k)}
+                                        if re.search(r"msm_fixed|comb|challenge|eval_frac|decompress|var_|poly|reduce|compress|transcript|batch_", k)}
     json.dump(summary, open(os.path.join(out, "summary_pmc.json"), "w"), indent=1, sort_keys=True)
     for name, kernels in summary.items():
         for k, cs in sorted(kernels.items()):
