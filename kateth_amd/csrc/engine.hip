@@ -171,6 +171,7 @@ EnvKnobs read_env_knobs() {
     if (const char* e = getenv("KATETH_AMD_EVAL_GROUP")) k.eval_group = atoi(e);
     k.verify_serial = getenv("KATETH_AMD_VERIFY_SERIAL") != nullptr;
     if (const char* e = getenv("KATETH_AMD_VERIFY_CHUNK")) k.verify_chunk = (uint64_t)atoll(e) > 0 ? (uint64_t)atoll(e) : 0;
+    k.comb_full_wave = getenv("KATETH_AMD_COMB_FULL_WAVE") != nullptr;
     if (const char* e = getenv("KATETH_AMD_MSM_SPLITS")) {
       const int v = atoi(e);
       if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) k.msm_splits = (uint32_t)v;
@@ -564,13 +565,13 @@ static int32_t commit_host(const kzg_ctx* ctx, const uint8_t* blobs, uint64_t n,
           rc = fail(KZG_FAIL_HIP, "host-to-device copy failed");
           break;
         }
-        rc = msm_launch<true>(ctx, stage[slot], m, d_status + base, partials + (size_t)off * splits * 64, splits,
+        rc = msm_launch<true>(ctx, stage[slot], m, d_status + base, partials + (size_t)off * splits * 64, splits, 64,
                               msm_scratch + (size_t)slot * msm_scratch_bytes(ctx, chunk), comp_st);
         if (rc == 0 && hipEventRecord(done[slot], comp_st) != hipSuccess) rc = fail(KZG_FAIL_HIP, "event record failed");
       }
       if (rc == 0)
         rc = msm_finish(ctx, gm, d_out ? d_out + gbase * 48 : nullptr, d_aff ? d_aff + gbase * 96 : nullptr, d_status + gbase, partials, sums, splits,
-                        comp_st);
+                        64, comp_st);
     }
     if (rc) break;
     rc = ws_release(ctx, comp_st);

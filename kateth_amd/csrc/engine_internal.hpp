@@ -38,6 +38,7 @@ struct EnvKnobs {
   int eval_group = 0;            // KATETH_AMD_EVAL_GROUP: 16 | 64 (0 = automatic)
   bool verify_serial = false;    // KATETH_AMD_VERIFY_SERIAL
   uint64_t verify_chunk = 0;     // KATETH_AMD_VERIFY_CHUNK: blobs per host-buffer staging chunk (0 = default)
+  bool comb_full_wave = false;   // KATETH_AMD_COMB_FULL_WAVE: never use the comb's two-blobs-per-wave mode (measurement aid)
   uint32_t msm_splits = 0;       // KATETH_AMD_MSM_SPLITS: force the (blob, split) decomposition of the fixed-base MSM (power of two <= 64; 0 = automatic)
   uint64_t challenge_split_max = 0;  // KATETH_AMD_CHALLENGE_SPLIT_MAX: largest batch hashed by the two-wave SHA-256 kernel (0 = default)
 };
@@ -159,6 +160,15 @@ static inline void launch_challenge_and_decode(const kzg_ctx* ctx, hipStream_t s
                      n_b, status_b, affine, inf);
 }
 
+// The comb's half-wave mode: once a batch fills the chip with two blobs per wave, a blob takes 32 lanes (each lane owns
+// twice the blocks for the same number of Horner doublings).  Units = waves of the MSM kernel = rows of 64 lane sums.
+static inline uint32_t msm_lanes_per_blob(const kzg_ctx* ctx, uint64_t n, uint32_t splits) {
+  if (!ctx->use_comb || splits != 1 || ctx->knobs.comb_full_wave) return 64;
+  if (ctx->comb.G > 32 || (64u * ctx->comb.nb) % (32u / ctx->comb.G) != 0) return 64;
+  return n >= (uint64_t)ctx->num_cus * 16 ? 32 : 64;  // 2 waves per SIMD x 4 SIMDs x 2 blobs per wave
+}
+static inline uint64_t msm_units(uint64_t n, uint32_t splits, uint32_t lpb) { return lpb == 64 ? n * splits : (n + 1) / 2; }
+
 // Scratch the fixed-base MSM needs besides the lane sums: the comb's bit-plane masks (the blob transposed, 128 KiB per blob).
 static inline size_t msm_scratch_bytes(const kzg_ctx* ctx, uint64_t n) { return ctx->use_comb ? (size_t)n * KZG_BYTES_PER_BLOB : 0; }
 
@@ -166,7 +176,7 @@ static inline size_t msm_scratch_bytes(const kzg_ctx* ctx, uint64_t n) { return 
 // partials[unit * 64 + lane].  `scratch`: msm_scratch_bytes(ctx, n) bytes.
 template <bool BE_BYTES>
 static int32_t msm_launch(const kzg_ctx* ctx, const uint8_t* d_scalars, uint64_t n, int32_t* d_status, g1_xyzz* partials, uint32_t splits,
-                          void* scratch, hipStream_t st) {
+                          uint32_t lpb, void* scratch, hipStream_t st) {
   if (ctx->use_comb) {
     uint64_t* masks = reinterpret_cast<uint64_t*>(scratch);
     {
@@ -174,7 +184,7 @@ static int32_t msm_launch(const kzg_ctx* ctx, const uint8_t* d_scalars, uint64_t
       hipLaunchKernelGGL((k_comb_transpose<BE_BYTES>), dim3((unsigned)(n * 8)), dim3(512), 0, st, d_scalars, n, masks, d_status);
     }
     ProfScope ps(ctx, PROF_MSM_FIXED, st);
-    hipLaunchKernelGGL(k_msm_comb28, dim3((unsigned)(n * splits)), dim3(64), 0, st, masks, splits, ctx->d_table, ctx->comb, partials);
+    hipLaunchKernelGGL(k_msm_comb28, dim3((unsigned)msm_units(n, splits, lpb)), dim3(64), 0, st, masks, n, splits, lpb, ctx->d_table, ctx->comb, partials);
     HIP_TRY(hipGetLastError());
     return 0;
   }
@@ -197,10 +207,11 @@ static int32_t msm_launch(const kzg_ctx* ctx, const uint8_t* d_scalars, uint64_t
 // of a blob -- 6 + log2(splits) levels of latency instead of the splits + 5 a sequential walk over the splits costs (a
 // single blob uses 64 splits).  `partials` must have room for n * splits unit sums after the n * splits * 64 lane sums.
 static inline int32_t msm_finish(const kzg_ctx* ctx, uint64_t n, uint8_t* d_out48, uint8_t* d_out_affine96, const int32_t* d_status, g1_xyzz* partials,
-                                 g1_xyzz* sums, uint32_t splits, hipStream_t st) {
+                                 g1_xyzz* sums, uint32_t splits, uint32_t lpb, hipStream_t st) {
   ProfScope ps(ctx, PROF_REDUCE_COMPRESS, st);
   g1_xyzz* unit_sums = (splits == 1) ? sums : partials + (size_t)n * splits * 64;
-  hipLaunchKernelGGL(k_msm_reduce, dim3((unsigned)(n * splits)), dim3(64), 0, st, partials, n * splits, unit_sums);
+  const uint64_t units = msm_units(n, splits, lpb);
+  hipLaunchKernelGGL(k_msm_reduce, dim3((unsigned)units), dim3(64), 0, st, partials, units, lpb, unit_sums);
   if (splits > 1) hipLaunchKernelGGL(k_msm_reduce_splits, dim3((unsigned)n), dim3(64), 0, st, unit_sums, splits, n, sums);
   hipLaunchKernelGGL(k_g1_compress, dim3(blocks_for(n, 64)), dim3(64), 0, st, sums, n, d_status, d_out48, d_out_affine96, ctx->use_comb ? ctx->d_comb_k : (const uint4*)nullptr);
   HIP_TRY(hipGetLastError());
@@ -210,7 +221,8 @@ static inline int32_t msm_finish(const kzg_ctx* ctx, uint64_t n, uint8_t* d_out4
 template <bool BE_BYTES>
 static int32_t msm_pipeline(const kzg_ctx* ctx, const uint8_t* d_scalars, uint64_t n, uint8_t* d_out48, uint8_t* d_out_affine96, int32_t* d_status,
                             g1_xyzz* partials, g1_xyzz* sums, uint32_t splits, void* scratch, hipStream_t st) {
-  int32_t rc = msm_launch<BE_BYTES>(ctx, d_scalars, n, d_status, partials, splits, scratch, st);
+  const uint32_t lpb = msm_lanes_per_blob(ctx, n, splits);
+  int32_t rc = msm_launch<BE_BYTES>(ctx, d_scalars, n, d_status, partials, splits, lpb, scratch, st);
   if (rc) return rc;
-  return msm_finish(ctx, n, d_out48, d_out_affine96, d_status, partials, sums, splits, st);
+  return msm_finish(ctx, n, d_out48, d_out_affine96, d_status, partials, sums, splits, lpb, st);
 }

@@ -124,17 +124,28 @@ struct CombWalker {
   uint32_t h, s, q, r;
 };
 
-// One wave per (blob, split).  lane = (group, owner): group grp = lane / lpg walks planes [grp H, grp H + H) of its own
-// table; owner = split * lpg + lane % lpg owns blocks [owner * bpo, owner * bpo + bpo) of the 64 nb blocks.
-static __global__ __launch_bounds__(64, 2) void k_msm_comb28(const uint64_t* __restrict__ masks, uint32_t splits, const uint4* __restrict__ table,
-                                                             CombGeom g, g1_xyzz* __restrict__ partials) {
+// One wave per unit.  lpb = 64 lanes per blob: unit = (blob, split).  lpb = 32 (large batches, splits = 1): a wave carries
+// TWO blobs on its two halves -- every lane owns twice the blocks for the same H - 1 doublings, which halves the Horner
+// overhead.  Within a blob's lpb lanes: lane l = (group, owner); group grp = l / (lpb / G) walks planes
+// [grp H, grp H + H) of its own table; owner = split * (lpb / G) + l % (lpb / G) owns blocks [owner * bpo, owner * bpo + bpo)
+// of the 64 nb blocks.
+static __global__ __launch_bounds__(64, 2) void k_msm_comb28(const uint64_t* __restrict__ masks, uint64_t n, uint32_t splits, uint32_t lpb,
+                                                             const uint4* __restrict__ table, CombGeom g, g1_xyzz* __restrict__ partials) {
   const int lane = threadIdx.x;
   const uint64_t unit = blockIdx.x;
-  const uint64_t blob = unit / splits;
-  const uint32_t split = (uint32_t)(unit % splits);
-  const uint32_t grp = (uint32_t)lane / g.lpg;
-  const uint32_t owner = split * g.lpg + (uint32_t)lane % g.lpg;
-  const uint32_t bpo = (64u * g.nb) / (splits * g.lpg);
+  const uint32_t l = (uint32_t)lane % lpb;
+  const uint64_t blob = (lpb == 64u) ? unit / splits : unit * (64u / lpb) + (uint32_t)lane / lpb;
+  const uint32_t split = (lpb == 64u) ? (uint32_t)(unit % splits) : 0u;
+  if (blob >= n) {  // odd batch in half-wave mode: the idle half contributes the identity
+    g1_xyzz none;
+    xyzz_set_inf(none);
+    partials[unit * 64 + lane] = none;
+    return;
+  }
+  const uint32_t lpg = lpb / g.G;
+  const uint32_t grp = l / lpg;
+  const uint32_t owner = split * lpg + l % lpg;
+  const uint32_t bpo = (64u * g.nb) / (splits * lpg);
   const uint32_t b0 = owner * bpo;
   const uint64_t* mrow = masks + blob * (64u * 256u);  // [plane][chunk]
   const uint32_t kbase = grp * g.H;

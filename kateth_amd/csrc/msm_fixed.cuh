@@ -283,8 +283,9 @@ static __global__ __launch_bounds__(64, 2) void k_msm_fixed28(const uint8_t* __r
 
 #endif  // KZG_TEST_WINDOW_MSM
 
-// One wave per (blob, split) unit: sums the unit's 64 lane partials (6-level tree through LDS).
-static __global__ __launch_bounds__(64) void k_msm_reduce(const g1_xyzz* __restrict__ partials, uint64_t units, g1_xyzz* __restrict__ unit_sums) {
+// One wave per unit: sums the lane partials of each group of `lpb` lanes (64: one sum per unit; 32: the comb's half-wave
+// mode, two blobs per unit) by a tree through LDS; unit_sums[u * (64 / lpb) + lane / lpb].
+static __global__ __launch_bounds__(64) void k_msm_reduce(const g1_xyzz* __restrict__ partials, uint64_t units, uint32_t lpb, g1_xyzz* __restrict__ unit_sums) {
   __shared__ g1_xyzz28 lds[32];
   const int lane = threadIdx.x;
   const uint64_t u = blockIdx.x;
@@ -296,7 +297,7 @@ static __global__ __launch_bounds__(64) void k_msm_reduce(const g1_xyzz* __restr
     xyzz28_from_xyzz(acc, in);
   }
 #pragma unroll 1
-  for (int step = 1; step < 64; step <<= 1) {
+  for (int step = 1; step < (int)lpb; step <<= 1) {
     const int m = 2 * step - 1;
     if ((lane & m) == step) lds[lane >> 1] = acc;
     __syncthreads();
@@ -308,10 +309,10 @@ static __global__ __launch_bounds__(64) void k_msm_reduce(const g1_xyzz* __restr
     }
     __syncthreads();
   }
-  if (lane == 0) {
+  if ((lane & (int)(lpb - 1)) == 0) {
     g1_xyzz out;
     xyzz28_to_xyzz(out, acc);
-    unit_sums[u] = out;
+    unit_sums[u * (64u / lpb) + (uint32_t)lane / lpb] = out;
   }
 }
 // One wave per blob: sums the blob's `splits` (<= 64) unit sums.

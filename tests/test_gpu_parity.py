@@ -1150,3 +1150,30 @@ def test_bench_rank_launcher_two_real_engine_ranks_on_one_card(workload):
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], capture_output=True, text=True, timeout=120,
                          env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
     assert bad.returncode != 0 and "WORLD_SIZE=2" in (bad.stdout + bad.stderr)
+
+
+def test_half_wave_mode_on_an_odd_batch(engine, torch_cuda):
+    """from 4,096 blobs on, the comb MSM carries two blobs per wave (32 lanes each); an odd batch leaves the last wave half
+    empty.  Commitments and proofs of 4,099 blobs equal, item for item, those of the same blobs computed in small batches
+    (one blob per wave / several waves per blob)."""
+    torch = torch_cuda
+    n = 4099
+    d_blobs = torch.empty(n * 131072, dtype=torch.uint8, device="cuda")
+    engine.synth_blobs_dev(0x0DD, 0, n, d_blobs.data_ptr())
+    d_c = torch.empty(n * 48, dtype=torch.uint8, device="cuda")
+    d_p = torch.empty(n * 48, dtype=torch.uint8, device="cuda")
+    d_st = torch.empty(n, dtype=torch.int32, device="cuda")
+    engine.blob_to_commitment_batch_dev(d_blobs.data_ptr(), n, d_c.data_ptr(), d_st.data_ptr())
+    engine.compute_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), n, d_p.data_ptr(), d_st.data_ptr())
+    torch.cuda.synchronize()
+    assert int(d_st.abs().sum()) == 0
+    big_c, big_p = d_c.cpu().numpy().tobytes(), d_p.cpu().numpy().tobytes()
+    for first, m in ((0, 3), (2047, 130), (4090, 9)):
+        c2 = torch.empty(m * 48, dtype=torch.uint8, device="cuda")
+        p2 = torch.empty(m * 48, dtype=torch.uint8, device="cuda")
+        engine.blob_to_commitment_batch_dev(d_blobs.data_ptr() + first * 131072, m, c2.data_ptr(), d_st.data_ptr())
+        engine.compute_blob_proof_batch_dev(d_blobs.data_ptr() + first * 131072, c2.data_ptr(), m, p2.data_ptr(), d_st.data_ptr())
+        torch.cuda.synchronize()
+        assert c2.cpu().numpy().tobytes() == big_c[48 * first:48 * (first + m)], first
+        assert p2.cpu().numpy().tobytes() == big_p[48 * first:48 * (first + m)], first
+    assert engine.verify_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n) is True
