@@ -751,7 +751,7 @@ def test_production_windows_against_golden_and_c_port(window_bits, golden, torch
     s = kateth_amd.Setup.load_json(TRUSTED_SETUP, window_bits=window_bits)
     try:
         assert s.window_bits == window_bits
-        assert s.plane_groups == {16: 16, 22: 8}[window_bits]
+        assert s.plane_groups in {16: (16,), 22: (8, 4)}[window_bits]  # class 22: 8 groups when 192 GiB + headroom are free, else 4
         assert s.table_bytes == s.plane_groups * 64 * {16: 4 << 15, 22: 1 << 22}[window_bits] * 96  # 12.9 GB / 192 GiB
         n = 96
         d_blobs = torch.empty(n * 131072, dtype=torch.uint8, device="cuda")
