@@ -19,11 +19,11 @@ run trace_commit --kernel-trace --stats --output-format csv -d $OUT/trace_commit
 run trace_proof --kernel-trace --stats --output-format csv -d $OUT/trace_proof -- python3 $R/bench.py --workload proof --steps 5 --warmup 1 --no-cpu-baseline --window-bits $WIN
 run trace_verify --kernel-trace --stats --output-format csv -d $OUT/trace_verify -- python3 $R/bench.py --workload verify --steps 5 --warmup 1 --no-cpu-baseline --window-bits $WIN
 [ -n "$TRACE_ONLY" ] && { python3 $R/tools/summarize_profiles.py $OUT; exit 0; }
-run pmc_verify_sq --pmc SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/pmc_verify_sq -- python3 $R/bench.py --workload verify --steps 3 --warmup 1 --no-cpu-baseline --window-bits 12
-run pmc_verify_fetch --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_verify_fetch -- python3 $R/bench.py --workload verify --steps 3 --warmup 1 --no-cpu-baseline --window-bits 12
-run pmc_verify_write --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_verify_write -- python3 $R/bench.py --workload verify --steps 3 --warmup 1 --no-cpu-baseline --window-bits 12
+run pmc_verify_sq --pmc SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/pmc_verify_sq -- python3 $R/bench.py --workload verify --steps 3 --warmup 1 --no-cpu-baseline --window-bits $WIN
+run pmc_verify_fetch --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_verify_fetch -- python3 $R/bench.py --workload verify --steps 3 --warmup 1 --no-cpu-baseline --window-bits $WIN
+run pmc_verify_write --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_verify_write -- python3 $R/bench.py --workload verify --steps 3 --warmup 1 --no-cpu-baseline --window-bits $WIN
 run pmc_commit_sq --pmc SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/pmc_commit_sq -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra --window-bits $WIN
 run pmc_commit_fetch --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_commit_fetch -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra --window-bits $WIN
 run pmc_commit_write --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_commit_write -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra --window-bits $WIN
-run pmc_proof_sq --pmc SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/pmc_proof_sq -- python3 $R/bench.py --workload proof --steps 3 --warmup 1 --no-cpu-baseline --window-bits 12
+run pmc_proof_sq --pmc SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/pmc_proof_sq -- python3 $R/bench.py --workload proof --steps 3 --warmup 1 --no-cpu-baseline --window-bits $WIN
 python3 $R/tools/summarize_profiles.py $OUT
