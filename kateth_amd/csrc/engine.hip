@@ -108,6 +108,18 @@ extern "C" int32_t kzg_profile_begin(const kzg_ctx* ctx) {
 
 static const char* const PROF_NAMES[PROF_KINDS] = {"k_msm_fixed28", "k_challenge*", "k_eval_frac", "k_g1_decompress", "k_poly",
                                                     "k_var_* (two lincombs)", "k_msm_reduce* + k_g1_compress", "k_comb_transpose"};
+#if defined(KZG_TEST_WINDOW_MSM)
+// test build only: {wall-clock start, wall-clock end (100 MHz ticks), shader cycles, XCC_ID << 32 | HW_ID} of each unit of the
+// most recent k_msm_comb28 launch that fitted the buffer
+extern "C" int32_t kzg_test_read_wave_times(const kzg_ctx* ctx, uint64_t* out, uint64_t units) {
+  if (!ctx || !ctx->d_wave_times || units > ctx->wave_times_cap) return fail(KZG_FAIL_ARGUMENT, "no wave-time buffer");
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out, ctx->d_wave_times, units * 32, hipMemcpyDeviceToHost));
+  return 0;
+}
+#endif
+
 extern "C" const char* kzg_ctx_msm_kernel_name(const kzg_ctx* ctx) { return (ctx && !ctx->use_comb) ? (ctx->msm_radix28 ? "k_msm_fixed28" : "k_msm_fixed") : "k_msm_comb28"; }
 extern "C" int32_t kzg_ctx_plane_groups(const kzg_ctx* ctx) { return (ctx && ctx->use_comb) ? (int32_t)ctx->comb.G : 0; }
 extern "C" const char* kzg_profile_kind_name(int32_t kind) { return (kind >= 0 && kind < PROF_KINDS) ? PROF_NAMES[kind] : ""; }
@@ -172,6 +184,7 @@ EnvKnobs read_env_knobs() {
     k.verify_serial = getenv("KATETH_AMD_VERIFY_SERIAL") != nullptr;
     if (const char* e = getenv("KATETH_AMD_VERIFY_CHUNK")) k.verify_chunk = (uint64_t)atoll(e) > 0 ? (uint64_t)atoll(e) : 0;
     k.comb_full_wave = getenv("KATETH_AMD_COMB_FULL_WAVE") != nullptr;
+    if (const char* e = getenv("KATETH_AMD_COMB_FAIR")) k.comb_fair = (uint32_t)atoi(e) < 40u ? (uint32_t)atoi(e) : 0u;
     if (const char* e = getenv("KATETH_AMD_MSM_SPLITS")) {
       const int v = atoi(e);
       if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) k.msm_splits = (uint32_t)v;
@@ -194,6 +207,9 @@ extern "C" void kzg_ctx_destroy(kzg_ctx* ctx) {
   if (ctx->d_eval_tab) (void)hipFree(ctx->d_eval_tab);
   if (ctx->d_gen_affine) (void)hipFree(ctx->d_gen_affine);
   if (ctx->d_comb_k) (void)hipFree(ctx->d_comb_k);
+#if defined(KZG_TEST_WINDOW_MSM)
+  if (ctx->d_wave_times) (void)hipFree(ctx->d_wave_times);
+#endif
   delete ctx->pairing;
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
@@ -426,6 +442,7 @@ extern "C" int32_t kzg_ctx_create(const uint8_t* g1_lagrange, const uint8_t* g2_
     if (const char* e = getenv("KATETH_AMD_COMB_GROUPS")) G = (uint32_t)atoi(e);
     if (!(G == 1 || G == 2 || G == 4 || G == 8 || G == 16)) return fail(KZG_FAIL_ARGUMENT, "plane groups must be 1, 2, 4, 8 or 16");
     ctx->comb = comb_make_geom(nb, G);
+    ctx->comb.fair = read_env_knobs().comb_fair;
     ctx->window_class = window_mode ? c : (nb == 3 ? 22u : 64u / nb);
   }
   if (hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess ||
@@ -441,6 +458,10 @@ extern "C" int32_t kzg_ctx_create(const uint8_t* g1_lagrange, const uint8_t* g2_
   if (!ctx->msm_radix28) {  // the 12 x 32-bit-limb kernel walks round 1's window table
     ctx->use_comb = false;
     ctx->window_class = ctx->geom.c;
+  }
+  if (const char* e = getenv("KATETH_AMD_WAVE_TIMES")) {  // measurement aid (tools/gpu_wave_times.py)
+    ctx->wave_times_cap = (uint64_t)atoll(e);
+    if (ctx->wave_times_cap && hipMalloc(&ctx->d_wave_times, ctx->wave_times_cap * 32) != hipSuccess) ctx->wave_times_cap = 0;
   }
 #endif
   int32_t rc = ctx_build(ctx, g1_lagrange, g2_monomial);

@@ -38,6 +38,7 @@ struct EnvKnobs {
   int eval_group = 0;            // KATETH_AMD_EVAL_GROUP: 16 | 64 (0 = automatic)
   bool verify_serial = false;    // KATETH_AMD_VERIFY_SERIAL
   uint64_t verify_chunk = 0;     // KATETH_AMD_VERIFY_CHUNK: blobs per host-buffer staging chunk (0 = default)
+  uint32_t comb_fair = 20;       // KATETH_AMD_COMB_FAIR=s: the MSM waves of a SIMD trade issue priority every 2^s cycles; 0 = hardware default (measurement aid)
   bool comb_full_wave = false;   // KATETH_AMD_COMB_FULL_WAVE: never use the comb's two-blobs-per-wave mode (measurement aid)
   uint32_t msm_splits = 0;       // KATETH_AMD_MSM_SPLITS: force the (blob, split) decomposition of the fixed-base MSM (power of two <= 64; 0 = automatic)
   uint64_t challenge_split_max = 0;  // KATETH_AMD_CHALLENGE_SPLIT_MAX: largest batch hashed by the two-wave SHA-256 kernel (0 = default)
@@ -74,6 +75,10 @@ struct kzg_ctx {
   uint4* d_table = nullptr;      // fixed-base table: comb (msm_comb.cuh) comb_table_entries(comb) * 96 B, or window table_entries(geom) * 96 B
   bool use_comb = true;          // subset-sum comb MSM; false only in the TEST build (KATETH_AMD_MSM=window / KATETH_AMD_MSM_RADIX=32 there)
   CombGeom comb{};
+#if defined(KZG_TEST_WINDOW_MSM)
+  uint64_t* d_wave_times = nullptr;  // test build, KATETH_AMD_WAVE_TIMES=<units>: per-unit timestamps of the last k_msm_comb28 launch
+  uint64_t wave_times_cap = 0;
+#endif
   uint4* d_comb_k = nullptr;     // the comb's constant term K = [(2^256-1)/2] G, affine, canonical 2^384-Montgomery (96 B)
   uint32_t window_class = 0;     // what kzg_ctx_window_bits reports
   uint4* d_bases_brp = nullptr;  // 4096 affine Lagrange points, BRP order
@@ -184,7 +189,12 @@ static int32_t msm_launch(const kzg_ctx* ctx, const uint8_t* d_scalars, uint64_t
       hipLaunchKernelGGL((k_comb_transpose<BE_BYTES>), dim3((unsigned)(n * 8)), dim3(512), 0, st, d_scalars, n, masks, d_status);
     }
     ProfScope ps(ctx, PROF_MSM_FIXED, st);
+    #if defined(KZG_TEST_WINDOW_MSM)
+    hipLaunchKernelGGL(k_msm_comb28, dim3((unsigned)msm_units(n, splits, lpb)), dim3(64), 0, st, masks, n, splits, lpb, ctx->d_table, ctx->comb, partials,
+                       msm_units(n, splits, lpb) <= ctx->wave_times_cap ? ctx->d_wave_times : (uint64_t*)nullptr);
+#else
     hipLaunchKernelGGL(k_msm_comb28, dim3((unsigned)msm_units(n, splits, lpb)), dim3(64), 0, st, masks, n, splits, lpb, ctx->d_table, ctx->comb, partials);
+#endif
     HIP_TRY(hipGetLastError());
     return 0;
   }

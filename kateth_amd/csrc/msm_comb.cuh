@@ -35,6 +35,7 @@ struct CombGeom {
   uint32_t lpg;   // lanes per group = 64 / G
   uint32_t ep64;  // table entries per 64 points (one group): sum over the blocks of 2^(t-1)
   uint32_t epg;   // entries per group = 64 * ep64
+  uint32_t fair;  // s > 0: the two waves of a SIMD trade issue priority every 2^s shader cycles (k_msm_comb28); 0: hardware default (oldest first)
 };
 
 KZG_HD uint32_t comb_tbits(uint32_t nb, uint32_t r) { return nb == 3u ? (r == 0u ? 22u : 21u) : 64u / nb; }
@@ -50,6 +51,7 @@ KZG_HD CombGeom comb_make_geom(uint32_t nb, uint32_t G) {
   g.lpg = 64u / G;
   g.ep64 = nb == 3u ? (1u << 22) : nb << (64u / nb - 1u);
   g.epg = 64u * g.ep64;
+  g.fair = 20u;
   return g;
 }
 KZG_HD uint64_t comb_table_entries(const CombGeom& g) { return (uint64_t)g.G * g.epg; }
@@ -130,9 +132,17 @@ struct CombWalker {
 // [grp H, grp H + H) of its own table; owner = split * (lpb / G) + l % (lpb / G) owns blocks [owner * bpo, owner * bpo + bpo)
 // of the 64 nb blocks.
 static __global__ __launch_bounds__(64, 2) void k_msm_comb28(const uint64_t* __restrict__ masks, uint64_t n, uint32_t splits, uint32_t lpb,
-                                                             const uint4* __restrict__ table, CombGeom g, g1_xyzz* __restrict__ partials) {
+                                                             const uint4* __restrict__ table, CombGeom g, g1_xyzz* __restrict__ partials
+#if defined(KZG_TEST_WINDOW_MSM)
+                                                             ,
+                                                             uint64_t* __restrict__ wave_times  // test build: {wall start, wall end, cycles, hw id} per unit
+#endif
+) {
   const int lane = threadIdx.x;
   const uint64_t unit = blockIdx.x;
+#if defined(KZG_TEST_WINDOW_MSM)
+  const uint64_t wt_wall0 = wall_clock64(), wt_cyc0 = clock64();
+#endif
   const uint32_t l = (uint32_t)lane % lpb;
   const uint64_t blob = (lpb == 64u) ? unit / splits : unit * (64u / lpb) + (uint32_t)lane / lpb;
   const uint32_t split = (lpb == 64u) ? (uint32_t)(unit % splits) : 0u;
@@ -198,8 +208,22 @@ static __global__ __launch_bounds__(64, 2) void k_msm_comb28(const uint64_t* __r
     advance();
   }
 
+  // Two waves share a SIMD and the instruction arbiter serves the OLDER one first.  Measured per wave (tools/gpu_wave_times.py,
+  // 4,096 blobs = one round of 2,048 waves): the older wave of every pair ran at its solo rate and finished after 18.0 ms, the
+  // younger one took the leftover issue slots and finished after 29.7 ms -- the last 12 ms alone, at 5.3 instead of 4.1 cycles
+  // per instruction.  So the two waves trade priority (s_setprio 3 / 0, keyed on the wave slot's parity) every 2^g.fair
+  // shader cycles; the period is long against a step (the low-priority wave's steps take 4x as long, so with a short period it
+  // notices its turn late: 2^16 left the pair 24.7 / 29.2 ms apart) and short against the kernel.  With 2^20 cycles the pair
+  // ends 27.8 / 28.4 ms and the launch takes 29.2 instead of 30.7 ms (profiles/r02/wave_fairness_sweep.json).
+  const uint32_t prio_parity = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1u;  // hwreg(HW_REG_HW_ID, 0, 4): the wave slot within the SIMD
 #pragma unroll 1
   for (uint32_t t = 0; t < total; t++) {
+    if (g.fair) {
+      if ((((uint32_t)(__builtin_amdgcn_s_memtime() >> g.fair)) & 1u) == prio_parity)
+        __builtin_amdgcn_s_setprio(3);
+      else
+        __builtin_amdgcn_s_setprio(0);
+    }
     fp28 cx, cy;
     f28_load_entry(cx, cy, nx, ny, nneg);
     const bool cneg = nneg, cdbl = ndbl;
@@ -232,6 +256,17 @@ static __global__ __launch_bounds__(64, 2) void k_msm_comb28(const uint64_t* __r
   g1_xyzz out;
   xyzz28_to_xyzz(out, acc);  // back to canonical 2^384-Montgomery limbs for k_msm_reduce
   partials[unit * 64 + lane] = out;
+#if defined(KZG_TEST_WINDOW_MSM)
+  if (wave_times && lane == 0) {
+    uint32_t hwid, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    wave_times[unit * 4 + 0] = wt_wall0;
+    wave_times[unit * 4 + 1] = wall_clock64();
+    wave_times[unit * 4 + 2] = clock64() - wt_cyc0;
+    wave_times[unit * 4 + 3] = ((uint64_t)xcc << 32) | hwid;
+  }
+#endif
 }
 
 // ---- table build -------------------------------------------------------------------------------------------------
