@@ -8,6 +8,7 @@
 // 16 mixed additions of the affine input) -- about 0.65 M VALU instructions against 1.3 M for the 12 x 32-bit-limb path.
 #pragma once
 #include "fp28.cuh"
+#include "issue_fair.cuh"
 
 namespace kzg {
 
@@ -39,6 +40,7 @@ KZG_HD void f28_pow_sched(fp28& r, const fp28& a, const uint8_t* sched, int len,
   for (int i = 0; i < F28_N; i++) acc.l[i] = first == 0 ? t1.l[i] : (first == 1 ? t3.l[i] : (first == 2 ? t5.l[i] : t7.l[i]));
 #pragma unroll 1
   for (int s = 0; s < len; s++) {
+    issue_fair_tick(18);  // one thread per point, two waves per SIMD: see issue_fair.cuh
     const int nsq = sched[2 * s], idx = sched[2 * s + 1];
 #pragma unroll 1
     for (int q = 0; q < nsq; q++) f28_sqr(acc, acc);
@@ -248,6 +250,7 @@ KZG_HD_NOINLINE void g1_mul_by_z2_jac28(g1_jac28& acc, const fp28& x, const fp28
   acc.inf = 0;
 #pragma unroll 1
   for (int i = 126; i >= 0; i--) {
+    issue_fair_tick(18);
     jac28_dbl(acc);  // inline: the accumulator stays in registers over the runs of doublings
     const uint64_t w = i >= 64 ? hi : lo;
     if ((w >> (i & 63)) & 1ull) {

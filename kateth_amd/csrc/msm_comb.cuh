@@ -24,6 +24,7 @@
 // mixed addition of msm_fixed.cuh (xyzz28_madd_fast, fp28.cuh) with the next table entry gathered while the current
 // addition runs, and the mask of the step after that already in flight.
 #pragma once
+#include "issue_fair.cuh"
 #include "msm_fixed.cuh"
 
 namespace kzg {
@@ -208,22 +209,13 @@ static __global__ __launch_bounds__(64, 2) void k_msm_comb28(const uint64_t* __r
     advance();
   }
 
-  // Two waves share a SIMD and the instruction arbiter serves the OLDER one first.  Measured per wave (tools/gpu_wave_times.py,
-  // 4,096 blobs = one round of 2,048 waves): the older wave of every pair ran at its solo rate and finished after 18.0 ms, the
-  // younger one took the leftover issue slots and finished after 29.7 ms -- the last 12 ms alone, at 5.3 instead of 4.1 cycles
-  // per instruction.  So the two waves trade priority (s_setprio 3 / 0, keyed on the wave slot's parity) every 2^g.fair
-  // shader cycles; the period is long against a step (the low-priority wave's steps take 4x as long, so with a short period it
-  // notices its turn late: 2^16 left the pair 24.7 / 29.2 ms apart) and short against the kernel.  With 2^20 cycles the pair
-  // ends 27.8 / 28.4 ms and the launch takes 29.2 instead of 30.7 ms (profiles/r02/wave_fairness_sweep.json).
-  const uint32_t prio_parity = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1u;  // hwreg(HW_REG_HW_ID, 0, 4): the wave slot within the SIMD
+  // The two waves of a SIMD trade issue priority every 2^g.fair shader cycles (issue_fair.cuh).  Measured at 4,096 blobs = one
+  // round of 2,048 waves: left to the hardware the older wave of every pair finished after 18.0 ms and the younger after
+  // 29.7 ms; with a period of 2^16 cycles 24.7 / 29.2 ms (a low-priority wave's steps are 4x as long, it notices its turn
+  // late); with 2^20 cycles 27.8 / 28.4 ms and the launch takes 29.2 instead of 30.7 ms (profiles/r02/wave_fairness_sweep.json).
 #pragma unroll 1
   for (uint32_t t = 0; t < total; t++) {
-    if (g.fair) {
-      if ((((uint32_t)(__builtin_amdgcn_s_memtime() >> g.fair)) & 1u) == prio_parity)
-        __builtin_amdgcn_s_setprio(3);
-      else
-        __builtin_amdgcn_s_setprio(0);
-    }
+    if (g.fair) issue_fair_tick(g.fair);
     fp28 cx, cy;
     f28_load_entry(cx, cy, nx, ny, nneg);
     const bool cneg = nneg, cdbl = ndbl;
