@@ -186,14 +186,37 @@ static __global__ __launch_bounds__(64, 2) void k_msm_comb28(const uint64_t* __r
       w.r = b0 % nb;
     }
   };
-  // pipeline registers: m1 = mask of step t+1 with its walker position p1; (nx, ny) = table entry of step t
-  uint64_t m1 = mrow[(kbase + w.h) * 64u + w.q];
+  // pipeline registers: mb* = mask(s) covering step t+1 with its walker position p1; (nx, ny) = table entry of step t.
+  // A lane's chunks are consecutive, so when they come in aligned groups of four (bpo a multiple of 4 nb: every production
+  // shape) the four masks are ONE 32-byte load per group instead of an 8-byte load per step: with [plane][chunk] rows a
+  // 128-byte line holds 16 chunks of one plane = 4 owners x 4 groups, and the table gathers (20 GB per launch through a
+  // 4-MB L2) evicted it between a lane's visits -- FETCH_SIZE counted 7.9 GB of mask re-fetches per 4,096 blobs.
+  const bool wide = (bpo % (4u * nb)) == 0u;
+  const uint32_t q0 = b0 / nb;
+  uint64_t mb0 = 0, mb1 = 0, mb2 = 0, mb3 = 0;
+  auto fetch_mask = [&]() {  // the mask of the step at w; in wide mode only when w enters a new group of four chunks
+    if (wide) {
+      if (w.r == 0u && ((w.q - q0) & 3u) == 0u) {
+        const uint4* src = reinterpret_cast<const uint4*>(mrow + (kbase + w.h) * 64u + w.q);
+        const uint4 lo = src[0], hi = src[1];
+        mb0 = (uint64_t)lo.x | ((uint64_t)lo.y << 32);
+        mb1 = (uint64_t)lo.z | ((uint64_t)lo.w << 32);
+        mb2 = (uint64_t)hi.x | ((uint64_t)hi.y << 32);
+        mb3 = (uint64_t)hi.z | ((uint64_t)hi.w << 32);
+      }
+    } else {
+      mb0 = mrow[(kbase + w.h) * 64u + w.q];
+    }
+  };
+  fetch_mask();
   CombWalker p1 = w;
   advance();
   fp_t nx, ny;
   bool nneg = false, ndbl = false;
   uint32_t nidx = 0;
-  auto gather = [&]() {  // entry of the step at p1 from its mask m1
+  auto gather = [&]() {  // entry of the step at p1 from its mask
+    const uint32_t k = wide ? ((p1.q - q0) & 3u) : 0u;
+    const uint64_t m1 = k == 0u ? mb0 : (k == 1u ? mb1 : (k == 2u ? mb2 : mb3));
     const uint32_t tb = comb_tbits(nb, p1.r);
     const uint32_t pat = (uint32_t)(m1 >> comb_point_off(nb, p1.r)) & ((1u << tb) - 1u);
     nneg = (pat >> (tb - 1u)) != 0u;  // top sign +1: the table holds the mirrored pattern, negated
@@ -202,9 +225,9 @@ static __global__ __launch_bounds__(64, 2) void k_msm_comb28(const uint64_t* __r
     ndbl = (p1.s == 0u) && (p1.h != g.H - 1u);
     load_affine96(nx, ny, tgrp, nidx);
   };
-  gather();
+  gather();  // always before the next fetch_mask(): a new group's load overwrites masks whose patterns are already cut out
   if (total > 1u) {
-    m1 = mrow[(kbase + w.h) * 64u + w.q];
+    fetch_mask();
     p1 = w;
     advance();
   }
@@ -223,7 +246,7 @@ static __global__ __launch_bounds__(64, 2) void k_msm_comb28(const uint64_t* __r
     if (t + 1u < total) {
       gather();
       if (t + 2u < total) {
-        m1 = mrow[(kbase + w.h) * 64u + w.q];
+        fetch_mask();
         p1 = w;
         advance();
       }
