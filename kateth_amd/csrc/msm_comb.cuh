@@ -16,13 +16,16 @@
 //   * the planes are combined by Horner's rule inside a lane (one doubling of the lane's accumulator per plane).  To keep
 //     that overhead small the planes are cut into G groups of H = 256/G, each with its OWN table built on 2^(H g) L_i/2,
 //     so a lane only walks H planes (H - 1 doublings against H x blocks-per-lane additions) and the lane sums of a
-//     blob add up without any scaling: G = 4 -> 103 GB, 63 doublings per 768 additions.
+//     blob add up without any scaling: G = 8 (bench.py's class 22) -> 192 GiB and 31 doublings per 768 additions of a
+//     64-lane blob (1,536 in half-wave mode); G = 4 -> 96 GiB, 63 doublings, within 1 % of G = 8.
 // The bit planes come from a transposition kernel (k_comb_transpose: the blob as a 256 x 64 array of 64-bit masks, one
 // mask = bit k of 64 consecutive scalars; it also performs Blob::from_slice's canonicity check, src/blob.rs:26-37).
 //
-// Work decomposition: one wave per (blob, split); lane = (plane group, block owner).  The hot loop is the radix-2^28
-// mixed addition of msm_fixed.cuh (xyzz28_madd_fast, fp28.cuh) with the next table entry gathered while the current
-// addition runs, and the mask of the step after that already in flight.
+// Work decomposition: one wave per (blob, split), or per PAIR of blobs from num_CUs x 16 blobs per launch on (half-wave
+// mode: 32 lanes per blob); lane = (plane group, block owner).  The hot loop is the radix-2^28 mixed addition of
+// msm_fixed.cuh (xyzz28_madd_fast, fp28.cuh) with the next table entry gathered while the current addition runs, the masks
+// of a lane's next four chunks fetched by one 32-byte load, and the two waves of a SIMD trading issue priority
+// (issue_fair.cuh) so that they finish together.
 #pragma once
 #include "issue_fair.cuh"
 #include "msm_fixed.cuh"
