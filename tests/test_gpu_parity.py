@@ -650,8 +650,8 @@ def test_comb_geometries_agree(golden, torch_cuda, monkeypatch):
 
 
 def test_host_buffer_commitment_pipeline_matches_device_path(engine, torch_cuda):
-    """kzg_blob_to_commitment_batch streams host blobs in 512-blob chunks (copy of chunk k+1 beside the MSM of chunk k, one
-    reduce/compress per group): two full chunks and a ragged one, an invalid blob in the last chunk, against the
+    """kzg_blob_to_commitment_batch streams host blobs in chunks of at least 512 blobs (copy of chunk k+1 beside the MSM of
+    chunk k, one reduce/compress per group): two full chunks and a ragged one, an invalid blob in the last chunk, against the
     device-pointer entry point"""
     torch = torch_cuda
     n = 1111
@@ -667,6 +667,29 @@ def test_host_buffer_commitment_pipeline_matches_device_path(engine, torch_cuda)
     host_blobs = d_blobs.cpu().numpy().tobytes()
     for m in (n, 512, 513, 1):
         got, got_st = engine.blob_to_commitment_batch(host_blobs[: m * 131072], m)
+        assert got_st == want_st[:m], m
+        assert got == want[: 48 * m], m
+
+
+def test_host_buffer_commitment_chunk_plans(engine, torch_cuda):
+    """the larger chunk plans of kzg_blob_to_commitment_batch: 8,400 blobs = chunks of 2,048 in a group of 8,192 + a tail group
+    of 208 with splits of its own; 16,500 blobs = four half-wave chunks of 4,096 (two blobs per wave, each its own group) + a
+    tail of 116; an invalid blob in a half-wave chunk; against the device-pointer entry point"""
+    torch = torch_cuda
+    n = 16500
+    d_blobs = torch.empty(n * 131072, dtype=torch.uint8, device="cuda")
+    engine.synth_blobs_dev(0xC4A2, 3, n, d_blobs.data_ptr())
+    d_blobs[9000 * 131072 + 32 * 77: 9000 * 131072 + 32 * 77 + 32] = 0xFF  # blob 9000, element 77: not canonical
+    d_c = torch.empty(n * 48, dtype=torch.uint8, device="cuda")
+    d_st = torch.empty(n, dtype=torch.int32, device="cuda")
+    engine.blob_to_commitment_batch_dev(d_blobs.data_ptr(), n, d_c.data_ptr(), d_st.data_ptr())
+    torch.cuda.synchronize()
+    want, want_st = d_c.cpu().numpy().tobytes(), d_st.cpu().tolist()
+    assert want_st[9000] == 2 and sum(1 for v in want_st if v) == 1
+    host = d_blobs.cpu().numpy()
+    del d_blobs
+    for m in (8400, n):
+        got, got_st = engine.blob_to_commitment_batch(host[: m * 131072].tobytes(), m)
         assert got_st == want_st[:m], m
         assert got == want[: 48 * m], m
 
