@@ -101,12 +101,6 @@ static __global__ __launch_bounds__(64) void k_g1_decompress(const uint8_t* __re
                                                       uint4* __restrict__ affine, uint8_t* __restrict__ inf) {
   g1_decompress_item((uint64_t)blockIdx.x * blockDim.x + threadIdx.x, in_a, n_a, status_a, in_b, n_b, status_b, affine, inf);
 }
-// items [first, n_a + n_b): the rest of a batch whose head was decoded in the shadow of the hash kernel (k_challenge_beside_decode)
-static __global__ __launch_bounds__(64) void k_g1_decompress_from(uint64_t first, const uint8_t* __restrict__ in_a, uint64_t n_a,
-                                                           int32_t* __restrict__ status_a, const uint8_t* __restrict__ in_b, uint64_t n_b,
-                                                           int32_t* __restrict__ status_b, uint4* __restrict__ affine, uint8_t* __restrict__ inf) {
-  g1_decompress_item(first + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, in_a, n_a, status_a, in_b, n_b, status_b, affine, inf);
-}
 
 // ---------------------------------------------------------------------------
 // K4: Blob::challenge (src/blob.rs:78-97) -- z = SHA-256("FSBLOBVERIFY_V1_" ||
@@ -122,17 +116,30 @@ __device__ __forceinline__ void load_be_words16(uint32_t* w, const uint8_t* __re
   w[3] = __builtin_bswap32(v.w);
 }
 
+__device__ __forceinline__ void load_be_chunk256(uint32_t* c, const uint8_t* __restrict__ p) {  // 256 B, 16-B aligned
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    uint4 v = q[k];
+    c[4 * k] = __builtin_bswap32(v.x);
+    c[4 * k + 1] = __builtin_bswap32(v.y);
+    c[4 * k + 2] = __builtin_bswap32(v.z);
+    c[4 * k + 3] = __builtin_bswap32(v.w);
+  }
+}
+
 // The message is  header(32 B) || blob(131072 B) || commitment(48 B): SHA block k >= 1 covers blob bytes
 // [64k-32, 64k+32).  Each lane streams its blob in ALIGNED 256-byte chunks (two whole cache lines per
 // step, next chunk prefetched while four blocks are hashed): a 32-byte carry from the previous chunk
 // plus the chunk's 256 bytes make exactly four blocks and the next carry.  (Fetching 64 B per step --
 // half a line, a new DRAM row per access, 65,536 concurrent streams -- left the kernel memory-stalled:
 // 13.4 ms at n = 65,536 against 6.7 ms of pure instruction issue.)
-// CW = words per chunk: 64 (256 B: two cache lines per step, 292 VGPRs: one wave per SIMD) or 32 (128 B, < 256 VGPRs: a second
-// wave of another role fits beside it, k_challenge_beside_decode).
-template <int CW>
-__device__ __forceinline__ void challenge_lane(const uint8_t* __restrict__ blob, const uint8_t* __restrict__ com, fr_t* __restrict__ z_out) {
-  static_assert(CW == 64 || CW == 32, "chunk = 32-byte carry + whole blocks");
+static __global__ __launch_bounds__(64) void k_challenge(const uint8_t* __restrict__ blobs, const uint8_t* __restrict__ commitments48, uint64_t n,
+                                                  fr_t* __restrict__ z_plain) {
+  const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n) return;
+  const uint8_t* blob = blobs + b * 131072ull;
+  const uint8_t* com = commitments48 + b * 48;
   sha256_state s;
   sha256_init(s);
   uint32_t carry[8];
@@ -144,25 +151,13 @@ __device__ __forceinline__ void challenge_lane(const uint8_t* __restrict__ blob,
   carry[5] = 0;
   carry[6] = 0;
   carry[7] = 4096;  // u128 big-endian degree
-  uint32_t cur[CW], nxt[CW];
-  constexpr uint32_t STEPS = 131072u / (4u * CW);
-  auto load_chunk = [&](uint32_t* c, const uint8_t* p) {
-    const uint4* q = reinterpret_cast<const uint4*>(p);
-#pragma unroll
-    for (int k = 0; k < CW / 4; k++) {
-      uint4 v = q[k];
-      c[4 * k] = __builtin_bswap32(v.x);
-      c[4 * k + 1] = __builtin_bswap32(v.y);
-      c[4 * k + 2] = __builtin_bswap32(v.z);
-      c[4 * k + 3] = __builtin_bswap32(v.w);
-    }
-  };
-  load_chunk(nxt, blob);
+  uint32_t cur[64], nxt[64];
+  load_be_chunk256(nxt, blob);
 #pragma unroll 1
-  for (uint32_t j = 0; j < STEPS; j++) {
+  for (uint32_t j = 0; j < 512; j++) {
 #pragma unroll
-    for (int q = 0; q < CW; q++) cur[q] = nxt[q];
-    if (j + 1 < STEPS) load_chunk(nxt, blob + 4u * CW * (j + 1));
+    for (int q = 0; q < 64; q++) cur[q] = nxt[q];
+    if (j + 1 < 512) load_be_chunk256(nxt, blob + 256u * (j + 1));
     uint32_t w[16];
 #pragma unroll
     for (int q = 0; q < 8; q++) {
@@ -170,10 +165,11 @@ __device__ __forceinline__ void challenge_lane(const uint8_t* __restrict__ blob,
       w[8 + q] = cur[q];
     }
     sha256_block(s, w);
+    sha256_block(s, cur + 8);
+    sha256_block(s, cur + 24);
+    sha256_block(s, cur + 40);
 #pragma unroll
-    for (int k = 0; k < CW / 16 - 1; k++) sha256_block(s, cur + 8 + 16 * k);
-#pragma unroll
-    for (int q = 0; q < 8; q++) carry[q] = cur[CW - 8 + q];
+    for (int q = 0; q < 8; q++) carry[q] = cur[56 + q];
   }
   // block 2048: last 32 blob bytes (the carry) + first 32 commitment bytes
   uint32_t w[16];
@@ -193,35 +189,7 @@ __device__ __forceinline__ void challenge_lane(const uint8_t* __restrict__ blob,
 #pragma unroll
   for (int q = 0; q < 8; q++) v.v[7 - q] = s.h[q];
   fr_reduce_256(v);
-  *z_out = v;
-}
-static __global__ __launch_bounds__(64) void k_challenge(const uint8_t* __restrict__ blobs, const uint8_t* __restrict__ commitments48, uint64_t n,
-                                                  fr_t* __restrict__ z_plain) {
-  const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= n) return;
-  challenge_lane<64>(blobs + b * 131072ull, commitments48 + b * 48, z_plain + b);
-}
-
-// Chip-filling batches (one hash wave per SIMD, n = 65,536 on 256 CUs): a lone wave issues an instruction every ~5.3
-// cycles where the SIMD could issue every 4.1, and the hash holds the chip for 6 ms.  This grid puts point-decoding waves
-// into that shadow: workgroups of FOUR waves (the hardware deals the waves of a workgroup over the CU's four SIMDs, so
-// every SIMD gets exactly one hash wave -- single-wave workgroups were stacked two to a SIMD, profiles/r01), the first
-// sha_wgs workgroups hash 256 blobs each at raised priority, the rest decode 256 points each in the issue slots the hash
-// leaves free (both roles < 256 VGPRs: one wave of each per SIMD).  Only the head [0, dec_items) of the points is decoded
-// here -- what fits into the shadow; the rest goes to k_g1_decompress_from beside the evaluation kernel.
-static __global__ __launch_bounds__(256, 2) void k_challenge_beside_decode(const uint8_t* __restrict__ blobs, const uint8_t* __restrict__ commitments48,
-                                                                           uint64_t n, fr_t* __restrict__ z_plain, uint32_t sha_wgs, uint64_t dec_items,
-                                                                           const uint8_t* __restrict__ in_a, uint64_t n_a, int32_t* __restrict__ status_a,
-                                                                           const uint8_t* __restrict__ in_b, uint64_t n_b, int32_t* __restrict__ status_b,
-                                                                           uint4* __restrict__ affine, uint8_t* __restrict__ inf) {
-  if (blockIdx.x < sha_wgs) {
-    __builtin_amdgcn_s_setprio(3);
-    const uint64_t b = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (b < n) challenge_lane<32>(blobs + b * 131072ull, commitments48 + b * 48, z_plain + b);
-  } else {
-    const uint64_t t = (uint64_t)(blockIdx.x - sha_wgs) * 256 + threadIdx.x;
-    if (t < dec_items) g1_decompress_item(t, in_a, n_a, status_a, in_b, n_b, status_b, affine, inf);
-  }
+  z_plain[b] = v;
 }
 
 // The same hash for LATENCY-bound batch sizes (a handful of waves on an otherwise idle chip: the proof path's 4,096-blob

@@ -182,7 +182,6 @@ EnvKnobs read_env_knobs() {
     if (const char* e = getenv("KATETH_AMD_PROOF_OVERLAP")) k.proof_overlap = atoi(e) != 0;
     if (const char* e = getenv("KATETH_AMD_EVAL_GROUP")) k.eval_group = atoi(e);
     k.verify_serial = getenv("KATETH_AMD_VERIFY_SERIAL") != nullptr;
-    if (const char* e = getenv("KATETH_AMD_VERIFY_SHADOW")) k.verify_shadow = (uint32_t)atoi(e) <= 100u ? (uint32_t)atoi(e) : 0u;
     if (const char* e = getenv("KATETH_AMD_VERIFY_CHUNK")) k.verify_chunk = (uint64_t)atoll(e) > 0 ? (uint64_t)atoll(e) : 0;
     k.comb_full_wave = getenv("KATETH_AMD_COMB_FULL_WAVE") != nullptr;
     if (const char* e = getenv("KATETH_AMD_COMB_FAIR")) k.comb_fair = (uint32_t)atoi(e) < 40u ? (uint32_t)atoi(e) : 0u;

@@ -37,7 +37,6 @@ struct EnvKnobs {
   int proof_overlap = -1;        // KATETH_AMD_PROOF_OVERLAP (-1 = default)
   int eval_group = 0;            // KATETH_AMD_EVAL_GROUP: 16 | 64 (0 = automatic)
   bool verify_serial = false;    // KATETH_AMD_VERIFY_SERIAL
-  uint32_t verify_shadow = 45;   // KATETH_AMD_VERIFY_SHADOW: percent of the 2n points decoded in the shadow of the chip-filling hash kernel (0 = none)
   uint64_t verify_chunk = 0;     // KATETH_AMD_VERIFY_CHUNK: blobs per host-buffer staging chunk (0 = default)
   uint32_t comb_fair = 20;       // KATETH_AMD_COMB_FAIR=s: the MSM waves of a SIMD trade issue priority every 2^s cycles; 0 = hardware default (measurement aid)
   bool comb_full_wave = false;   // KATETH_AMD_COMB_FULL_WAVE: never use the comb's two-blobs-per-wave mode (measurement aid)

@@ -365,27 +365,15 @@ static int32_t phase1_items(kzg_verify_session* s, const uint8_t* blobs, const u
     launch_challenge_and_decode(ctx, st, blobs, com, m, z, prf, n, s->stat + 2 * n, com, n, s->stat + n, s->aff, s->inf);
     (void)hipEventRecord(s->ev_join, st);
   } else {
-    // chip-filling batch (the one-lane-per-blob hash): the head of the points is decoded in the hash kernel's shadow
-    const uint64_t split_max = ctx->knobs.challenge_split_max ? ctx->knobs.challenge_split_max : (uint64_t)ctx->num_cus * 4 * 64 / 2;
-    uint64_t shadow = 0;
-    if (decode_here && base == 0 && m == n && m > split_max && !ctx->knobs.verify_serial)
-      shadow = (2 * n * ctx->knobs.verify_shadow / 100) & ~(uint64_t)255;
-    if (shadow) {
-      ProfScope ps(ctx, PROF_CHALLENGE, st);
-      const uint32_t sha_wgs = (uint32_t)blocks_for(m, 256);
-      hipLaunchKernelGGL(k_challenge_beside_decode, dim3(sha_wgs + (unsigned)(shadow / 256)), dim3(256), 0, st, blobs, com, m, z, sha_wgs, shadow, prf, n,
-                         s->stat + 2 * n, com, n, s->stat + n, s->aff, s->inf);
-    } else {
-      launch_challenge(ctx, st, blobs, com + base * 48, m, z);
-    }
+    launch_challenge(ctx, st, blobs, com + base * 48, m, z);
     if (decode_here) {
       (void)hipEventRecord(s->ev_fork, st);
       hipStream_t side = ctx->knobs.verify_serial ? st : s->side;
       (void)hipStreamWaitEvent(side, s->ev_fork, 0);
       {
         ProfScope ps(ctx, PROF_DECODE, side);
-        hipLaunchKernelGGL(k_g1_decompress_from, dim3(blocks_for(2 * n - shadow, 64)), dim3(64), 0, side, shadow, prf, n, s->stat + 2 * n, com, n,
-                           s->stat + n, s->aff, s->inf);
+        hipLaunchKernelGGL(k_g1_decompress, dim3(blocks_for(2 * n, 64)), dim3(64), 0, side, prf, n, s->stat + 2 * n, com, n, s->stat + n, s->aff,
+                           s->inf);
       }
       (void)hipEventRecord(s->ev_join, side);
     }
