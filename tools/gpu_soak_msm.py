@@ -17,7 +17,8 @@ batches = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 n = 4096
 import __graft_entry__ as g  # noqa: E402
 
-s28 = kateth_amd.Setup.load_json(SETUP, window_bits=16)  # the product library: comb kernel (blocks of 16 points)
+cls = int(sys.argv[2]) if len(sys.argv) > 2 else 22
+s28 = kateth_amd.Setup.load_json(SETUP, window_bits=cls)  # the product library: comb kernel (class 22: blocks of 22/21 points; 16: of 16 points)
 os.environ["KATETH_AMD_MSM_RADIX"] = "32"  # honoured only by the test-only build (tests/window_msm, -DKZG_TEST_WINDOW_MSM)
 s32 = kateth_amd.Setup.load_json(SETUP, window_bits=12, lib_path=g.TEST_LIB_WINDOW_MSM)
 d_blobs = torch.empty(n * 131072, dtype=torch.uint8, device="cuda")
