@@ -192,6 +192,55 @@ static __global__ __launch_bounds__(64) void k_challenge(const uint8_t* __restri
   z_plain[b] = v;
 }
 
+// the PRODUCER wave of the two latency kernels: message schedule (W + K) of block k into wk[k & 1], one block ahead of the
+// consumer(s); one workgroup barrier per block
+__device__ __forceinline__ void challenge_producer(uint32_t (*wk)[64 * 64], int lane, const uint8_t* __restrict__ blob, const uint8_t* __restrict__ com) {
+  constexpr uint32_t NBLK = 2050;
+  uint32_t w[16], nxt[16];
+  // block 0: "FSBLOBVERIFY_V1_" || u128_be(4096) || blob[0:32]
+  w[0] = 0x4653424cu;
+  w[1] = 0x4f425645u;
+  w[2] = 0x52494659u;
+  w[3] = 0x5f56315fu;
+  w[4] = 0;
+  w[5] = 0;
+  w[6] = 0;
+  w[7] = 4096;
+  load_be_words16(w + 8, blob);
+  load_be_words16(w + 12, blob + 16);
+  // block 1 = blob[32:96], fetched while block 0 is expanded
+  load_be_words16(nxt, blob + 32);
+  load_be_words16(nxt + 4, blob + 48);
+  load_be_words16(nxt + 8, blob + 64);
+  load_be_words16(nxt + 12, blob + 80);
+#pragma unroll 1
+  for (uint32_t k = 0; k < NBLK; k++) {
+    sha256_expand_to_lds(wk[k & 1], lane, w);
+#pragma unroll
+    for (int q = 0; q < 16; q++) w[q] = nxt[q];
+    const uint32_t k2 = k + 2;  // the block after next
+    if (k2 < 2048) {  // blob[64 k2 - 32, 64 k2 + 32)
+      const uint8_t* src = blob + 64ull * k2 - 32;
+      load_be_words16(nxt, src);
+      load_be_words16(nxt + 4, src + 16);
+      load_be_words16(nxt + 8, src + 32);
+      load_be_words16(nxt + 12, src + 48);
+    } else if (k2 == 2048) {  // last 32 blob bytes || first 32 commitment bytes
+      load_be_words16(nxt, blob + 131040);
+      load_be_words16(nxt + 4, blob + 131056);
+      load_be_words16(nxt + 8, com);
+      load_be_words16(nxt + 12, com + 16);
+    } else if (k2 == 2049) {  // last 16 commitment bytes, padding, bit length of 131,152 bytes
+      load_be_words16(nxt, com + 32);
+      nxt[4] = 0x80000000u;
+#pragma unroll
+      for (int q = 5; q < 15; q++) nxt[q] = 0;
+      nxt[15] = 131152u * 8u;
+    }
+    __syncthreads();
+  }
+}
+
 // The same hash for LATENCY-bound batch sizes (a handful of waves on an otherwise idle chip: the proof path's 4,096-blob
 // chunks, single-blob calls): 128-thread workgroups of 64 blobs, wave 1 expands the message schedule one block ahead
 // (sha256_expand_to_lds), wave 0 runs the rounds.  3.7 ms instead of 5.6 ms per 2,050-block stream; the total
@@ -207,49 +256,7 @@ __device__ __forceinline__ void challenge_split_workgroup(uint32_t (*wk)[64 * 64
   const uint8_t* com = commitments48 + b * 48;
   constexpr uint32_t NBLK = 2050;
   if (producer) {
-    uint32_t w[16], nxt[16];
-    // block 0: "FSBLOBVERIFY_V1_" || u128_be(4096) || blob[0:32]
-    w[0] = 0x4653424cu;
-    w[1] = 0x4f425645u;
-    w[2] = 0x52494659u;
-    w[3] = 0x5f56315fu;
-    w[4] = 0;
-    w[5] = 0;
-    w[6] = 0;
-    w[7] = 4096;
-    load_be_words16(w + 8, blob);
-    load_be_words16(w + 12, blob + 16);
-    // block 1 = blob[32:96], fetched while block 0 is expanded
-    load_be_words16(nxt, blob + 32);
-    load_be_words16(nxt + 4, blob + 48);
-    load_be_words16(nxt + 8, blob + 64);
-    load_be_words16(nxt + 12, blob + 80);
-#pragma unroll 1
-    for (uint32_t k = 0; k < NBLK; k++) {
-      sha256_expand_to_lds(wk[k & 1], lane, w);
-#pragma unroll
-      for (int q = 0; q < 16; q++) w[q] = nxt[q];
-      const uint32_t k2 = k + 2;  // the block after next
-      if (k2 < 2048) {  // blob[64 k2 - 32, 64 k2 + 32)
-        const uint8_t* src = blob + 64ull * k2 - 32;
-        load_be_words16(nxt, src);
-        load_be_words16(nxt + 4, src + 16);
-        load_be_words16(nxt + 8, src + 32);
-        load_be_words16(nxt + 12, src + 48);
-      } else if (k2 == 2048) {  // last 32 blob bytes || first 32 commitment bytes
-        load_be_words16(nxt, blob + 131040);
-        load_be_words16(nxt + 4, blob + 131056);
-        load_be_words16(nxt + 8, com);
-        load_be_words16(nxt + 12, com + 16);
-      } else if (k2 == 2049) {  // last 16 commitment bytes, padding, bit length of 131,152 bytes
-        load_be_words16(nxt, com + 32);
-        nxt[4] = 0x80000000u;
-#pragma unroll
-        for (int q = 5; q < 15; q++) nxt[q] = 0;
-        nxt[15] = 131152u * 8u;
-      }
-      __syncthreads();
-    }
+    challenge_producer(wk, lane, blob, com);
   } else {
     sha256_state s;
     sha256_init(s);
@@ -272,6 +279,69 @@ static __global__ __launch_bounds__(128) void k_challenge_split(const uint8_t* _
   __shared__ uint32_t wk[2][64 * 64];
   challenge_split_workgroup(wk, blockIdx.x, blobs, commitments48, n, z_plain);
 }
+// Batches small enough for THREE waves per 64 blobs to have a SIMD each (n <= 16,384 on 256 CUs; single items): the rounds
+// run on lane pairs (sha256_rounds_pair: 11 instead of 14 instructions per round on the critical chain), so 64 blobs
+// take two consumer waves + the producer wave.  Y lanes read their W + K from an all-zero LDS region.
+__device__ __forceinline__ void challenge_pair_workgroup(uint32_t (*wk)[64 * 64], uint32_t* zeros, uint64_t wg, const uint8_t* __restrict__ blobs,
+                                                         const uint8_t* __restrict__ commitments48, uint64_t n, fr_t* __restrict__ z_plain) {
+  const int tid = threadIdx.x;  // 192 threads: [0, 128) consumer lane pairs, [128, 192) producer
+  const bool producer = tid >= 128;
+  const int p = producer ? tid - 128 : tid >> 1;  // blob within the workgroup
+  uint64_t b = wg * 64 + p;
+  const bool live = b < n;
+  if (!live) b = n - 1;  // idle lanes shadow the last blob: every wave must reach every barrier
+  for (int i = tid; i < 64 * 64; i += 192) zeros[i] = 0;
+  __syncthreads();
+  if (producer) {
+    challenge_producer(wk, p, blobs + b * 131072ull, commitments48 + b * 48);
+  } else {
+    const bool is_y = (tid & 1) != 0;
+    sha256_state init;
+    sha256_init(init);
+    sha256_half st;
+#pragma unroll
+    for (int q = 0; q < 4; q++) st.s[q] = is_y ? init.h[q] : init.h[4 + q];
+#pragma unroll 1
+    for (uint32_t k = 0; k < 2050; k++) {
+      __syncthreads();
+      sha256_rounds_pair(st, is_y ? zeros + p : wk[k & 1] + p, is_y);
+    }
+    uint32_t other[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) other[q] = sha_pair_swap(st.s[q]);
+    if (live && !is_y) {  // X holds h[4..7], its neighbour's words are h[0..3]
+      fr_t v;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        v.v[7 - q] = other[q];
+        v.v[3 - q] = st.s[q];
+      }
+      fr_reduce_256(v);
+      z_plain[b] = v;
+    }
+  }
+}
+static __global__ __launch_bounds__(192) void k_challenge_pair(const uint8_t* __restrict__ blobs, const uint8_t* __restrict__ commitments48, uint64_t n,
+                                                               fr_t* __restrict__ z_plain) {
+  __shared__ uint32_t wk[2][64 * 64];
+  __shared__ uint32_t zeros[64 * 64];
+  challenge_pair_workgroup(wk, zeros, blockIdx.x, blobs, commitments48, n, z_plain);
+}
+static __global__ __launch_bounds__(192) void k_challenge_pair_and_decode(const uint8_t* __restrict__ blobs, const uint8_t* __restrict__ commitments48,
+                                                                          uint64_t n, fr_t* __restrict__ z_plain, uint32_t sha_wgs,
+                                                                          const uint8_t* __restrict__ in_a, uint64_t n_a, int32_t* __restrict__ status_a,
+                                                                          const uint8_t* __restrict__ in_b, uint64_t n_b, int32_t* __restrict__ status_b,
+                                                                          uint4* __restrict__ affine, uint8_t* __restrict__ inf) {
+  __shared__ uint32_t wk[2][64 * 64];
+  __shared__ uint32_t zeros[64 * 64];
+  if (blockIdx.x < sha_wgs) {
+    challenge_pair_workgroup(wk, zeros, blockIdx.x, blobs, commitments48, n, z_plain);
+  } else {
+    const uint64_t t = (uint64_t)(blockIdx.x - sha_wgs) * 192 + threadIdx.x;
+    g1_decompress_item(t, in_a, n_a, status_a, in_b, n_b, status_b, affine, inf);
+  }
+}
+
 // Challenges AND point decoding of a small batch in ONE launch: workgroups [0, sha_wgs) hash (two waves per 64 blobs),
 // the rest decode 128 points each.  Both are single long dependency chains per lane; as two concurrent kernels the
 // dispatcher stacked their waves on the same SIMDs (decode 4.6 ms instead of 1.9 ms beside a 3.7 ms hash).  Workgroups

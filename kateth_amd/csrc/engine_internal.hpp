@@ -147,7 +147,9 @@ static inline void launch_challenge(const kzg_ctx* ctx, hipStream_t st, const ui
   ProfScope ps(ctx, PROF_CHALLENGE, st);
   uint64_t split_max = (uint64_t)ctx->num_cus * 4 * 64 / 2;  // 2 waves per 64 blobs, one wave per SIMD: 32,768 on 256 CUs
   if (ctx->knobs.challenge_split_max) split_max = ctx->knobs.challenge_split_max;
-  if (n <= split_max)
+  if ((uint64_t)blocks_for(n, 64) * 3 <= (uint64_t)ctx->num_cus * 4 && !ctx->knobs.challenge_split_max)
+    hipLaunchKernelGGL(k_challenge_pair, dim3(blocks_for(n, 64)), dim3(192), 0, st, blobs, commitments48, n, z);  // three waves per 64 blobs, a SIMD each
+  else if (n <= split_max)
     hipLaunchKernelGGL(k_challenge_split, dim3(blocks_for(n, 64)), dim3(128), 0, st, blobs, commitments48, n, z);
   else
     hipLaunchKernelGGL(k_challenge, dim3(blocks_for(n, 64)), dim3(64), 0, st, blobs, commitments48, n, z);
@@ -160,6 +162,13 @@ static inline void launch_challenge_and_decode(const kzg_ctx* ctx, hipStream_t s
                                                int32_t* status_b, uint4* affine, uint8_t* inf) {
   ProfScope ps(ctx, PROF_CHALLENGE, st);
   const uint32_t sha_wgs = (uint32_t)blocks_for(n, 64);
+  if ((uint64_t)sha_wgs * 3 + blocks_for(n_a + n_b, 64) <= (uint64_t)ctx->num_cus * 4 && !ctx->knobs.challenge_split_max) {
+    // every wave still gets a SIMD of its own with three hash waves per 64 blobs: the rounds run on lane pairs
+    const uint32_t dec_wgs = (uint32_t)blocks_for(n_a + n_b, 192);
+    hipLaunchKernelGGL(k_challenge_pair_and_decode, dim3(sha_wgs + dec_wgs), dim3(192), 0, st, blobs, commitments48, n, z, sha_wgs, in_a, n_a, status_a,
+                       in_b, n_b, status_b, affine, inf);
+    return;
+  }
   const uint32_t dec_wgs = (uint32_t)blocks_for(n_a + n_b, 128);
   hipLaunchKernelGGL(k_challenge_and_decode, dim3(sha_wgs + dec_wgs), dim3(128), 0, st, blobs, commitments48, n, z, sha_wgs, in_a, n_a, status_a, in_b,
                      n_b, status_b, affine, inf);

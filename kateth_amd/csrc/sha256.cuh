@@ -164,6 +164,45 @@ __device__ __forceinline__ void sha256_rounds_from_lds(sha256_state& s, const ui
   s.h[6] += g;
   s.h[7] += h;
 }
+
+// ---- the 64 rounds on a PAIR of lanes -------------------------------------------------------------------------------
+// Latency path, one step further: the consumer's 14 instructions per round are two almost independent halves,
+//   T1 = h + Sigma1(e) + Ch(e, f, g) + (W + K)      and      T2 = Sigma0(a) + Maj(a, b, c),
+// joined only by e' = d + T1, a' = T1 + T2.  An even lane X keeps (e, f, g, h), its odd neighbour Y keeps (a, b, c, d), and
+// both run the SAME instructions: rotations by per-lane amounts (v_alignbit_b32 takes the shift from a VGPR),
+// Maj(a, b, c) = Ch(~(a ^ b), b, c) so one Ch serves both (the selector is a0 for X and ~(a0 ^ a1) for Y: one
+// v_bitop3_b32 with the lane's role mask as third operand), W + K read from LDS by X and from an all-zero region by Y,
+// h added under the X mask; then X sends T1 and Y sends d to the neighbour (DPP quad_perm, folded into the add):
+// 11 instructions per round instead of 14 on the chain that bounds a single hash.
+struct sha256_half {
+  uint32_t s[4];  // X: e, f, g, h      Y: a, b, c, d
+};
+__device__ __forceinline__ uint32_t sha_pair_swap(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
+}
+// wk: this lane's base into the [t][blob] schedule (X) or into the zero region (Y); element t at wk[t * 64]
+__device__ __forceinline__ void sha256_rounds_pair(sha256_half& st, const uint32_t* __restrict__ wk, bool is_y) {
+  const uint32_t k1 = is_y ? 2u : 6u, k2 = is_y ? 13u : 11u, k3 = is_y ? 22u : 25u;
+  const uint32_t ymask = is_y ? 0xffffffffu : 0u, xmask = ~ymask;
+  uint32_t a0 = st.s[0], a1 = st.s[1], a2 = st.s[2], a3 = st.s[3];
+#pragma unroll
+  for (int i = 0; i < 64; i++) {
+    const uint32_t sig = xor3(__builtin_amdgcn_alignbit(a0, a0, k1), __builtin_amdgcn_alignbit(a0, a0, k2), __builtin_amdgcn_alignbit(a0, a0, k3));
+    const uint32_t sel = __builtin_amdgcn_bitop3_b32(a0, a1, ymask, 0xD2);  // X: a0      Y: ~(a0 ^ a1)
+    const uint32_t ch = sha_ch(sel, a1, a2);                                // X: Ch(e, f, g)   Y: Maj(a, b, c)
+    const uint32_t t = sig + ch + wk[i * 64] + (a3 & xmask);                // X: T1      Y: T2
+    const uint32_t send = is_y ? a3 : t;                                    // X sends T1, Y sends d
+    const uint32_t n0 = t + sha_pair_swap(send);                            // X: e' = T1 + d      Y: a' = T2 + T1
+    a3 = a2;
+    a2 = a1;
+    a1 = a0;
+    a0 = n0;
+  }
+  st.s[0] += a0;
+  st.s[1] += a1;
+  st.s[2] += a2;
+  st.s[3] += a3;
+}
 #endif
 
 // Generic (slow-path) hashing of a short host/device byte string; used for
