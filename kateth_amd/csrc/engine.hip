@@ -532,8 +532,11 @@ static int32_t commit_host(const kzg_ctx* ctx, const uint8_t* blobs, uint64_t n,
   // that repeat the Horner doublings).  A quarter of the batch per chunk; from 16,384 blobs on chunks of 4,096, which run in
   // the comb's half-wave mode.  A group of chunks shares the lane-sum trees and the encoding (and therefore its unit shape):
   // half-wave chunks are their own group, so a short last chunk gets splits of its own instead of a few 29-ms waves.
-  uint64_t chunk = n <= 512 ? n : (n + 3) / 4;
-  chunk = n > 8192 ? (n < 16384 ? 2048 : 4096) : (chunk < 512 ? 512 : ((chunk + 1) & ~(uint64_t)1));
+  uint64_t chunk = n;  // up to 512 blobs: one chunk
+  if (n > 8192)
+    chunk = n < 16384 ? 2048 : 4096;
+  else if (n > 512)
+    chunk = (n + 3) / 4 < 512 ? 512 : (((n + 3) / 4 + 1) & ~(uint64_t)1);
   const bool half_wave = msm_lanes_per_blob(ctx, chunk, choose_splits(ctx, chunk)) == 32;
   const uint64_t group = half_wave ? chunk : (n < 8192 ? n : 8192);  // a multiple of the chunk size when n > 8192
   uint32_t max_splits = 1;
