@@ -546,6 +546,34 @@ def test_proof_chunking_and_two_stream_pipeline_are_bit_exact(engine, torch_cuda
             e2.close()
 
 
+def test_three_challenge_kernels_agree(engine, torch_cuda, monkeypatch):
+    """Blob::challenge (src/blob.rs:78-97) has three device kernels: rounds on lane pairs (small batches), the
+    producer/consumer wave pair (mid-size batches) and one lane per blob (chip-filling batches).  Host-buffer verification
+    in chunks of 64 blobs hashes every chunk with the kernel the batch-size rule picks, and KATETH_AMD_CHALLENGE_SPLIT_MAX
+    overrides that rule: the same 130 triples (three chunks, a ragged last one) through all three kernels must verify,
+    and must reject a swapped proof -- a wrong z_i from any kernel breaks the batch equation"""
+    torch = torch_cuda
+    n = 130
+    d_blobs = torch.empty(n * 131072, dtype=torch.uint8, device="cuda")
+    engine.synth_blobs_dev(0x5AA5, 1, n, d_blobs.data_ptr())
+    d_c = torch.empty(n * 48, dtype=torch.uint8, device="cuda")
+    d_p = torch.empty(n * 48, dtype=torch.uint8, device="cuda")
+    d_st = torch.empty(n, dtype=torch.int32, device="cuda")
+    engine.blob_to_commitment_batch_dev(d_blobs.data_ptr(), n, d_c.data_ptr(), d_st.data_ptr())
+    engine.compute_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), n, d_p.data_ptr(), d_st.data_ptr())
+    torch.cuda.synchronize()
+    assert int(d_st.abs().sum()) == 0
+    blobs, cs, ps = (t.cpu().numpy().tobytes() for t in (d_blobs, d_c, d_p))
+    swapped = ps[48:96] + ps[48:]
+    for env in ({}, {"KATETH_AMD_CHALLENGE_SPLIT_MAX": "1000000"}, {"KATETH_AMD_CHALLENGE_SPLIT_MAX": "1"}):
+        e2 = _engine_with_env(monkeypatch, dict(env, KATETH_AMD_VERIFY_CHUNK="64"))
+        try:
+            assert e2.verify_blob_proof_batch_host(blobs, cs, ps, n) is True, env
+            assert e2.verify_blob_proof_batch_host(blobs, cs, swapped, n) is False, env
+        finally:
+            e2.close()
+
+
 def test_evaluation_kernel_group_shapes_agree(engine, golden, torch_cuda, monkeypatch):
     """batch verification evaluates each blob with 64 lanes (small batches) or 16 lanes (four blobs per wave, batches that
     fill the chip); both shapes must accept the same valid ragged batches, reject the same corrupted ones and report the
