@@ -182,6 +182,7 @@ EnvKnobs read_env_knobs() {
     if (const char* e = getenv("KATETH_AMD_PROOF_OVERLAP")) k.proof_overlap = atoi(e) != 0;
     if (const char* e = getenv("KATETH_AMD_EVAL_GROUP")) k.eval_group = atoi(e);
     k.verify_serial = getenv("KATETH_AMD_VERIFY_SERIAL") != nullptr;
+    if (const char* e = getenv("KATETH_AMD_VAR_MSM")) k.var_msm_classic = std::string(e) == "classic";
     if (const char* e = getenv("KATETH_AMD_VERIFY_CHUNK")) k.verify_chunk = (uint64_t)atoll(e) > 0 ? (uint64_t)atoll(e) : 0;
     k.comb_full_wave = getenv("KATETH_AMD_COMB_FULL_WAVE") != nullptr;
     if (const char* e = getenv("KATETH_AMD_COMB_FAIR")) k.comb_fair = (uint32_t)atoi(e) < 40u ? (uint32_t)atoi(e) : 0u;

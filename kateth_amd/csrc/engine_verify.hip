@@ -64,22 +64,42 @@ extern "C" void kzg_verify_session_destroy(kzg_verify_session* s) {
     session_free(s);
 }
 
-// Window sizes whose TOP window is full (255 mod c close to c): c = 8 (32 windows,
-// top raw digit 7 bits -> all 128 signed buckets used) or c = 4 for a handful of
-// terms.  With e.g. c = 12 the top window has 8 distinct digits and a few
-// buckets receive n/8 points each -- a serial chain that dominated the batch.
-static VarGeom choose_var_geom(uint64_t nterms) {
+// Window sizes.  Up to 16,383 terms: c = 8 (32 windows whose TOP window is full -- top raw digit 7 bits, all 128 signed
+// buckets used; with e.g. c = 12 the top window has 8 distinct digits and a few buckets receive n/8 points each, a serial
+// chain that dominated the batch), every bucket split over K threads, k_var_fold + k_var_windows; c = 4 for a handful of terms.
+// From 16,384 terms on (the batch sizes whose lincombs take milliseconds) the FLAT path: c = 13, 20 windows, 4,096 buckets
+// per full window = enough buckets for one thread each (no fold), 37 % fewer bucket additions, the top window's <= 232
+// magnitudes handled with 16 threads per bucket, and bit sums instead of running sums (k_var_bitsums).
+static VarGeom choose_var_geom(const kzg_ctx* ctx, uint64_t nterms) {
   VarGeom g;
+  g.top_n = 0;
+  g.ktop = 1;
+  if (nterms >= 16384 && !ctx->knobs.var_msm_classic) {
+    g.c = 13u;
+    g.W = 20u;  // 19 full windows + bits 247..254: a scalar < r has a raw top digit <= r >> 247 = 231, + 1 carry, never negated
+    g.half = 1u << 12;
+    g.top_n = 256u;
+    g.ktop = 16u;  // top_n * ktop = half: the top window costs k_var_bitsums what a full window does
+    return g;
+  }
   g.c = nterms >= 64 ? 8u : 4u;
   g.W = (256 + g.c - 1) / g.c;
   g.half = 1u << (g.c - 1);
   return g;
 }
 
-// host: sum_j 2^(c*j) * window[j]
+// host: sum_j 2^(c*j) * window[j]   (classic path), or sum_p 2^p * T[p] over the bit sums T[c j + b] (flat path)
 static void host_horner(g1_xyzz& out, const std::vector<g1_xyzz>& win, const VarGeom& g) {
   g1_xyzz acc;
   xyzz_set_inf(acc);
+  if (g.top_n) {
+    for (int p = (int)(g.W * g.c) - 1; p >= 0; p--) {
+      xyzz_dbl(acc);
+      xyzz_add(acc, win[p]);
+    }
+    out = acc;
+    return;
+  }
   for (int j = (int)g.W - 1; j >= 0; j--) {
     for (uint32_t k = 0; k < g.c; k++) xyzz_dbl(acc);
     xyzz_add(acc, win[j]);
@@ -132,10 +152,10 @@ struct MsmVarLayout {
   uint32_t nb = 0, K = 1;
   size_t o_counts = 0, o_offsets = 0, o_cursors = 0, o_entries = 0, o_part = 0, o_bsum = 0, o_win = 0, total = 0;
 };
-static MsmVarLayout msm_var_layout(uint64_t nterms) {
+static MsmVarLayout msm_var_layout(const kzg_ctx* ctx, uint64_t nterms) {
   MsmVarLayout L;
   if (nterms == 0) return L;
-  L.g = choose_var_geom(nterms);
+  L.g = choose_var_geom(ctx, nterms);
   L.nb = L.g.W * L.g.half;
   size_t off = 0;
   auto take = [&](size_t bytes) {
@@ -148,6 +168,13 @@ static MsmVarLayout msm_var_layout(uint64_t nterms) {
   L.o_cursors = take((size_t)(L.nb + 1) * 4);
   L.o_entries = take((size_t)nterms * L.g.W * 4);
   // split every bucket over K threads (power of two <= 64) so that a thread chains ~16 additions
+  if (L.g.top_n) {  // flat path: partials only for the top window; one output point per (window, bit)
+    L.o_part = take((size_t)L.g.top_n * L.g.ktop * sizeof(g1_xyzz28));
+    L.o_bsum = take((size_t)L.nb * sizeof(g1_xyzz28));
+    L.o_win = take((size_t)L.g.W * L.g.c * sizeof(g1_xyzz));
+    L.total = off;
+    return L;
+  }
   uint64_t load = nterms / L.g.half + 1;
   while (L.K < 64 && (uint64_t)L.K * 16 < load) L.K <<= 1;
   L.o_part = take((size_t)L.nb * L.K * sizeof(g1_xyzz28));
@@ -159,6 +186,7 @@ static MsmVarLayout msm_var_layout(uint64_t nterms) {
 
 struct MsmVarJob {
   VarGeom g{};
+  uint32_t nout = 0;  // points read back: W window sums, or W*c bit sums on the flat path
   uint8_t* buf = nullptr;
   bool owns_buf = false;
   std::vector<g1_xyzz> win;
@@ -167,12 +195,12 @@ struct MsmVarJob {
   bool active = false;
 };
 
-static int32_t msm_var_launch(MsmVarJob& job, const uint4* d_points, const uint8_t* d_inf, const fr_t* d_scalars, uint64_t nterms, hipStream_t st,
-                              uint8_t* prealloc = nullptr) {
+static int32_t msm_var_launch(const kzg_ctx* ctx, MsmVarJob& job, const uint4* d_points, const uint8_t* d_inf, const fr_t* d_scalars, uint64_t nterms,
+                              hipStream_t st, uint8_t* prealloc = nullptr) {
   job.active = false;
   job.st = st;
   if (nterms == 0) return 0;
-  const MsmVarLayout L = msm_var_layout(nterms);
+  const MsmVarLayout L = msm_var_layout(ctx, nterms);
   const VarGeom g = L.g;
   job.g = g;
   const uint32_t nb = L.nb, K = L.K;
@@ -191,15 +219,25 @@ static int32_t msm_var_launch(MsmVarJob& job, const uint4* d_points, const uint8
   g1_xyzz28* bpart = (g1_xyzz28*)(buf + L.o_part);
   g1_xyzz28* bsum = (g1_xyzz28*)(buf + L.o_bsum);
   g1_xyzz* winsum = (g1_xyzz*)(buf + L.o_win);
-  job.win.resize(g.W);
+  job.nout = g.top_n ? g.W * g.c : g.W;
+  job.win.resize(job.nout);
   job.active = true;
   HIP_TRY(hipMemsetAsync(counts, 0, (size_t)(nb + 1) * 4, st));
   hipLaunchKernelGGL(k_var_count, dim3(blocks_for(nterms, 256)), dim3(256), 0, st, d_scalars, d_inf, nterms, g, counts);
-  hipLaunchKernelGGL(k_var_scan, dim3(1), dim3(1024), 0, st, counts, nb, offsets, cursors);
-  hipLaunchKernelGGL(k_var_scatter, dim3(blocks_for(nterms, 256)), dim3(256), 0, st, d_scalars, d_inf, nterms, g, cursors, entries);
-  hipLaunchKernelGGL(k_var_buckets, dim3(blocks_for((uint64_t)nb * K, 64)), dim3(64), 0, st, d_points, offsets, entries, nb, K, bpart);
-  hipLaunchKernelGGL(k_var_fold, dim3(blocks_for((uint64_t)nb * K, 64)), dim3(64), 0, st, bpart, nb, K, bsum);
-  hipLaunchKernelGGL(k_var_windows, dim3(g.W), dim3(64), 0, st, bsum, g, winsum);
+  if (g.top_n) {
+    const uint32_t regular = (g.W - 1) * g.half;
+    hipLaunchKernelGGL(k_var_scan_wide<80>, dim3(1), dim3(1024), 0, st, counts, nb, offsets, cursors);  // nb = 20 * 4096 = 1024 * 80
+    hipLaunchKernelGGL(k_var_scatter, dim3(blocks_for(nterms, 256)), dim3(256), 0, st, d_scalars, d_inf, nterms, g, cursors, entries);
+    hipLaunchKernelGGL(k_var_buckets_flat, dim3(blocks_for((uint64_t)regular + (uint64_t)g.top_n * g.ktop, 64)), dim3(64), 0, st, d_points, offsets,
+                       entries, regular, g.top_n, g.ktop, bsum, bpart);
+    hipLaunchKernelGGL(k_var_bitsums, dim3(g.W * g.c), dim3(256), 0, st, bsum, bpart, g, winsum);
+  } else {
+    hipLaunchKernelGGL(k_var_scan, dim3(1), dim3(1024), 0, st, counts, nb, offsets, cursors);
+    hipLaunchKernelGGL(k_var_scatter, dim3(blocks_for(nterms, 256)), dim3(256), 0, st, d_scalars, d_inf, nterms, g, cursors, entries);
+    hipLaunchKernelGGL(k_var_buckets, dim3(blocks_for((uint64_t)nb * K, 64)), dim3(64), 0, st, d_points, offsets, entries, nb, K, bpart);
+    hipLaunchKernelGGL(k_var_fold, dim3(blocks_for((uint64_t)nb * K, 64)), dim3(64), 0, st, bpart, nb, K, bsum);
+    hipLaunchKernelGGL(k_var_windows, dim3(g.W), dim3(64), 0, st, bsum, g, winsum);
+  }
   HIP_TRY(hipGetLastError());
   // the window sums are read back in msm_var_finish: a device-to-host copy into pageable memory blocks the host
   // until the stream has drained, which would keep a second job from being enqueued beside this one
@@ -211,7 +249,7 @@ static int32_t msm_var_finish(MsmVarJob& job, g1_xyzz& result) {
   xyzz_set_inf(result);
   if (!job.active) return 0;
   int32_t rc = 0;
-  if (hipMemcpyAsync(job.win.data(), job.d_win, (size_t)job.g.W * sizeof(g1_xyzz), hipMemcpyDeviceToHost, job.st) != hipSuccess ||
+  if (hipMemcpyAsync(job.win.data(), job.d_win, (size_t)job.nout * sizeof(g1_xyzz), hipMemcpyDeviceToHost, job.st) != hipSuccess ||
       hipStreamSynchronize(job.st) != hipSuccess)
     rc = fail(KZG_FAIL_HIP, "variable-base MSM read-back failed");
   if (rc == 0) host_horner(result, job.win, job.g);
@@ -223,9 +261,8 @@ static int32_t msm_var_finish(MsmVarJob& job, g1_xyzz& result) {
 
 static int32_t msm_var(const kzg_ctx* ctx, const uint4* d_points, const uint8_t* d_inf, const fr_t* d_scalars, uint64_t nterms, hipStream_t st,
                        g1_xyzz& result) {
-  (void)ctx;
   MsmVarJob job;
-  int32_t rc = msm_var_launch(job, d_points, d_inf, d_scalars, nterms, st);
+  int32_t rc = msm_var_launch(ctx, job, d_points, d_inf, d_scalars, nterms, st);
   if (rc) {
     if (job.buf && job.owns_buf) (void)hipFree(job.buf);
     return rc;
@@ -248,7 +285,7 @@ static void scan_first_error(const int32_t* st, uint64_t n, int32_t* idx, int32_
 struct SessionLayout {
   size_t o_aff, o_inf, o_z, o_y, o_scal, o_stat, o_leaves, o_nodes, o_pts, o_msm_a, o_msm_b, o_rpow, o_ysum, total;
 };
-static SessionLayout session_layout(uint64_t n) {
+static SessionLayout session_layout(const kzg_ctx* ctx, uint64_t n) {
   SessionLayout L{};
   const uint64_t groups = (n + 255) / 256;
   size_t off = 0;
@@ -266,8 +303,8 @@ static SessionLayout session_layout(uint64_t n) {
   L.o_leaves = take(n * 32 + 32);
   L.o_nodes = take(groups * 32 + 32);
   L.o_pts = take(2 * n * 48 + 48);
-  L.o_msm_a = take(msm_var_layout(n).total + 256);
-  L.o_msm_b = take(msm_var_layout(2 * n + 1).total + 256);
+  L.o_msm_a = take(msm_var_layout(ctx, n).total + 256);
+  L.o_msm_b = take(msm_var_layout(ctx, 2 * n + 1).total + 256);
   L.o_rpow = take(64 * 32);
   L.o_ysum = take(((n + 255) / 256 + 1) * 32);
   L.total = off;
@@ -277,7 +314,7 @@ static SessionLayout session_layout(uint64_t n) {
 // Takes a session from the context's pool (or creates one), sized for n items, and enqueues its initialisation on `st`.
 static int32_t session_acquire(const kzg_ctx* ctx, uint64_t n, hipStream_t st, kzg_verify_session** out) {
   *out = nullptr;
-  const SessionLayout L = session_layout(n);
+  const SessionLayout L = session_layout(ctx, n);
   kzg_verify_session* s = nullptr;
   {
     std::lock_guard<std::mutex> guard(ctx->pool_lock);
@@ -634,13 +671,13 @@ extern "C" int32_t kzg_verify_phase2_dev(kzg_verify_session* s, const uint8_t* r
       (void)hipEventRecord(s->ev_fork, st);
       (void)hipStreamWaitEvent(s->side, s->ev_fork, 0);
       MsmVarJob ja, jb;
-      {
-        ProfScope psa(ctx, PROF_VAR_MSM, s->side);
-        rc = msm_var_launch(ja, s->aff, s->inf, s->scal + n, n, s->side, s->msm_a);
+      {  // B (2n + 1 terms) is the longer of the two: it is enqueued first so that its kernels are ahead in the dispatch order
+        ProfScope psb(ctx, PROF_VAR_MSM, st);
+        rc = msm_var_launch(ctx, jb, s->aff, s->inf, s->scal, 2 * n + 1, st, s->msm_b);
       }
       if (rc == 0) {
-        ProfScope psb(ctx, PROF_VAR_MSM, st);
-        rc = msm_var_launch(jb, s->aff, s->inf, s->scal, 2 * n + 1, st, s->msm_b);
+        ProfScope psa(ctx, PROF_VAR_MSM, s->side);
+        rc = msm_var_launch(ctx, ja, s->aff, s->inf, s->scal + n, n, s->side, s->msm_a);
       }
       int32_t rca = msm_var_finish(ja, Ax);
       int32_t rcb = msm_var_finish(jb, Bx);

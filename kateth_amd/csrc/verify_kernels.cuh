@@ -336,6 +336,10 @@ static __global__ __launch_bounds__(256) void k_batch_ysum_finish(const fr_t* __
 // ---------------------------------------------------------------------------
 struct VarGeom {
   uint32_t c, W, half;  // buckets per window = half = 2^(c-1)
+  // Large batches (the "flat" path, top_n != 0): c = 13, ONE thread per bucket for the full windows, the short top window
+  // (8 scalar bits: at most top_n magnitudes, each with 2^(c-8) times the load) split over ktop threads per bucket, and the
+  // per-window sum_d d*B_d replaced by bit sums (k_var_bitsums) that the host folds into its Horner loop.
+  uint32_t top_n, ktop;
 };
 
 // signed digits of one scalar, all windows, through a callback
@@ -396,6 +400,67 @@ static __global__ __launch_bounds__(1024) void k_var_scan(const uint32_t* __rest
   if (t == 0) offsets[len] = carry;
 }
 
+// the same scan for long counter arrays (81,920 counters at c = 13): each of the 1024 threads owns a contiguous segment of
+// PER counters (PER a multiple of 4: uint4 loads and stores, all issued before the first use), one block-wide scan of the
+// segment totals in between.  len <= 1024 * PER; counters past len read as zero.
+template <int PER>
+static __global__ __launch_bounds__(1024) void k_var_scan_wide(const uint32_t* __restrict__ counts, uint32_t len, uint32_t* __restrict__ offsets,
+                                                               uint32_t* __restrict__ cursors) {
+  static_assert(PER % 4 == 0, "vector width");
+  __shared__ uint32_t sh[1024];
+  const int t = threadIdx.x;
+  const uint32_t lo = (uint32_t)t * PER;
+  uint32_t v[PER];
+#pragma unroll
+  for (int q = 0; q < PER / 4; q++) {
+    uint4 x = make_uint4(0, 0, 0, 0);
+    if (lo + 4u * q + 3u < len) {
+      x = *reinterpret_cast<const uint4*>(counts + lo + 4u * q);
+    } else {
+      if (lo + 4u * q < len) x.x = counts[lo + 4u * q];
+      if (lo + 4u * q + 1u < len) x.y = counts[lo + 4u * q + 1u];
+      if (lo + 4u * q + 2u < len) x.z = counts[lo + 4u * q + 2u];
+    }
+    v[4 * q] = x.x;
+    v[4 * q + 1] = x.y;
+    v[4 * q + 2] = x.z;
+    v[4 * q + 3] = x.w;
+  }
+  uint32_t sum = 0;
+#pragma unroll
+  for (int q = 0; q < PER; q++) sum += v[q];
+  sh[t] = sum;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const uint32_t add = (t >= off) ? sh[t - off] : 0u;
+    __syncthreads();
+    sh[t] += add;
+    __syncthreads();
+  }
+  uint32_t run = sh[t] - sum;  // exclusive prefix of this segment
+#pragma unroll
+  for (int q = 0; q < PER / 4; q++) {
+    uint4 o;
+    o.x = run;
+    o.y = o.x + v[4 * q];
+    o.z = o.y + v[4 * q + 1];
+    o.w = o.z + v[4 * q + 2];
+    run = o.w + v[4 * q + 3];
+    if (lo + 4u * q + 3u < len) {
+      *reinterpret_cast<uint4*>(offsets + lo + 4u * q) = o;
+      *reinterpret_cast<uint4*>(cursors + lo + 4u * q) = o;
+    } else {
+      const uint32_t ov[4] = {o.x, o.y, o.z, o.w};
+      for (uint32_t e = 0; e < 4u; e++)
+        if (lo + 4u * q + e < len) {
+          offsets[lo + 4u * q + e] = ov[e];
+          cursors[lo + 4u * q + e] = ov[e];
+        }
+    }
+  }
+  if (t == 1023) offsets[len] = sh[1023];
+}
+
 static __global__ __launch_bounds__(256) void k_var_scatter(const fr_t* __restrict__ scalars, const uint8_t* __restrict__ inf, uint64_t nterms,
                                                      VarGeom g, uint32_t* __restrict__ cursors, uint32_t* __restrict__ entries) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -410,14 +475,9 @@ static __global__ __launch_bounds__(256) void k_var_scatter(const fr_t* __restri
 // 2^392-Montgomery domain (k_g1_decompress), the accumulator is XYZZ in radix-2^28 limbs with the MSM hot loop's inline
 // adder (xyzz28_madd_fast; the out-of-line complete adder takes the identity and the P == +-Q cases, which DO occur
 // here: a batch may repeat a point); the next entry is in flight while the current one is added.
-static __global__ __launch_bounds__(64, 2) void k_var_buckets(const uint4* __restrict__ points, const uint32_t* __restrict__ offsets,
-                                                       const uint32_t* __restrict__ entries, uint32_t nbuckets, uint32_t K,
-                                                       g1_xyzz28* __restrict__ partial_sums) {
-  const uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (id >= (uint64_t)nbuckets * K) return;
-  const uint32_t bkt = (uint32_t)(id / K), k0 = (uint32_t)(id % K);
-  const uint32_t lo = offsets[bkt], hi = offsets[bkt + 1];
-  g1_xyzz28 acc;
+// entries lo + k0, lo + k0 + K, ... of one bucket's sorted list, summed
+__device__ __forceinline__ void var_bucket_chain(g1_xyzz28& acc, const uint4* __restrict__ points, const uint32_t* __restrict__ entries, uint32_t lo,
+                                                 uint32_t hi, uint32_t k0, uint32_t K) {
   xyzz28_set_inf(acc);
   fp_t nx, ny;
   bn_zero(nx);
@@ -448,7 +508,34 @@ static __global__ __launch_bounds__(64, 2) void k_var_buckets(const uint4* __res
       acc = tmp;
     }
   }
+}
+static __global__ __launch_bounds__(64, 2) void k_var_buckets(const uint4* __restrict__ points, const uint32_t* __restrict__ offsets,
+                                                       const uint32_t* __restrict__ entries, uint32_t nbuckets, uint32_t K,
+                                                       g1_xyzz28* __restrict__ partial_sums) {
+  const uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= (uint64_t)nbuckets * K) return;
+  const uint32_t bkt = (uint32_t)(id / K), k0 = (uint32_t)(id % K);
+  g1_xyzz28 acc;
+  var_bucket_chain(acc, points, entries, offsets[bkt], offsets[bkt + 1], k0, K);
   partial_sums[id] = acc;  // the fold and window kernels stay in the radix-2^28 field
+}
+// flat path: threads [0, regular) own one bucket of a full window each (sum straight into bucket_sums); the rest split the
+// top window's buckets [regular, regular + top_n) over ktop threads each (partials for k_var_fold)
+static __global__ __launch_bounds__(64, 2) void k_var_buckets_flat(const uint4* __restrict__ points, const uint32_t* __restrict__ offsets,
+                                                                   const uint32_t* __restrict__ entries, uint32_t regular, uint32_t top_n, uint32_t ktop,
+                                                                   g1_xyzz28* __restrict__ bucket_sums, g1_xyzz28* __restrict__ top_partials) {
+  const uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  g1_xyzz28 acc;
+  if (id < regular) {
+    var_bucket_chain(acc, points, entries, offsets[id], offsets[id + 1], 0u, 1u);
+    bucket_sums[id] = acc;
+  } else {
+    const uint64_t t = id - regular;
+    if (t >= (uint64_t)top_n * ktop) return;
+    const uint32_t bkt = regular + (uint32_t)(t / ktop);
+    var_bucket_chain(acc, points, entries, offsets[bkt], offsets[bkt + 1], (uint32_t)(t % ktop), ktop);
+    top_partials[t] = acc;
+  }
 }
 
 // One wave folds the K partial sums of 64/K buckets: K is a power of two <= 64, lanes
@@ -548,6 +635,51 @@ static __global__ __launch_bounds__(64) void k_var_windows(const g1_xyzz28* __re
     g1_xyzz out;
     xyzz28_to_xyzz(out, tot);
     window_sums[j] = out;
+  }
+}
+
+// flat path: T[j][b] = sum of the buckets B[j][d] whose magnitude d has bit b set, so that
+//   sum_j 2^(c j) sum_d d B[j][d]  =  sum_{j,b} 2^(c j + b) T[j][b]
+// -- the per-window running sums (a chain of 2 * half dependent additions, or ~50 even when cut into segments) become W*c
+// independent tree sums of depth log2(256) + 8, and the weights 2^(c j + b) are the host's Horner loop, which doubles once
+// per bit anyway.  One 256-thread workgroup per (window, bit): 260 workgroups of four 248-VGPR waves are one round on 256 CUs
+// (512 threads took two).  The top window's buckets arrive as ktop partial sums each
+// (top_partials[(d - 1) * ktop + k]) and are summed here directly: top_n * ktop = half items, the same depth as a full window.
+static __global__ __launch_bounds__(256) void k_var_bitsums(const g1_xyzz28* __restrict__ bucket_sums, const g1_xyzz28* __restrict__ top_partials, VarGeom g,
+                                                            g1_xyzz* __restrict__ out) {
+  __shared__ g1_xyzz28 lds[128];
+  const uint32_t j = blockIdx.x / g.c, b = blockIdx.x % g.c;
+  const bool top = (j + 1 == g.W);
+  const uint32_t limit = top ? g.top_n : g.half;
+  const uint32_t per = top ? g.ktop : 1u;  // stored points per bucket
+  const g1_xyzz28* B = top ? top_partials : bucket_sums + (uint64_t)j * g.half;
+  g1_xyzz28 acc;
+  xyzz28_set_inf(acc);
+  const uint32_t low_mask = (1u << b) - 1u;
+#pragma unroll 1
+  for (uint32_t i = threadIdx.x; i < (limit / 2u + 1u) * per; i += 256u) {
+    const uint32_t di = i / per, k = i % per;
+    const uint32_t d = ((di >> b) << (b + 1u)) | (1u << b) | (di & low_mask);  // the di-th number with bit b set
+    if (d > limit) break;  // d grows with i
+    g1_xyzz28 t = B[(uint64_t)(d - 1u) * per + k];
+    xyzz28_add_complete(acc, t);
+  }
+#pragma unroll 1
+  for (uint32_t step = 128; step >= 1; step >>= 1) {
+    if (threadIdx.x >= step && threadIdx.x < 2 * step) lds[threadIdx.x - step] = acc;
+    __syncthreads();
+    if (threadIdx.x < step) {
+      g1_xyzz28 other = lds[threadIdx.x];
+      g1_xyzz28 mine = acc;
+      xyzz28_add_complete(mine, other);
+      acc = mine;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    g1_xyzz o;
+    xyzz28_to_xyzz(o, acc);
+    out[blockIdx.x] = o;
   }
 }
 

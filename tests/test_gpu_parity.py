@@ -574,6 +574,41 @@ def test_three_challenge_kernels_agree(engine, torch_cuda, monkeypatch):
             e2.close()
 
 
+def test_flat_and_classic_variable_base_msm_agree(engine, torch_cuda, monkeypatch):
+    """the three lincombs of verify_proof_batch (src/kzg/setup.rs:152-155) run as two variable-base MSMs; from 16,384 terms
+    on they take the flat path (c = 13, one thread per bucket, bit sums), below that -- and with KATETH_AMD_VAR_MSM=classic --
+    c = 8 with per-bucket partials.  20,000 triples (A: 20,000 terms, B: 40,001), a repeated point and an infinity among them:
+    the two partial sums of phase 2 must be the same 192 bytes from both paths, and both must accept / reject alike"""
+    torch = torch_cuda
+    n = 20000
+    d_blobs = torch.empty(n * 131072, dtype=torch.uint8, device="cuda")
+    engine.synth_blobs_dev(0x7A57, 5, n, d_blobs.data_ptr())
+    d_blobs[131072 * 3: 131072 * 4] = d_blobs[131072 * 2: 131072 * 3]  # blob 3 == blob 2: a repeated commitment/proof pair
+    d_blobs[131072 * 7: 131072 * 8] = 0  # zero blob: commitment and proof are the point at infinity
+    d_c = torch.empty(n * 48, dtype=torch.uint8, device="cuda")
+    d_p = torch.empty(n * 48, dtype=torch.uint8, device="cuda")
+    d_st = torch.empty(n, dtype=torch.int32, device="cuda")
+    engine.blob_to_commitment_batch_dev(d_blobs.data_ptr(), n, d_c.data_ptr(), d_st.data_ptr())
+    engine.compute_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), n, d_p.data_ptr(), d_st.data_ptr())
+    torch.cuda.synchronize()
+    assert int(d_st.abs().sum()) == 0
+    bad_p = d_p.clone()
+    bad_p[48 * 11: 48 * 12] = d_p[48 * 12: 48 * 13]
+    classic = _engine_with_env(monkeypatch, {"KATETH_AMD_VAR_MSM": "classic"})
+    try:
+        sums = []
+        for e in (engine, classic):
+            sess, root, err = e.verify_phase1_dev(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n)
+            assert err[0] == err[2] == err[4] == -1
+            sums.append(e.verify_phase2_dev(sess, root, 0, n))
+            e.verify_session_destroy(sess)
+            assert e.verify_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n) is True
+            assert e.verify_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), bad_p.data_ptr(), n) is False
+        assert sums[0] == sums[1] and len(sums[0]) == 192
+    finally:
+        classic.close()
+
+
 def test_evaluation_kernel_group_shapes_agree(engine, golden, torch_cuda, monkeypatch):
     """batch verification evaluates each blob with 64 lanes (small batches) or 16 lanes (four blobs per wave, batches that
     fill the chip); both shapes must accept the same valid ragged batches, reject the same corrupted ones and report the
