@@ -64,17 +64,18 @@ extern "C" void kzg_verify_session_destroy(kzg_verify_session* s) {
     session_free(s);
 }
 
-// Window sizes.  Up to 16,383 terms: c = 8 (32 windows whose TOP window is full -- top raw digit 7 bits, all 128 signed
+// Window sizes.  Up to 32,767 terms: c = 8 (32 windows whose TOP window is full -- top raw digit 7 bits, all 128 signed
 // buckets used; with e.g. c = 12 the top window has 8 distinct digits and a few buckets receive n/8 points each, a serial
 // chain that dominated the batch), every bucket split over K threads, k_var_fold + k_var_windows; c = 4 for a handful of terms.
-// From 16,384 terms on (the batch sizes whose lincombs take milliseconds) the FLAT path: c = 13, 20 windows, 4,096 buckets
+// From 32,768 terms on (measured: 8,192 items 7.06 ms flat / 6.59 ms classic, 16,384 items even, 32,768 items 13.06 / 14.09,
+// 65,536 items 17.9 / 18.7) the FLAT path: c = 13, 20 windows, 4,096 buckets
 // per full window = enough buckets for one thread each (no fold), 37 % fewer bucket additions, the top window's <= 232
 // magnitudes handled with 16 threads per bucket, and bit sums instead of running sums (k_var_bitsums).
 static VarGeom choose_var_geom(const kzg_ctx* ctx, uint64_t nterms) {
   VarGeom g;
   g.top_n = 0;
   g.ktop = 1;
-  if (nterms >= 16384 && !ctx->knobs.var_msm_classic) {
+  if (nterms >= 32768 && !ctx->knobs.var_msm_classic) {
     g.c = 13u;
     g.W = 20u;  // 19 full windows + bits 247..254: a scalar < r has a raw top digit <= r >> 247 = 231, + 1 carry, never negated
     g.half = 1u << 12;

@@ -575,12 +575,12 @@ def test_three_challenge_kernels_agree(engine, torch_cuda, monkeypatch):
 
 
 def test_flat_and_classic_variable_base_msm_agree(engine, torch_cuda, monkeypatch):
-    """the three lincombs of verify_proof_batch (src/kzg/setup.rs:152-155) run as two variable-base MSMs; from 16,384 terms
+    """the three lincombs of verify_proof_batch (src/kzg/setup.rs:152-155) run as two variable-base MSMs; from 32,768 terms
     on they take the flat path (c = 13, one thread per bucket, bit sums), below that -- and with KATETH_AMD_VAR_MSM=classic --
-    c = 8 with per-bucket partials.  20,000 triples (A: 20,000 terms, B: 40,001), a repeated point and an infinity among them:
+    c = 8 with per-bucket partials.  33,000 triples (A: 33,000 terms, B: 66,001), a repeated point and an infinity among them:
     the two partial sums of phase 2 must be the same 192 bytes from both paths, and both must accept / reject alike"""
     torch = torch_cuda
-    n = 20000
+    n = 33000
     d_blobs = torch.empty(n * 131072, dtype=torch.uint8, device="cuda")
     engine.synth_blobs_dev(0x7A57, 5, n, d_blobs.data_ptr())
     d_blobs[131072 * 3: 131072 * 4] = d_blobs[131072 * 2: 131072 * 3]  # blob 3 == blob 2: a repeated commitment/proof pair
