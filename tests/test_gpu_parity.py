@@ -605,6 +605,20 @@ def test_flat_and_classic_variable_base_msm_agree(engine, torch_cuda, monkeypatc
             assert e.verify_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n) is True
             assert e.verify_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), bad_p.data_ptr(), n) is False
         assert sums[0] == sums[1] and len(sums[0]) == 192
+        # every triple the same: all buckets collect multiples of ONE point, so the complete adder's P == Q branch is taken in
+        # the bucket chains (second entry of every list) and between equal bucket sums in the bit-sum trees
+        d_blobs.view(n, 131072)[:] = d_blobs.view(n, 131072)[0].clone()
+        d_c.view(n, 48)[:] = d_c.view(n, 48)[0].clone()
+        d_p.view(n, 48)[:] = d_p.view(n, 48)[0].clone()
+        torch.cuda.synchronize()
+        sums = []
+        for e in (engine, classic):
+            sess, root, err = e.verify_phase1_dev(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n)
+            assert err[0] == err[2] == err[4] == -1
+            sums.append(e.verify_phase2_dev(sess, root, 0, n))
+            e.verify_session_destroy(sess)
+            assert e.verify_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n) is True
+        assert sums[0] == sums[1]
     finally:
         classic.close()
 
