@@ -540,11 +540,11 @@ static int32_t commit_host(const kzg_ctx* ctx, const uint8_t* blobs, uint64_t n,
     chunk = (n + 3) / 4 < 512 ? 512 : (((n + 3) / 4 + 1) & ~(uint64_t)1);
   const bool half_wave = msm_lanes_per_blob(ctx, chunk, choose_splits(ctx, chunk)) == 32;
   const uint64_t group = half_wave ? chunk : (n < 8192 ? n : 8192);  // a multiple of the chunk size when n > 8192
-  uint32_t max_splits = 1;
+  uint64_t max_units = 1;  // (blob, split) units of the largest group: its lane sums live in the workspace
   for (uint64_t gbase = 0; gbase < n; gbase += group) {
     const uint64_t gm = (n - gbase < group) ? (n - gbase) : group;
-    const uint32_t sp = choose_splits(ctx, gm < chunk ? gm : chunk);
-    if (sp > max_splits) max_splits = sp;
+    const uint64_t units = gm * choose_splits(ctx, gm < chunk ? gm : chunk);
+    if (units > max_units) max_units = units;
   }
   uint8_t* stage[2] = {nullptr, nullptr};
   uint8_t* d_out = nullptr;
@@ -572,7 +572,7 @@ static int32_t commit_host(const kzg_ctx* ctx, const uint8_t* blobs, uint64_t n,
       rc = fail(KZG_FAIL_HIP, "host-buffer commitment: allocation failed");
       break;
     }
-    const size_t partial_bytes = align_up((size_t)group * max_splits * 65 * sizeof(g1_xyzz), 256);
+    const size_t partial_bytes = align_up((size_t)max_units * 65 * sizeof(g1_xyzz), 256);
     const size_t sums_bytes = align_up((size_t)group * sizeof(g1_xyzz), 256);
     rc = ws_reserve(ctx, partial_bytes + sums_bytes + 2 * msm_scratch_bytes(ctx, chunk));
     if (rc) break;
