@@ -227,6 +227,7 @@ static int32_t msm_var_launch(const kzg_ctx* ctx, MsmVarJob& job, const uint4* d
   hipLaunchKernelGGL(k_var_count, dim3(blocks_for(nterms, 256)), dim3(256), 0, st, d_scalars, d_inf, nterms, g, counts);
   if (g.top_n) {
     const uint32_t regular = (g.W - 1) * g.half;
+    if (nb > 1024u * 80u || g.top_n * g.ktop > g.half) return fail(KZG_FAIL_ARGUMENT, "flat MSM geometry out of range");
     hipLaunchKernelGGL(k_var_scan_wide<80>, dim3(1), dim3(1024), 0, st, counts, nb, offsets, cursors);  // nb = 20 * 4096 = 1024 * 80
     hipLaunchKernelGGL(k_var_scatter, dim3(blocks_for(nterms, 256)), dim3(256), 0, st, d_scalars, d_inf, nterms, g, cursors, entries);
     hipLaunchKernelGGL(k_var_buckets_flat, dim3(blocks_for((uint64_t)regular + (uint64_t)g.top_n * g.ktop, 64)), dim3(64), 0, st, d_points, offsets,
