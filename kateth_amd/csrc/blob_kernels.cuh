@@ -277,6 +277,7 @@ __device__ __forceinline__ void challenge_split_workgroup(uint32_t (*wk)[64 * 64
 static __global__ __launch_bounds__(128) void k_challenge_split(const uint8_t* __restrict__ blobs, const uint8_t* __restrict__ commitments48, uint64_t n,
                                                                 fr_t* __restrict__ z_plain) {
   __shared__ uint32_t wk[2][64 * 64];
+  asm volatile("" ::: "v255", "a8");  // one wave per SIMD, whatever the dispatcher would like to pack (see k_challenge_pair)
   challenge_split_workgroup(wk, blockIdx.x, blobs, commitments48, n, z_plain);
 }
 // Batches small enough for THREE waves per 64 blobs to have a SIMD each (n <= 16,384 on 256 CUs; single items): the rounds
@@ -325,6 +326,10 @@ static __global__ __launch_bounds__(192) void k_challenge_pair(const uint8_t* __
                                                                fr_t* __restrict__ z_plain) {
   __shared__ uint32_t wk[2][64 * 64];
   __shared__ uint32_t zeros[64 * 64];
+  // Claim more than half of a SIMD's register file (nothing is stored there): a second workgroup then cannot put a wave next
+  // to one of this kernel's on the same SIMD, so the dispatcher has to give every workgroup a CU of its own (256 workgroups
+  // = 16,384 blobs on 256 CUs).  Left to itself it paired workgroups on some CUs and the hash took 4.7 instead of 3.7 ms.
+  asm volatile("" ::: "v255", "a8");
   challenge_pair_workgroup(wk, zeros, blockIdx.x, blobs, commitments48, n, z_plain);
 }
 static __global__ __launch_bounds__(192) void k_challenge_pair_and_decode(const uint8_t* __restrict__ blobs, const uint8_t* __restrict__ commitments48,

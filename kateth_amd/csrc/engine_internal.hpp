@@ -148,7 +148,7 @@ static inline void launch_challenge(const kzg_ctx* ctx, hipStream_t st, const ui
   ProfScope ps(ctx, PROF_CHALLENGE, st);
   uint64_t split_max = (uint64_t)ctx->num_cus * 4 * 64 / 2;  // 2 waves per 64 blobs, one wave per SIMD: 32,768 on 256 CUs
   if (ctx->knobs.challenge_split_max) split_max = ctx->knobs.challenge_split_max;
-  if ((uint64_t)blocks_for(n, 64) * 3 <= (uint64_t)ctx->num_cus * 4 && !ctx->knobs.challenge_split_max)
+  if ((uint64_t)blocks_for(n, 64) <= (uint64_t)ctx->num_cus && !ctx->knobs.challenge_split_max)  // one workgroup per CU
     hipLaunchKernelGGL(k_challenge_pair, dim3(blocks_for(n, 64)), dim3(192), 0, st, blobs, commitments48, n, z);  // three waves per 64 blobs, a SIMD each
   else if (n <= split_max)
     hipLaunchKernelGGL(k_challenge_split, dim3(blocks_for(n, 64)), dim3(128), 0, st, blobs, commitments48, n, z);
@@ -157,13 +157,20 @@ static inline void launch_challenge(const kzg_ctx* ctx, hipStream_t st, const ui
 }
 
 // Small batches: challenges of n blobs and decoding of n_a + n_b points in one launch (k_challenge_and_decode).
-constexpr uint64_t KZG_FUSED_PREP_MAX = 16384;  // 512 hash waves + 512 decode waves (verify): still one wave per SIMD on 256 CUs
+constexpr uint64_t KZG_FUSED_PREP_MAX = 16384;  // the two-wave kernel's limit: 512 hash waves + 512 decode waves (verify), one wave per SIMD on 256 CUs
+// Hash and decode in one launch only while every workgroup gets a CU of its own (the lane-pair kernel's three-wave workgroups
+// share SIMDs as soon as two land on one CU: measured 4.5 ms instead of 3.7 ms per hash at 12,288 blobs); beyond that the hash
+// runs alone -- still on lane pairs up to one workgroup per CU = 16,384 blobs -- and the points are decoded beside the evaluation.
+static inline bool fused_prep_fits(const kzg_ctx* ctx, uint64_t n_blobs, uint64_t n_points) {
+  if (ctx->knobs.challenge_split_max) return n_blobs <= KZG_FUSED_PREP_MAX;  // tests force the two-wave / one-lane kernels
+  return (uint64_t)blocks_for(n_blobs, 64) + blocks_for(n_points, 192) <= (uint64_t)ctx->num_cus;
+}
 static inline void launch_challenge_and_decode(const kzg_ctx* ctx, hipStream_t st, const uint8_t* blobs, const uint8_t* commitments48, uint64_t n, fr_t* z,
                                                const uint8_t* in_a, uint64_t n_a, int32_t* status_a, const uint8_t* in_b, uint64_t n_b,
                                                int32_t* status_b, uint4* affine, uint8_t* inf) {
   ProfScope ps(ctx, PROF_CHALLENGE, st);
   const uint32_t sha_wgs = (uint32_t)blocks_for(n, 64);
-  if ((uint64_t)sha_wgs * 3 + blocks_for(n_a + n_b, 64) <= (uint64_t)ctx->num_cus * 4 && !ctx->knobs.challenge_split_max) {
+  if ((uint64_t)sha_wgs + blocks_for(n_a + n_b, 192) <= (uint64_t)ctx->num_cus && !ctx->knobs.challenge_split_max) {
     // every wave still gets a SIMD of its own with three hash waves per 64 blobs: the rounds run on lane pairs
     const uint32_t dec_wgs = (uint32_t)blocks_for(n_a + n_b, 192);
     hipLaunchKernelGGL(k_challenge_pair_and_decode, dim3(sha_wgs + dec_wgs), dim3(192), 0, st, blobs, commitments48, n, z, sha_wgs, in_a, n_a, status_a,

@@ -92,7 +92,7 @@ static int32_t proof_dev_locked(const kzg_ctx* ctx, const uint8_t* d_blobs, cons
     (void)hipMemsetAsync(cstat, 0, m * sizeof(int32_t), side);
     if (d_commitments48) {
       const uint8_t* com = d_commitments48 + base * 48;
-      if (m <= KZG_FUSED_PREP_MAX) {
+      if (fused_prep_fits(ctx, m, m)) {
         // commitment check and SHA-256 challenge in one launch: both are long per-lane dependency chains and must not share SIMDs
         launch_challenge_and_decode(ctx, side, blobs, com, m, z, com, m, cstat, (const uint8_t*)nullptr, (uint64_t)0, (int32_t*)nullptr, (uint4*)nullptr,
                                     (uint8_t*)nullptr);

@@ -340,7 +340,11 @@ static int32_t session_acquire(const kzg_ctx* ctx, uint64_t n, hipStream_t st, k
     s = new (std::nothrow) kzg_verify_session();
     if (!s) return fail(KZG_FAIL_ARGUMENT, "out of host memory");
     s->ctx = ctx;
-    if (hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking) != hipSuccess ||
+    // the side stream carries the point decoder (long per-lane chains) next to the evaluation kernel's flood of short waves:
+    // highest queue priority, so that its workgroups are placed first when both kernels become runnable
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    if (hipStreamCreateWithPriority(&s->side, hipStreamNonBlocking, prio_greatest) != hipSuccess ||
         hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) != hipSuccess) {
       session_free(s);
@@ -400,13 +404,23 @@ static int32_t phase1_items(kzg_verify_session* s, const uint8_t* blobs, const u
   // 7.5 ms).  The point decoding then runs on the side stream concurrently with the evaluation kernel, whose short blocks
   // rebalance dynamically.  Small batches (everything together below one wave per SIMD) are latency-bound instead:
   // there hashing and decoding are ONE launch whose workgroups the dispatcher deals over different CUs.
-  if (decode_here && m <= KZG_FUSED_PREP_MAX && base == 0 && m == n) {
+  if (decode_here && base == 0 && m == n && fused_prep_fits(ctx, m, 2 * n)) {
     launch_challenge_and_decode(ctx, st, blobs, com, m, z, prf, n, s->stat + 2 * n, com, n, s->stat + n, s->aff, s->inf);
     (void)hipEventRecord(s->ev_join, st);
   } else {
+    // The latency hash kernels claim more than half a register file per wave, so nothing shares THEIR SIMDs and the dispatcher
+    // cannot pack them (left alone it put several workgroups on one CU: 4.7 ms instead of 3.7 ms per hash at 16,384 blobs,
+    // 5.9 instead of 4.0 ms at 32,768).  While they leave SIMDs free -- a quarter of the chip at 16,384 blobs -- the decode
+    // kernel is released before the hash is enqueued and runs there, two waves per free SIMD; otherwise it waits for the hash.
+    const uint64_t hash_wgs = blocks_for(m, 64);
+    const uint64_t hash_waves = hash_wgs <= ctx->num_cus ? 3 * hash_wgs : 2 * hash_wgs;  // lane-pair kernel, else producer/consumer pairs
+    const bool beside_hash = decode_here && !ctx->knobs.verify_serial && !ctx->knobs.challenge_split_max &&
+                             m <= (uint64_t)ctx->num_cus * 128 /* not the one-lane kernel */ &&
+                             hash_waves + (blocks_for(2 * n, 64) + 1) / 2 <= (uint64_t)ctx->num_cus * 4;
+    if (beside_hash) (void)hipEventRecord(s->ev_fork, st);
     launch_challenge(ctx, st, blobs, com + base * 48, m, z);
     if (decode_here) {
-      (void)hipEventRecord(s->ev_fork, st);
+      if (!beside_hash) (void)hipEventRecord(s->ev_fork, st);
       hipStream_t side = ctx->knobs.verify_serial ? st : s->side;
       (void)hipStreamWaitEvent(side, s->ev_fork, 0);
       {

@@ -19,7 +19,7 @@ KZG_HD void issue_fair_tick(uint32_t shift) {
   if ((((uint32_t)(__builtin_amdgcn_s_memtime() >> shift)) & 1u) == parity)
     __builtin_amdgcn_s_setprio(3);
   else
-    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_setprio(1);  // not 0: a kernel that ticks stays above one that does not (the point decoder's long chains beside the evaluation kernel)
 #else
   (void)shift;
 #endif
