@@ -462,7 +462,9 @@ extern "C" int32_t kzg_ctx_create(const uint8_t* g1_lagrange, const uint8_t* g2_
   }
   if (const char* e = getenv("KATETH_AMD_WAVE_TIMES")) {  // measurement aid (tools/gpu_wave_times.py)
     ctx->wave_times_cap = (uint64_t)atoll(e);
-    if (ctx->wave_times_cap && hipMalloc(&ctx->d_wave_times, ctx->wave_times_cap * 32) != hipSuccess) ctx->wave_times_cap = 0;
+    if (ctx->wave_times_cap && (hipMalloc(&ctx->d_wave_times, ctx->wave_times_cap * 32) != hipSuccess ||
+                                hipMemset(ctx->d_wave_times, 0, ctx->wave_times_cap * 32) != hipSuccess))
+      ctx->wave_times_cap = 0;
   }
 #endif
   int32_t rc = ctx_build(ctx, g1_lagrange, g2_monomial);

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 c = int(sys.argv[2]) if len(sys.argv) > 2 else 22
-os.environ["KATETH_AMD_WAVE_TIMES"] = str(4 * n)
+os.environ["KATETH_AMD_WAVE_TIMES"] = str(max(4 * n, 4096))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
@@ -31,12 +31,14 @@ lib = s._lib
 lib.kzg_test_read_wave_times.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]
 lib.kzg_test_read_wave_times.restype = ctypes.c_int32
 out = {}
-for units in (n // 2, n, 2 * n, 4 * n):
+for units in sorted({n // 2, n, 2 * n, 4 * n} | {n * k for k in (3, 6, 8, 12, 16, 24, 32, 48, 64)}):
+    if units == 0:
+        continue
     buf = np.zeros((units, 4), dtype=np.uint64)
     if lib.kzg_test_read_wave_times(s._h, buf.ctypes.data, units) != 0:
         continue
     if not buf[:, 1].all():
-        continue  # the launch had a different unit count
+        continue  # the launch had fewer units (the buffer is zeroed at context creation)
     t0 = buf[:, 0].min()
     start = (buf[:, 0] - t0) / 100.0  # microseconds
     end = (buf[:, 1] - t0) / 100.0
@@ -66,6 +68,6 @@ for units in (n // 2, n, 2 * n, 4 * n):
                         "longer_min_us": float(hi.min()), "longer_max_us": float(hi.max()),
                         "slot_pairs": {str(k): int(v) for k, v in zip(*np.unique(slot.min(axis=1) * 16 + slot.max(axis=1), return_counts=True))},
                         "same_parity_pairs": int(((slot[:, 0] ^ slot[:, 1]) & 1 == 0).sum())}
-    out[str(units)] = rec
+    out = {str(units): rec}  # keep the largest unit count whose stamps are all set = the launch's own
 print(json.dumps(out, indent=1))
 s.close()
