@@ -101,6 +101,14 @@ static __global__ __launch_bounds__(64) void k_g1_decompress(const uint8_t* __re
                                                       uint4* __restrict__ affine, uint8_t* __restrict__ inf) {
   g1_decompress_item((uint64_t)blockIdx.x * blockDim.x + threadIdx.x, in_a, n_a, status_a, in_b, n_b, status_b, affine, inf);
 }
+// items [first, first + count) of the same list: a batch whose points are decoded in two launches (beside the hash kernel as
+// far as SIMDs are free, the rest after it)
+static __global__ __launch_bounds__(64) void k_g1_decompress_range(uint64_t first, uint64_t count, const uint8_t* __restrict__ in_a, uint64_t n_a,
+                                                            int32_t* __restrict__ status_a, const uint8_t* __restrict__ in_b, uint64_t n_b,
+                                                            int32_t* __restrict__ status_b, uint4* __restrict__ affine, uint8_t* __restrict__ inf) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < count) g1_decompress_item(first + t, in_a, n_a, status_a, in_b, n_b, status_b, affine, inf);
+}
 
 // ---------------------------------------------------------------------------
 // K4: Blob::challenge (src/blob.rs:78-97) -- z = SHA-256("FSBLOBVERIFY_V1_" ||

@@ -410,23 +410,35 @@ static int32_t phase1_items(kzg_verify_session* s, const uint8_t* blobs, const u
   } else {
     // The latency hash kernels claim more than half a register file per wave, so nothing shares THEIR SIMDs and the dispatcher
     // cannot pack them (left alone it put several workgroups on one CU: 4.7 ms instead of 3.7 ms per hash at 16,384 blobs,
-    // 5.9 instead of 4.0 ms at 32,768).  While they leave SIMDs free -- a quarter of the chip at 16,384 blobs -- the decode
-    // kernel is released before the hash is enqueued and runs there, two waves per free SIMD; otherwise it waits for the hash.
+    // 5.9 instead of 4.0 ms at 32,768).  The SIMDs they leave free -- a quarter of the chip at 16,384 blobs -- take decode waves,
+    // two each: while the hash leaves SIMDs free the decode kernel is released as soon as the hash is enqueued and runs beside
+    // it; when the hash fills the chip (from ~30,700 blobs on, and always with the one-lane hash) it waits for the hash and runs
+    // beside the evaluation kernel.
     const uint64_t hash_wgs = blocks_for(m, 64);
     const uint64_t hash_waves = hash_wgs <= ctx->num_cus ? 3 * hash_wgs : 2 * hash_wgs;  // lane-pair kernel, else producer/consumer pairs
-    const bool beside_hash = decode_here && !ctx->knobs.verify_serial && !ctx->knobs.challenge_split_max &&
-                             m <= (uint64_t)ctx->num_cus * 128 /* not the one-lane kernel */ &&
-                             hash_waves + (blocks_for(2 * n, 64) + 1) / 2 <= (uint64_t)ctx->num_cus * 4;
-    if (beside_hash) (void)hipEventRecord(s->ev_fork, st);
-    launch_challenge(ctx, st, blobs, com + base * 48, m, z);
-    if (decode_here) {
-      if (!beside_hash) (void)hipEventRecord(s->ev_fork, st);
-      hipStream_t side = ctx->knobs.verify_serial ? st : s->side;
+    const uint64_t simds = (uint64_t)ctx->num_cus * 4;
+    uint64_t beside = 0;  // points decoded beside the hash
+    if (decode_here && !ctx->knobs.verify_serial && !ctx->knobs.challenge_split_max && m <= (uint64_t)ctx->num_cus * 128 /* not the one-lane kernel */ &&
+        hash_waves + 64 <= simds)
+      beside = 2 * n;  // all of them: what does not fit beside the hash is at least queued AHEAD of the evaluation kernel's waves
+                       // (measured, ms per call at 24,000 / 28,000 / 30,000 / 32,768 triples: only what fits 10.5 / 11.4 / 11.9 / 10.9,
+                       // everything 9.0 / 10.0 / 10.6 / 11.6 -- so not when the hash fills the chip)
+    hipStream_t side = ctx->knobs.verify_serial ? st : s->side;
+    if (beside) (void)hipEventRecord(s->ev_fork, st);  // the inputs are ready here
+    launch_challenge(ctx, st, blobs, com + base * 48, m, z);  // enqueued first: its workgroups must find their SIMDs empty
+    if (beside) {
       (void)hipStreamWaitEvent(side, s->ev_fork, 0);
-      {
+      ProfScope ps(ctx, PROF_DECODE, side);
+      hipLaunchKernelGGL(k_g1_decompress_range, dim3(blocks_for(beside, 64)), dim3(64), 0, side, (uint64_t)0, beside, prf, n, s->stat + 2 * n, com, n,
+                         s->stat + n, s->aff, s->inf);
+    }
+    if (decode_here) {
+      if (beside < 2 * n) {
+        (void)hipEventRecord(s->ev_fork, st);  // re-recorded: the first wait is already enqueued
+        (void)hipStreamWaitEvent(side, s->ev_fork, 0);
         ProfScope ps(ctx, PROF_DECODE, side);
-        hipLaunchKernelGGL(k_g1_decompress, dim3(blocks_for(2 * n, 64)), dim3(64), 0, side, prf, n, s->stat + 2 * n, com, n, s->stat + n, s->aff,
-                           s->inf);
+        hipLaunchKernelGGL(k_g1_decompress_range, dim3(blocks_for(2 * n - beside, 64)), dim3(64), 0, side, beside, 2 * n - beside, prf, n,
+                           s->stat + 2 * n, com, n, s->stat + n, s->aff, s->inf);
       }
       (void)hipEventRecord(s->ev_join, side);
     }
