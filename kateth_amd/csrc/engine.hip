@@ -76,6 +76,7 @@ uint32_t choose_splits(const kzg_ctx* ctx, uint64_t n) {
   // aim for >= 4 waves per SIMD-slot-pair across the chip; splits is a power of two <= 64
   const uint64_t target = (uint64_t)ctx->num_cus * 8;
   if (ctx->use_comb) {  // a lane must own a whole number of blocks: splits divides (64 * nb) / lpg; k_msm_reduce_splits sums <= 64 units
+    if (ctx->d_table_lat && n <= KZG_LAT_MAX_BLOBS && !ctx->knobs.msm_splits) return KZG_LAT_SPLITS;  // the latency comb: 8 blocks x 4 planes per lane
     const uint32_t per_lane = (64u * ctx->comb.nb) / ctx->comb.lpg;
     auto ok = [&](uint32_t v) { return v >= 1 && v <= 64 && per_lane % v == 0; };
     if (ctx->knobs.msm_splits && ok(ctx->knobs.msm_splits)) return ctx->knobs.msm_splits;
@@ -185,6 +186,7 @@ EnvKnobs read_env_knobs() {
     if (const char* e = getenv("KATETH_AMD_VAR_MSM")) k.var_msm_classic = std::string(e) == "classic";
     if (const char* e = getenv("KATETH_AMD_VERIFY_CHUNK")) k.verify_chunk = (uint64_t)atoll(e) > 0 ? (uint64_t)atoll(e) : 0;
     k.comb_full_wave = getenv("KATETH_AMD_COMB_FULL_WAVE") != nullptr;
+    if (const char* e = getenv("KATETH_AMD_LAT_TABLE")) k.lat_table = atoi(e) != 0;
     if (const char* e = getenv("KATETH_AMD_COMB_FAIR")) k.comb_fair = (uint32_t)atoi(e) < 40u ? (uint32_t)atoi(e) : 0u;
     if (const char* e = getenv("KATETH_AMD_MSM_SPLITS")) {
       const int v = atoi(e);
@@ -203,6 +205,7 @@ extern "C" void kzg_ctx_destroy(kzg_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipDeviceSynchronize();
   if (ctx->d_table) (void)hipFree(ctx->d_table);
+  if (ctx->d_table_lat) (void)hipFree(ctx->d_table_lat);
   if (ctx->d_bases_brp) (void)hipFree(ctx->d_bases_brp);
   if (ctx->d_roots_brp) (void)hipFree(ctx->d_roots_brp);
   if (ctx->d_eval_tab) (void)hipFree(ctx->d_eval_tab);
@@ -242,11 +245,11 @@ struct ScratchAllocs {
 
 // ---- comb table (msm_comb.cuh): G groups x 64 chunks x ep64 subset sums, built a few chunks at a time through an XYZZ
 // staging buffer and the batch normaliser of the window table ----
-static int32_t comb_build(kzg_ctx* ctx, ScratchAllocs& scratch, TraceTimer& tt) {
-  const CombGeom cg = ctx->comb;
+static int32_t comb_build_table(kzg_ctx* ctx, const CombGeom& cg, uint4** out_table, ScratchAllocs& scratch, TraceTimer& tt) {
   hipStream_t st = nullptr;
-  ctx->table_bytes = comb_table_entries(cg) * 96;
-  HIP_TRY(hipMalloc(&ctx->d_table, ctx->table_bytes));
+  uint4* d_table = nullptr;
+  HIP_TRY(hipMalloc(&d_table, comb_table_entries(cg) * 96));
+  *out_table = d_table;  // owned by the context from here on (freed in kzg_ctx_destroy)
   tt.mark("table allocation");
   uint4 *d_B = nullptr, *d_D = nullptr;
   HIP_TRY(scratch.alloc(&d_B, (size_t)cg.G * 4096 * 96));
@@ -267,10 +270,24 @@ static int32_t comb_build(kzg_ctx* ctx, ScratchAllocs& scratch, TraceTimer& tt) 
       constexpr int KN = 8;
       const uint64_t count = (uint64_t)nq * cg.ep64;
       const uint64_t nthreads = (count + KN - 1) / KN;
-      hipLaunchKernelGGL(k_table_normalize<KN>, dim3((unsigned)((nthreads + 63) / 64)), dim3(64), 0, st, d_tmp, count, ctx->d_table,
+      hipLaunchKernelGGL(k_table_normalize<KN>, dim3((unsigned)((nthreads + 63) / 64)), dim3(64), 0, st, d_tmp, count, d_table,
                          (uint64_t)grp * cg.epg + (uint64_t)q0 * cg.ep64, true);
       HIP_TRY(hipGetLastError());
     }
+  }
+  HIP_TRY(hipDeviceSynchronize());
+  tt.mark("comb table build kernels");
+  return 0;
+}
+static int32_t comb_build(kzg_ctx* ctx, ScratchAllocs& scratch, TraceTimer& tt) {
+  ctx->table_bytes = comb_table_entries(ctx->comb) * 96;
+  int32_t rc = comb_build_table(ctx, ctx->comb, &ctx->d_table, scratch, tt);
+  if (rc) return rc;
+  if (ctx->comb.nb == 3 && ctx->knobs.lat_table) {  // class 22: the latency comb beside it
+    ctx->comb_lat = comb_make_geom(8, 64);
+    ctx->comb_lat.fair = ctx->comb.fair;
+    rc = comb_build_table(ctx, ctx->comb_lat, &ctx->d_table_lat, scratch, tt);
+    if (rc) return rc;
   }
   // K = [c0] G on the host (255 doublings + additions of the generator, once)
   {

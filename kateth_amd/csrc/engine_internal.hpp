@@ -40,6 +40,7 @@ struct EnvKnobs {
   bool var_msm_classic = false;  // KATETH_AMD_VAR_MSM=classic: c = 8 with per-bucket partials for every batch size (cross-check of the flat path)
   uint64_t verify_chunk = 0;     // KATETH_AMD_VERIFY_CHUNK: blobs per host-buffer staging chunk (0 = default)
   uint32_t comb_fair = 20;       // KATETH_AMD_COMB_FAIR=s: the MSM waves of a SIMD trade issue priority every 2^s cycles; 0 = hardware default (measurement aid)
+  bool lat_table = true;         // KATETH_AMD_LAT_TABLE=0: no latency comb beside a class-22 table (measurement aid)
   bool comb_full_wave = false;   // KATETH_AMD_COMB_FULL_WAVE: never use the comb's two-blobs-per-wave mode (measurement aid)
   uint32_t msm_splits = 0;       // KATETH_AMD_MSM_SPLITS: force the (blob, split) decomposition of the fixed-base MSM (power of two <= 64; 0 = automatic)
   uint64_t challenge_split_max = 0;  // KATETH_AMD_CHALLENGE_SPLIT_MAX: largest batch hashed by the two-wave SHA-256 kernel (0 = default)
@@ -80,6 +81,10 @@ struct kzg_ctx {
   uint64_t* d_wave_times = nullptr;  // test build, KATETH_AMD_WAVE_TIMES=<units>: per-unit timestamps of the last k_msm_comb28 launch
   uint64_t wave_times_cap = 0;
 #endif
+  // class 22 only: a second, small comb for latency (blocks of 8 points, 64 plane groups of 4 planes: 3 doublings per lane
+  // instead of 31, 403 MB) used by calls of at most KZG_LAT_MAX_BLOBS blobs, where a lane's chain -- not the chip -- is the cost
+  CombGeom comb_lat{};
+  uint4* d_table_lat = nullptr;
   uint4* d_comb_k = nullptr;     // the comb's constant term K = [(2^256-1)/2] G, affine, canonical 2^384-Montgomery (96 B)
   uint32_t window_class = 0;     // what kzg_ctx_window_bits reports
   uint4* d_bases_brp = nullptr;  // 4096 affine Lagrange points, BRP order
@@ -184,6 +189,9 @@ static inline void launch_challenge_and_decode(const kzg_ctx* ctx, hipStream_t s
 
 // The comb's half-wave mode: once a batch fills the chip with two blobs per wave, a blob takes 32 lanes (each lane owns
 // twice the blocks for the same number of Horner doublings).  Units = waves of the MSM kernel = rows of 64 lane sums.
+constexpr uint64_t KZG_LAT_MAX_BLOBS = 16;
+constexpr uint32_t KZG_LAT_SPLITS = 64;  // the main class-22 comb never splits 64 ways (24 blocks per lane), so the split count names the table
+static inline bool msm_uses_lat(const kzg_ctx* ctx, uint32_t splits) { return ctx->d_table_lat != nullptr && splits == KZG_LAT_SPLITS; }
 static inline uint32_t msm_lanes_per_blob(const kzg_ctx* ctx, uint64_t n, uint32_t splits) {
   if (!ctx->use_comb || splits != 1 || ctx->knobs.comb_full_wave) return 64;
   if (ctx->comb.G > 32 || (64u * ctx->comb.nb) % (32u / ctx->comb.G) != 0) return 64;
@@ -206,11 +214,14 @@ static int32_t msm_launch(const kzg_ctx* ctx, const uint8_t* d_scalars, uint64_t
       hipLaunchKernelGGL((k_comb_transpose<BE_BYTES>), dim3((unsigned)(n * 8)), dim3(512), 0, st, d_scalars, n, masks, d_status);
     }
     ProfScope ps(ctx, PROF_MSM_FIXED, st);
-    #if defined(KZG_TEST_WINDOW_MSM)
-    hipLaunchKernelGGL(k_msm_comb28, dim3((unsigned)msm_units(n, splits, lpb)), dim3(64), 0, st, masks, n, splits, lpb, ctx->d_table, ctx->comb, partials,
+    const bool lat = msm_uses_lat(ctx, splits);
+    const uint4* table = lat ? ctx->d_table_lat : ctx->d_table;
+    const CombGeom geom = lat ? ctx->comb_lat : ctx->comb;
+#if defined(KZG_TEST_WINDOW_MSM)
+    hipLaunchKernelGGL(k_msm_comb28, dim3((unsigned)msm_units(n, splits, lpb)), dim3(64), 0, st, masks, n, splits, lpb, table, geom, partials,
                        msm_units(n, splits, lpb) <= ctx->wave_times_cap ? ctx->d_wave_times : (uint64_t*)nullptr);
 #else
-    hipLaunchKernelGGL(k_msm_comb28, dim3((unsigned)msm_units(n, splits, lpb)), dim3(64), 0, st, masks, n, splits, lpb, ctx->d_table, ctx->comb, partials);
+    hipLaunchKernelGGL(k_msm_comb28, dim3((unsigned)msm_units(n, splits, lpb)), dim3(64), 0, st, masks, n, splits, lpb, table, geom, partials);
 #endif
     HIP_TRY(hipGetLastError());
     return 0;

@@ -1252,6 +1252,56 @@ def test_bench_rank_launcher_two_real_engine_ranks_on_one_card(workload):
     assert bad.returncode != 0 and "WORLD_SIZE=2" in (bad.stdout + bad.stderr)
 
 
+def test_latency_comb_of_the_class_22_table(engine, torch_cuda, monkeypatch):
+    """a class-22 context carries a second, small comb (blocks of 8 points, 64 plane groups) for calls of at most 16 blobs:
+    commitments and proofs of 1, 3, 16 (latency comb) and 17 (main comb) blobs must equal the class-8 engine's, with the
+    latency comb switched off (KATETH_AMD_LAT_TABLE=0) as well, and an invalid blob keeps its status"""
+    import kateth_amd
+
+    torch = torch_cuda
+    n = 17
+    d_blobs = torch.empty(n * 131072, dtype=torch.uint8, device="cuda")
+    engine.synth_blobs_dev(0x1A7, 9, n, d_blobs.data_ptr())
+    d_blobs[2 * 131072 + 32 * 100: 2 * 131072 + 32 * 100 + 32] = 0xFF  # blob 2, element 100: not canonical
+    want_c = torch.empty(n * 48, dtype=torch.uint8, device="cuda")
+    want_p = torch.empty(n * 48, dtype=torch.uint8, device="cuda")
+    st = torch.empty(n, dtype=torch.int32, device="cuda")
+    engine.blob_to_commitment_batch_dev(d_blobs.data_ptr(), n, want_c.data_ptr(), st.data_ptr())
+    torch.cuda.synchronize()
+    want_st = st.cpu().tolist()
+    assert want_st[2] == 2 and sum(1 for v in want_st if v) == 1
+    want_c[2 * 48: 3 * 48] = want_c[0:48]  # a decodable commitment for the bad blob
+    engine.compute_blob_proof_batch_dev(d_blobs.data_ptr(), want_c.data_ptr(), n, want_p.data_ptr(), st.data_ptr())
+    torch.cuda.synchronize()
+    want_pst = st.cpu().tolist()
+    wc, wp = want_c.cpu().numpy().tobytes(), want_p.cpu().numpy().tobytes()
+    for env in ({}, {"KATETH_AMD_LAT_TABLE": "0"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        big = kateth_amd.Setup.load_json(TRUSTED_SETUP, window_bits=22)
+        try:
+            for m in (1, 3, 16, 17):
+                c = torch.zeros(m * 48, dtype=torch.uint8, device="cuda")
+                p = torch.zeros(m * 48, dtype=torch.uint8, device="cuda")
+                s2 = torch.full((m,), -7, dtype=torch.int32, device="cuda")
+                big.blob_to_commitment_batch_dev(d_blobs.data_ptr(), m, c.data_ptr(), s2.data_ptr())
+                torch.cuda.synchronize()
+                assert s2.cpu().tolist() == want_st[:m], (env, m)
+                got = c.cpu().numpy().tobytes()
+                for i in range(m):
+                    if i != 2:
+                        assert got[48 * i: 48 * i + 48] == wc[48 * i: 48 * i + 48], (env, m, i)
+                big.compute_blob_proof_batch_dev(d_blobs.data_ptr(), want_c.data_ptr(), m, p.data_ptr(), s2.data_ptr())
+                torch.cuda.synchronize()
+                assert s2.cpu().tolist() == want_pst[:m], (env, m)
+                gotp = p.cpu().numpy().tobytes()
+                for i in range(m):
+                    if want_pst[i] == 0:
+                        assert gotp[48 * i: 48 * i + 48] == wp[48 * i: 48 * i + 48], (env, m, i)
+        finally:
+            big.close()
+
+
 def test_half_wave_mode_on_an_odd_batch(engine, torch_cuda):
     """from 4,096 blobs on, the comb MSM carries two blobs per wave (32 lanes each); an odd batch leaves the last wave half
     empty.  Commitments and proofs of 4,099 blobs equal, item for item, those of the same blobs computed in small batches
