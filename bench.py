@@ -57,8 +57,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", choices=("commit", "proof", "verify"), default="commit")
     ap.add_argument("--batch", type=int, default=0, help="blobs per GPU per step (default: 4096 commit/proof, 65536 verify; configs[4]: 131072 with --gpus 8)")
-    ap.add_argument("--window-bits", type=int, default=int(os.environ.get("KATETH_AMD_WINDOW_BITS", "22")),
-                    help="index bits per lookup of the fixed-base comb table (22 -> blocks of 22+21+21 points, 103 GB of the 288 GB HBM, 49,152 additions per blob; 16 -> 3.2 GB, 65,536 additions: the library default; 8 -> 25 MB); falls back to smaller classes if the table cannot be allocated")
+    ap.add_argument("--window-bits", type=int, default=int(os.environ.get("KATETH_AMD_WINDOW_BITS", "0")),
+                    help="table class of the fixed-base comb (include/kateth_amd.h, kzg_config): 0 = the library default = the fastest class the device has room for "
+                         "(class 22: blocks of 22+21+21 points, 8 plane groups = 192 GiB of the 288 GB HBM, 49,152 additions per blob; 4 groups = 96 GiB below 232 GiB free); "
+                         "16 -> 12.9 GB, 65,536 additions; 8 -> 100 MB, 131,072 additions")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL, the measured path) or gloo (rehearsal: ranks may share one card, gathers go through the host)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary proof/verify workloads")
@@ -214,8 +216,8 @@ class Rank:
         self.setup_path = os.path.join(ROOT, "tests", "golden", "trusted_setup_4096.json")
         t0 = time.time()
         self.setup, tried = None, []
-        for c in [args.window_bits] + [w for w in (16, 8) if w < args.window_bits]:
-            try:  # the table is sized for 288 GB of HBM; step down if this device cannot hold it
+        for c in [args.window_bits] + [w for w in (16, 8) if 0 < w < args.window_bits]:
+            try:  # an explicitly requested class that cannot be allocated steps down (0 = the engine chooses by free memory)
                 self.setup = kateth_amd.Setup.load_json(self.setup_path, device=self.local_dev, window_bits=c)
                 break
             except kateth_amd.kzg.EngineError as err:

@@ -56,19 +56,37 @@ extern "C" {
 #define KZG_FAIL_NO_DEVICE (-3)
 #define KZG_FAIL_SETUP_G1 (-4) /* LoadSetupError::Bls on a g1_lagrange point, src/kzg/setup.rs:59-64 */
 #define KZG_FAIL_SETUP_G2 (-5) /* LoadSetupError::Bls on a g2_monomial point, src/kzg/setup.rs:67-72 */
+/* A setup the comb table cannot represent: some +-1 combination of a block of consecutive g1_lagrange points is the point
+ * at infinity (repeated / opposite points).  The reference would load it; no ceremony output or set of independent points
+ * is affected.  Rejected at creation instead of producing wrong commitments. */
+#define KZG_FAIL_SETUP_UNSUPPORTED (-6)
 
 typedef struct kzg_ctx kzg_ctx;
 
+/*
+ * The fixed-base MSM table is a subset-sum comb (kateth_amd/csrc/msm_comb.cuh): the 4096 Lagrange points are cut into blocks
+ * of t consecutive points, a table entry (96 B, affine) is one +-1 combination of a block, and the 256 bit planes of the
+ * scalars are cut into G plane groups with a table each.  Table bytes = G * 64 * e * 96 with e entries per 64 points and
+ * group; mixed additions per blob = 256 * (blocks per 64 points) * 64; a lane doubles its accumulator 256/G - 1 times.
+ *
+ *   class | blocks per 64 points | e        | default G | resident table   | additions per blob
+ *   ------+----------------------+----------+-----------+------------------+-------------------
+ *    22   | 22 + 21 + 21 points  | 2^22     | 8 (or 4)  | 192 GiB (96 GiB) | 49,152
+ *    16   | 4 x 16               | 4 * 2^15 | 16        | 12.9 GB          | 65,536
+ *     8   | 8 x 8                | 8 * 2^7  | 16        | 100.7 MB         | 131,072
+ *     4   | 16 x 4               | 16 * 2^3 | 16        | 12.6 MB          | 262,144
+ *
+ * Class 22 also keeps a 403-MB latency comb (blocks of 8 points, 64 plane groups) for calls of at most 16 blobs.  Building
+ * a table needs up to 13 GB of transient device scratch (XYZZ staging for the batch normalisation) on top of it.
+ */
 typedef struct kzg_config {
-  int32_t device;      /* HIP device ordinal this context lives on */
-  int32_t window_bits; /* index bits per lookup of the fixed-base MSM table, 4..22; 0 = default (16).  The table is a subset-sum
-                        * comb over blocks of t consecutive Lagrange points (msm_comb.cuh): t = 22 -> 103 GB and 49,152 additions
-                        * per blob; 16..21 -> blocks of 16, 3.2 GB, 65,536 additions; 8..15 -> blocks of 8 (25 MB); 4..7 -> blocks
-                        * of 4.  kzg_ctx_window_bits reports the class in use (22, 16, 8 or 4) */
-  int32_t flags;       /* reserved, must be 0 */
-  int32_t reserved;    /* plane groups G of the comb (tables; 1, 2, 4, 8 or 16); 0 = automatic: 16 for the small classes, 8 for
-                        * class 22 when the device has room for 192 GiB, else 4.  Table = G * 64 * e * 96 B with e = 2^22 (class 22),
-                        * 4 * 2^15 (16), 8 * 2^7 (8), 16 * 2^3 (4); a lane doubles its accumulator 256/G - 1 times per blob */
+  int32_t device;       /* HIP device ordinal this context lives on */
+  int32_t window_bits;  /* table class: 22, 16..21 (-> 16), 8..15 (-> 8), 4..7 (-> 4); 0 = AUTOMATIC: the fastest class the device
+                         * has room for when the context is created -- class 22 with G = 8 if >= 232 GiB are free, class 22 with
+                         * G = 4 if >= 136 GiB, class 16 if >= 21 GiB, else class 8.  kzg_ctx_window_bits / kzg_ctx_plane_groups /
+                         * kzg_ctx_table_bytes report what was built */
+  int32_t flags;        /* reserved, must be 0 */
+  int32_t plane_groups; /* G: 1, 2, 4, 8 or 16; 0 = automatic (see the table; class 22: 8 if >= 232 GiB are free, else 4) */
 } kzg_config;
 
 /* Thread-local text for the last negative return on this thread ("" if none). */
@@ -213,9 +231,11 @@ int32_t kzg_selftest_field_mul(const kzg_ctx* ctx, uint64_t lanes, uint64_t iter
 
 /*
  * Kernel timing for bench.py's `roofline` object: between begin and end every
- * launch of the dominant kernel (k_msm_fixed) is bracketed by HIP events on the
+ * launch of the timed kernel classes (below) is bracketed by HIP events on the
  * stream it is launched on.  end() synchronises those events and returns the
- * summed kernel milliseconds and the number of launches.
+ * summed milliseconds and the number of launches of the fixed-base MSM kernel
+ * (k_msm_comb28).  A profiling interval must not overlap calls still being
+ * enqueued from other threads (their unfinished event pairs are skipped).
  */
 int32_t kzg_profile_begin(const kzg_ctx* ctx);
 int32_t kzg_profile_end(const kzg_ctx* ctx, double* msm_ms_total, uint64_t* msm_launches);
@@ -227,7 +247,7 @@ int32_t kzg_profile_end(const kzg_ctx* ctx, double* msm_ms_total, uint64_t* msm_
 #define KZG_PROF_KINDS 8
 int32_t kzg_profile_end_kinds(const kzg_ctx* ctx, double* ms, uint64_t* launches);
 const char* kzg_profile_kind_name(int32_t kind);
-/* mixed additions the fixed-base MSM performs per blob: ceil(256/c) * 4096 */
+/* mixed additions the fixed-base MSM performs per blob: 256 bit planes x (blocks per 64 points) x 64 (table above) */
 uint64_t kzg_ctx_adds_per_blob(const kzg_ctx* ctx);
 
 #ifdef __cplusplus

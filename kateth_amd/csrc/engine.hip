@@ -59,18 +59,7 @@ int32_t ws_release(const kzg_ctx* ctx, hipStream_t st) {
 }
 
 
-static MsmGeom make_geom(uint32_t c) {
-  MsmGeom g;
-  g.c = c;
-  g.W = (256 + c - 1) / c;
-  g.half = 1u << (c - 1);
-  // largest raw top digit of a scalar < 2^255, plus a possible carry
-  uint32_t top_bits_lo = c * (g.W - 1);
-  uint32_t top_raw_max = (top_bits_lo >= 255) ? 0u : ((1u << (255 - top_bits_lo)) - 1u);
-  uint32_t top = top_raw_max + 1u;
-  g.top_entries = top < g.half ? top : g.half;
-  return g;
-}
+const MsmOverride* (*g_msm_override_hook)(kzg_ctx* ctx, uint32_t window_bits) = nullptr;  // set only by the test-only library (tests/window_msm)
 
 uint32_t choose_splits(const kzg_ctx* ctx, uint64_t n) {
   // aim for >= 4 waves per SIMD-slot-pair across the chip; splits is a power of two <= 64
@@ -88,6 +77,7 @@ uint32_t choose_splits(const kzg_ctx* ctx, uint64_t n) {
     }
     return best;
   }
+  // test-only window-table override: any power of two
   if (ctx->knobs.msm_splits) return ctx->knobs.msm_splits;
   uint32_t s = 1;
   while (s < 64 && n * s < target) s <<= 1;
@@ -96,32 +86,21 @@ uint32_t choose_splits(const kzg_ctx* ctx, uint64_t n) {
 
 extern "C" uint64_t kzg_ctx_adds_per_blob(const kzg_ctx* ctx) {
   if (!ctx) return 0;
-  return ctx->use_comb ? (uint64_t)256u * 64u * ctx->comb.nb : (uint64_t)ctx->geom.W * 4096u;
+  return ctx->use_comb ? (uint64_t)256u * 64u * ctx->comb.nb : ctx->msm_override->adds_per_blob;
 }
 
 extern "C" int32_t kzg_profile_begin(const kzg_ctx* ctx) {
   if (!ctx) return fail(KZG_FAIL_ARGUMENT, "null argument");
   std::lock_guard<std::mutex> guard(ctx->prof_lock);
-  ctx->profiling = true;
   ctx->prof_used = 0;
+  ctx->profiling.store(true);
   return 0;
 }
 
-static const char* const PROF_NAMES[PROF_KINDS] = {"k_msm_fixed28", "k_challenge*", "k_eval_frac", "k_g1_decompress", "k_poly",
+static const char* const PROF_NAMES[PROF_KINDS] = {"k_msm_comb28", "k_challenge*", "k_eval_frac", "k_g1_decompress", "k_poly",
                                                     "k_var_* (two lincombs)", "k_msm_reduce* + k_g1_compress", "k_comb_transpose"};
-#if defined(KZG_TEST_WINDOW_MSM)
-// test build only: {wall-clock start, wall-clock end (100 MHz ticks), shader cycles, XCC_ID << 32 | HW_ID} of each unit of the
-// most recent k_msm_comb28 launch that fitted the buffer
-extern "C" int32_t kzg_test_read_wave_times(const kzg_ctx* ctx, uint64_t* out, uint64_t units) {
-  if (!ctx || !ctx->d_wave_times || units > ctx->wave_times_cap) return fail(KZG_FAIL_ARGUMENT, "no wave-time buffer");
-  HIP_TRY(hipSetDevice(ctx->device));
-  HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(out, ctx->d_wave_times, units * 32, hipMemcpyDeviceToHost));
-  return 0;
-}
-#endif
 
-extern "C" const char* kzg_ctx_msm_kernel_name(const kzg_ctx* ctx) { return (ctx && !ctx->use_comb) ? (ctx->msm_radix28 ? "k_msm_fixed28" : "k_msm_fixed") : "k_msm_comb28"; }
+extern "C" const char* kzg_ctx_msm_kernel_name(const kzg_ctx* ctx) { return (ctx && ctx->msm_override) ? ctx->msm_override->kernel_name : "k_msm_comb28"; }
 extern "C" int32_t kzg_ctx_plane_groups(const kzg_ctx* ctx) { return (ctx && ctx->use_comb) ? (int32_t)ctx->comb.G : 0; }
 extern "C" const char* kzg_profile_kind_name(int32_t kind) { return (kind >= 0 && kind < PROF_KINDS) ? PROF_NAMES[kind] : ""; }
 
@@ -133,15 +112,19 @@ extern "C" int32_t kzg_profile_end_kinds(const kzg_ctx* ctx, double* ms_out, uin
     ms_out[k] = 0;
     launches[k] = 0;
   }
+  // Profiling must not overlap calls that are still being ENQUEUED on other threads (a pair whose second event is not yet
+  // recorded cannot be read): such pairs are skipped, never fatal, and the interval always ends.
+  ctx->profiling.store(false);
   for (size_t i = 0; i < ctx->prof_used; i++) {
     float ms = 0;
     const ProfEvent& pe = ctx->prof_events[i];
-    HIP_TRY(hipEventSynchronize(pe.e1));
-    HIP_TRY(hipEventElapsedTime(&ms, pe.e0, pe.e1));
+    if (hipEventSynchronize(pe.e1) != hipSuccess || hipEventElapsedTime(&ms, pe.e0, pe.e1) != hipSuccess) {
+      (void)hipGetLastError();
+      continue;
+    }
     ms_out[pe.kind] += ms;
     launches[pe.kind]++;
   }
-  ctx->profiling = false;
   ctx->prof_used = 0;
   return 0;
 }
@@ -161,7 +144,7 @@ extern "C" int32_t kzg_profile_end(const kzg_ctx* ctx, double* msm_ms_total, uin
 int32_t prof_next(const kzg_ctx* ctx, int kind, hipEvent_t* e0, hipEvent_t* e1) {
   *e0 = *e1 = nullptr;
   std::lock_guard<std::mutex> guard(ctx->prof_lock);
-  if (!ctx->profiling) return 0;
+  if (!ctx->profiling.load()) return 0;
   if (ctx->prof_used == ctx->prof_events.size()) {
     hipEvent_t a, b;
     HIP_TRY(hipEventCreate(&a));
@@ -211,9 +194,7 @@ extern "C" void kzg_ctx_destroy(kzg_ctx* ctx) {
   if (ctx->d_eval_tab) (void)hipFree(ctx->d_eval_tab);
   if (ctx->d_gen_affine) (void)hipFree(ctx->d_gen_affine);
   if (ctx->d_comb_k) (void)hipFree(ctx->d_comb_k);
-#if defined(KZG_TEST_WINDOW_MSM)
-  if (ctx->d_wave_times) (void)hipFree(ctx->d_wave_times);
-#endif
+  if (ctx->msm_override && ctx->msm_override->destroy) ctx->msm_override->destroy(ctx);
   delete ctx->pairing;
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
@@ -263,6 +244,9 @@ static int32_t comb_build_table(kzg_ctx* ctx, const CombGeom& cg, uint4** out_ta
   while (nq > 1 && (uint64_t)nq * cg.ep64 * sizeof(g1_xyzz) > (13ull << 30)) nq >>= 1;
   g1_xyzz* d_tmp = nullptr;
   HIP_TRY(scratch.alloc(&d_tmp, (size_t)nq * cg.ep64 * sizeof(g1_xyzz)));
+  uint32_t* d_inf_seen = nullptr;
+  HIP_TRY(scratch.alloc(&d_inf_seen, sizeof(uint32_t)));
+  HIP_TRY(hipMemsetAsync(d_inf_seen, 0, sizeof(uint32_t), st));
   for (uint32_t grp = 0; grp < cg.G; grp++) {
     for (uint32_t q0 = 0; q0 < 64; q0 += nq) {
       const uint64_t threads = (uint64_t)nq * (cg.ep64 >> sl);
@@ -271,12 +255,19 @@ static int32_t comb_build_table(kzg_ctx* ctx, const CombGeom& cg, uint4** out_ta
       const uint64_t count = (uint64_t)nq * cg.ep64;
       const uint64_t nthreads = (count + KN - 1) / KN;
       hipLaunchKernelGGL(k_table_normalize<KN>, dim3((unsigned)((nthreads + 63) / 64)), dim3(64), 0, st, d_tmp, count, d_table,
-                         (uint64_t)grp * cg.epg + (uint64_t)q0 * cg.ep64, true);
+                         (uint64_t)grp * cg.epg + (uint64_t)q0 * cg.ep64, true, d_inf_seen);
       HIP_TRY(hipGetLastError());
     }
   }
-  HIP_TRY(hipDeviceSynchronize());
+  uint32_t inf_seen = 0;
+  HIP_TRY(hipMemcpy(&inf_seen, d_inf_seen, sizeof(uint32_t), hipMemcpyDeviceToHost));
   tt.mark("comb table build kernels");
+  // A subset sum sum_p +-L_p over a block of consecutive setup points is the identity (e.g. repeated or opposite points):
+  // the table cannot hold it (affine entries).  The reference's P1::lincomb would accept such a setup; the ceremony file and
+  // any setup of independent points cannot produce one.  Rejected loudly rather than committed to wrongly.
+  if (inf_seen)
+    return fail(KZG_FAIL_SETUP_UNSUPPORTED, "degenerate setup: a +-1 combination of consecutive g1_lagrange points is the point at infinity "
+                                   "(repeated / opposite points); the fixed-base comb table cannot represent it");
   return 0;
 }
 static int32_t comb_build(kzg_ctx* ctx, ScratchAllocs& scratch, TraceTimer& tt) {
@@ -289,39 +280,51 @@ static int32_t comb_build(kzg_ctx* ctx, ScratchAllocs& scratch, TraceTimer& tt) 
     rc = comb_build_table(ctx, ctx->comb_lat, &ctx->d_table_lat, scratch, tt);
     if (rc) return rc;
   }
-  // K = [c0] G on the host (255 doublings + additions of the generator, once)
+  // K = [c0] S with S = sum of the setup points, summed on the device.  For a Lagrange basis S is the G1 generator (the
+  // basis sums to one), but Setup::load_json (src/kzg/setup.rs:46-82) accepts any in-group points and P1::lincomb is
+  // right for all of them, so nothing here assumes it.  The ladder runs on the host (255 doublings + additions, once).
   {
-    const uint32_t c0[8] = KZG_FR_COMB_C0_PLAIN, gx[12] = KZG_FP_G1X_MONT, gy[12] = KZG_FP_G1Y_MONT;
-    fp_t x, y;
-    for (int q = 0; q < 12; q++) {
-      x.v[q] = gx[q];
-      y.v[q] = gy[q];
+    uint4* d_sum = nullptr;
+    uint32_t* d_sum_inf = nullptr;
+    HIP_TRY(scratch.alloc(&d_sum, 96));
+    HIP_TRY(scratch.alloc(&d_sum_inf, sizeof(uint32_t)));
+    hipLaunchKernelGGL(k_setup_sum_bases, dim3(1), dim3(64), 0, nullptr, ctx->d_bases_brp, d_sum, d_sum_inf);
+    HIP_TRY(hipGetLastError());
+    uint32_t h[24], sum_inf = 0;
+    HIP_TRY(hipMemcpy(h, d_sum, 96, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&sum_inf, d_sum_inf, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (!sum_inf) {  // S = O: K = O, k_g1_compress adds nothing (d_comb_k stays null)
+      const uint32_t c0[8] = KZG_FR_COMB_C0_PLAIN;
+      fp_t x, y;
+      for (int q = 0; q < 12; q++) {
+        x.v[q] = h[q];
+        y.v[q] = h[12 + q];
+      }
+      g1_xyzz acc;
+      xyzz_set_inf(acc);
+      for (int bit = 255; bit >= 0; bit--) {
+        xyzz_dbl(acc);
+        if ((c0[bit >> 5] >> (bit & 31)) & 1u) xyzz_madd(acc, x, y);
+      }
+      fp_t kx, ky;
+      if (xyzz_to_affine(kx, ky, acc)) {
+        for (int q = 0; q < 12; q++) {
+          h[q] = kx.v[q];
+          h[12 + q] = ky.v[q];
+        }
+        HIP_TRY(hipMalloc(&ctx->d_comb_k, 96));
+        HIP_TRY(hipMemcpy(ctx->d_comb_k, h, 96, hipMemcpyHostToDevice));
+      }
     }
-    g1_xyzz acc;
-    xyzz_set_inf(acc);
-    for (int bit = 255; bit >= 0; bit--) {
-      xyzz_dbl(acc);
-      if ((c0[bit >> 5] >> (bit & 31)) & 1u) xyzz_madd(acc, x, y);
-    }
-    fp_t kx, ky;
-    if (!xyzz_to_affine(kx, ky, acc)) return fail(KZG_FAIL_ARGUMENT, "comb constant is the identity");
-    uint32_t h[24];
-    for (int q = 0; q < 12; q++) {
-      h[q] = kx.v[q];
-      h[12 + q] = ky.v[q];
-    }
-    HIP_TRY(hipMalloc(&ctx->d_comb_k, 96));
-    HIP_TRY(hipMemcpy(ctx->d_comb_k, h, 96, hipMemcpyHostToDevice));
   }
   HIP_TRY(hipDeviceSynchronize());
-  tt.mark("comb table build kernels");
+  tt.mark("comb constant term");
   return 0;
 }
 
 static int32_t ctx_build(kzg_ctx* ctx, const uint8_t* g1_lagrange, const uint8_t* g2_monomial) {
   TraceTimer tt(ctx->knobs.trace, "ctx_build");
   ScratchAllocs scratch;
-  const MsmGeom g = ctx->geom;
   hipStream_t st = nullptr;
   // ---- G2 monomial points (host): P2::decompress of all 65 (src/kzg/setup.rs:67-72) ----
   {
@@ -382,44 +385,17 @@ static int32_t ctx_build(kzg_ctx* ctx, const uint8_t* g1_lagrange, const uint8_t
   HIP_TRY(hipMalloc(&ctx->d_eval_tab, (size_t)2048 * EVAL_TAB_DWORDS * sizeof(uint32_t)));
   hipLaunchKernelGGL(k_setup_eval_tab, dim3(32), dim3(64), 0, st, ctx->d_roots_brp, ctx->d_eval_tab);
   HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  if (ctx->msm_override && ctx->msm_override->build) {  // test-only library (tests/window_msm)
+    int32_t rco = ctx->msm_override->build(ctx);
+    if (rco) return rco;
+  }
   if (ctx->use_comb) {
     int32_t rcc = comb_build(ctx, scratch, tt);
     if (rcc) return rcc;
-    HIP_TRY(hipDeviceSynchronize());
-    return 0;
-  }
-#if !defined(KZG_TEST_WINDOW_MSM)
-  (void)g;
-  (void)st;
-  return fail(KZG_FAIL_ARGUMENT, "the window-table MSM exists only in the test build");
-#else
-  // ---- fixed-base window table (test build, KATETH_AMD_MSM=window) ---------------
-  const uint64_t entries = table_entries(g);
-  ctx->table_bytes = entries * 96;
-  HIP_TRY(hipMalloc(&ctx->d_table, ctx->table_bytes));
-  tt.mark("table allocation");
-  uint4* d_win_bases = nullptr;
-  HIP_TRY(scratch.alloc(&d_win_bases, (size_t)g.W * 4096 * 96));
-  hipLaunchKernelGGL(k_table_window_bases, dim3(64), dim3(64), 0, st, ctx->d_bases_brp, d_win_bases, g);
-  HIP_TRY(hipGetLastError());
-  g1_xyzz* d_tmp = nullptr;
-  HIP_TRY(scratch.alloc(&d_tmp, (size_t)4096 * g.half * sizeof(g1_xyzz)));
-  for (uint32_t j = 0; j < g.W; j++) {
-    const uint32_t e = (j + 1 < g.W) ? g.half : g.top_entries;
-    const uint64_t count = (uint64_t)4096 * e;
-    uint32_t segs = e / 64;  // slices of >= 64 entries, at most 32 per base (two waves per SIMD)
-    segs = segs < 1 ? 1 : (segs > 32 ? 32 : segs);
-    hipLaunchKernelGGL(k_table_chain, dim3(64 * segs), dim3(64), 0, st, d_win_bases, j, e, segs, d_tmp);
-    constexpr int KN = 8;
-    const uint64_t threads = (count + KN - 1) / KN;
-    hipLaunchKernelGGL(k_table_normalize<KN>, dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, st, d_tmp, count, ctx->d_table,
-                       table_index(g, j, 0, 1), ctx->msm_radix28);
-    HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipDeviceSynchronize());
-  tt.mark("table build kernels");
   return 0;
-#endif
 }
 
 extern "C" int32_t kzg_ctx_create(const uint8_t* g1_lagrange, const uint8_t* g2_monomial, const kzg_config* cfg, kzg_ctx** out) {
@@ -430,38 +406,42 @@ extern "C" int32_t kzg_ctx_create(const uint8_t* g1_lagrange, const uint8_t* g2_
     return fail(KZG_FAIL_NO_DEVICE, "no HIP device visible: the kateth_amd engine has no CPU fallback");
   int device = cfg ? cfg->device : 0;
   if (device < 0 || device >= ndev) return fail(KZG_FAIL_ARGUMENT, "device ordinal out of range");
-#if defined(KZG_TEST_WINDOW_MSM)
-  const bool window_mode = getenv("KATETH_AMD_MSM") != nullptr && std::string(getenv("KATETH_AMD_MSM")) == "window";
-#else
-  const bool window_mode = false;
-#endif
-  uint32_t c = (cfg && cfg->window_bits) ? (uint32_t)cfg->window_bits : 16u;  // default: comb with blocks of 16 points, 3.2 GB, 65,536 adds per blob
-  if (c < 4 || c > 22) return fail(KZG_FAIL_ARGUMENT, "window_bits must be in [4,22]");
-  if (window_mode && c > 16) c = 16;
   HIP_TRY(hipSetDevice(device));
+  // Table class (index bits per lookup = points per block of the comb).  window_bits = 0 -- what Setup::load_json's drop-in
+  // passes, INTEGRATION.md section 5 -- takes the fastest class the device has room for RIGHT NOW, so that the default
+  // context is the benchmarked one on a 288-GB part:
+  //   class 22 (blocks of 22 + 21 + 21 points, 49,152 additions per blob), G = 8 plane groups = 192 GiB  if >= 232 GiB are free
+  //   class 22, G = 4 = 96 GiB (63 instead of 31 Horner doublings per lane: -2 %)                         if >= 136 GiB
+  //   class 16 (blocks of 16, G = 16, 65,536 additions per blob: -25 %) = 12.9 GB                         if >=  21 GiB
+  //   class 8  (blocks of 8, G = 16) = 100 MB                                                             otherwise
+  // (the margins cover the build's 13 GB of staging, the 0.4-GB latency comb, the call workspace and the caller's blobs).
+  // An explicit window_bits is honoured as given; kzg_ctx_window_bits / kzg_ctx_plane_groups report the choice.
+  constexpr size_t GiB = (size_t)1 << 30;
+  constexpr size_t GROUP22_BYTES = (size_t)64 * ((size_t)1 << 22) * 96;  // one plane group of class 22: 24 GiB
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+  uint32_t c = cfg ? (uint32_t)cfg->window_bits : 0u;
+  if (c == 0) c = free_b >= 4 * GROUP22_BYTES + 40 * GiB ? 22u : (free_b >= 21 * GiB ? 16u : 8u);
+  if (c < 4 || c > 22) return fail(KZG_FAIL_ARGUMENT, "window_bits must be 0 (automatic) or in [4,22]");
   kzg_ctx* ctx = new (std::nothrow) kzg_ctx();
   if (!ctx) return fail(KZG_FAIL_ARGUMENT, "out of host memory");
   ctx->device = device;
-  ctx->use_comb = !window_mode;
-  ctx->geom = make_geom(c > 16 ? 16 : c);
   {
-    // comb geometry: index bits per lookup = points per block.  22: blocks of 22 + 21 + 21 (49,152 adds per blob, 25.8 GB
-    // per plane group); 16..21: 4 x 16; 8..15: 8 x 8; 4..7: 16 x 4 (the small classes keep test contexts cheap)
+    // 22: blocks of 22 + 21 + 21; 16..21: 4 x 16; 8..15: 8 x 8; 4..7: 16 x 4 (the small classes keep test contexts cheap)
     const uint32_t nb = c >= 22 ? 3u : (c >= 16 ? 4u : (c >= 8 ? 8u : 16u));
-    // plane groups G (one table each, H = 256/G planes and H - 1 accumulator doublings per lane): 16 for the small classes
-    // (12.9 GB at blocks of 16); for blocks of 22/21 8 groups = 192 GiB when the device has the room (288 GB parts), else 4
+    // plane groups G (one table each, H = 256/G planes and H - 1 accumulator doublings per lane): 16 for the small classes;
+    // for blocks of 22/21 8 groups when the device has the room, else 4
     uint32_t G = 16;
-    if (nb == 3) {
-      size_t free_b = 0, total_b = 0;
-      G = 4;
-      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > (size_t)8 * 64 * ((size_t)1 << 22) * 96 + ((size_t)40 << 30)) G = 8;
-    }
-    if (cfg && cfg->reserved) G = (uint32_t)cfg->reserved;
+    if (nb == 3) G = free_b >= 8 * GROUP22_BYTES + 40 * GiB ? 8u : 4u;
+    if (cfg && cfg->plane_groups) G = (uint32_t)cfg->plane_groups;
     if (const char* e = getenv("KATETH_AMD_COMB_GROUPS")) G = (uint32_t)atoi(e);
-    if (!(G == 1 || G == 2 || G == 4 || G == 8 || G == 16)) return fail(KZG_FAIL_ARGUMENT, "plane groups must be 1, 2, 4, 8 or 16");
+    if (!(G == 1 || G == 2 || G == 4 || G == 8 || G == 16)) {
+      delete ctx;
+      return fail(KZG_FAIL_ARGUMENT, "plane groups must be 1, 2, 4, 8 or 16");
+    }
     ctx->comb = comb_make_geom(nb, G);
     ctx->comb.fair = read_env_knobs().comb_fair;
-    ctx->window_class = window_mode ? c : (nb == 3 ? 22u : 64u / nb);
+    ctx->window_class = nb == 3 ? 22u : 64u / nb;
   }
   if (hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess) {
@@ -471,19 +451,7 @@ extern "C" int32_t kzg_ctx_create(const uint8_t* g1_lagrange, const uint8_t* g2_
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cus = (uint32_t)prop.multiProcessorCount;
   ctx->knobs = read_env_knobs();
-#if defined(KZG_TEST_WINDOW_MSM)
-  if (const char* e = getenv("KATETH_AMD_MSM_RADIX")) ctx->msm_radix28 = atoi(e) != 32;  // test-only build
-  if (!ctx->msm_radix28) {  // the 12 x 32-bit-limb kernel walks round 1's window table
-    ctx->use_comb = false;
-    ctx->window_class = ctx->geom.c;
-  }
-  if (const char* e = getenv("KATETH_AMD_WAVE_TIMES")) {  // measurement aid (tools/gpu_wave_times.py)
-    ctx->wave_times_cap = (uint64_t)atoll(e);
-    if (ctx->wave_times_cap && (hipMalloc(&ctx->d_wave_times, ctx->wave_times_cap * 32) != hipSuccess ||
-                                hipMemset(ctx->d_wave_times, 0, ctx->wave_times_cap * 32) != hipSuccess))
-      ctx->wave_times_cap = 0;
-  }
-#endif
+  if (g_msm_override_hook) ctx->msm_override = g_msm_override_hook(ctx, c);  // test-only library (tests/window_msm), never the product
   int32_t rc = ctx_build(ctx, g1_lagrange, g2_monomial);
   if (rc != 0) {
     std::string keep = g_last_error;
@@ -538,11 +506,10 @@ extern "C" int32_t kzg_blob_to_commitment_batch_dev(const kzg_ctx* ctx, const vo
   return rc;
 }
 
-// Host-buffer entry point.  The blobs cross PCIe in chunks of 512 (64 MiB) through two device staging buffers: while the
-// MSM kernel of chunk k runs on a compute stream, chunk k+1 is copied in on a copy stream, so that for large batches the
-// transfer (~23 GB/s from pageable memory: 22 ms per 4,096 blobs) hides behind the MSM instead of preceding it.  Only the
-// MSM kernel is launched per chunk; the latency-bound tail (lane-sum trees, inversion + encoding) runs once per group of up
-// to 8,192 blobs -- run per 512-blob chunk it cost 24 % (63.8 ms instead of 51.3 ms per 4,096 blobs at c = 12).
+// Host-buffer entry point.  The blobs cross PCIe in chunks (plan below) through two device staging buffers: while the MSM
+// kernel of chunk k runs on a compute stream, chunk k+1 is copied in on a copy stream, so that the transfer (56-57 GB/s:
+// 9.4 ms per 4,096 blobs) hides behind the MSM instead of preceding it.  Only the MSM kernel is launched per chunk; the
+// latency-bound tail (lane-sum trees, inversion + encoding) runs once per group of chunks.
 static int32_t commit_host(const kzg_ctx* ctx, const uint8_t* blobs, uint64_t n, uint8_t* out48, uint8_t* out_affine96, int32_t* status) {
   if (!ctx || (n && (!blobs || (!out48 && !out_affine96) || !status))) return fail(KZG_FAIL_ARGUMENT, "null argument");
   if (n == 0) return 0;
@@ -671,29 +638,7 @@ extern "C" int32_t kzg_synth_blobs_dev(const kzg_ctx* ctx, uint64_t seed, uint64
   return 0;
 }
 
-__global__ __launch_bounds__(256) void k_microbench_fp_mul(uint32_t* out, uint64_t iters) {
-  fp_t a, b;
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-#pragma unroll
-  for (int q = 0; q < 12; q++) {
-    a.v[q] = FpParams::one(q) ^ (t & 0xffu);
-    b.v[q] = FpParams::r2(q) >> 1;
-  }
-  a.v[11] &= 0x0fffffffu;
-#pragma unroll 1
-  for (uint64_t it = 0; it < iters; it++) {
-    fp_t r;
-    mont_mul_lazy<FpParams>(r, a, b);  // the multiply the MSM hot loop uses (operands stay in [0, 2p))
-    a = b;
-    b = r;
-  }
-  uint32_t x = 0;
-#pragma unroll
-  for (int q = 0; q < 12; q++) x ^= b.v[q];
-  out[t] = x;
-}
-
-// the same chain with the multiply of the radix-2^28 MSM kernel (fp28.cuh)
+// a chain of dependent products with the multiply of the radix-2^28 MSM kernel (fp28.cuh)
 __global__ __launch_bounds__(256) void k_microbench_fp28_mul(uint32_t* out, uint64_t iters) {
   fp28 a, b;
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -724,7 +669,7 @@ extern "C" int32_t kzg_microbench_fp_mul(const kzg_ctx* ctx, uint64_t lanes, uin
   hipEvent_t e0, e1;
   HIP_TRY(hipEventCreate(&e0));
   HIP_TRY(hipEventCreate(&e1));
-  auto kern = ctx->msm_radix28 ? k_microbench_fp28_mul : k_microbench_fp_mul;  // the multiply the MSM kernel in use is built on
+  auto kern = k_microbench_fp28_mul;  // the multiply the MSM kernel is built on
   hipLaunchKernelGGL(kern, dim3((unsigned)(lanes / 256)), dim3(256), 0, nullptr, d_out, (uint64_t)16);
   HIP_TRY(hipEventRecord(e0, nullptr));
   hipLaunchKernelGGL(kern, dim3((unsigned)(lanes / 256)), dim3(256), 0, nullptr, d_out, iters);

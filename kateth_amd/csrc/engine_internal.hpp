@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <chrono>
 #include <mutex>
 #include <new>
@@ -71,16 +72,30 @@ struct ProfEvent {
 };
 
 struct kzg_verify_session;
+struct kzg_ctx;
+// Extension point for the TEST-ONLY library (tests/window_msm/window_msm.hip = the product objects + one more translation
+// unit): an alternative fixed-base MSM -- round 1's window-table kernels as independent cross-checks of the comb, and a
+// time-stamping instance of the comb kernel.  The product library never sets g_msm_override_hook: kzg_ctx_create then has one
+// path, and none of that code is in kateth_amd/csrc.
+struct MsmOverride {
+  const char* kernel_name;
+  bool replaces_table;     // true: build() fills ctx->d_table / table_bytes / window_class instead of the comb build
+  uint64_t adds_per_blob;  // reported by kzg_ctx_adds_per_blob when the table is replaced
+  int32_t (*build)(kzg_ctx* ctx);
+  // the MSM alone: 64 lane sums per (blob, split) unit into partials[unit * 64 + lane]; scratch = msm_scratch_bytes(ctx, n) bytes
+  int32_t (*launch)(const kzg_ctx* ctx, bool be_bytes, const uint8_t* d_scalars, uint64_t n, int32_t* d_status, g1_xyzz* partials, uint32_t splits,
+                    uint32_t lpb, void* scratch, hipStream_t st);
+  void (*destroy)(kzg_ctx* ctx);
+};
+extern const MsmOverride* (*g_msm_override_hook)(kzg_ctx* ctx, uint32_t window_bits);  // nullptr in the product library
+
 struct kzg_ctx {
   int device = 0;
-  MsmGeom geom{};
-  uint4* d_table = nullptr;      // fixed-base table: comb (msm_comb.cuh) comb_table_entries(comb) * 96 B, or window table_entries(geom) * 96 B
-  bool use_comb = true;          // subset-sum comb MSM; false only in the TEST build (KATETH_AMD_MSM=window / KATETH_AMD_MSM_RADIX=32 there)
+  uint4* d_table = nullptr;      // fixed-base comb table (msm_comb.cuh): comb_table_entries(comb) * 96 B
+  bool use_comb = true;          // false only under a test override that replaces the table
   CombGeom comb{};
-#if defined(KZG_TEST_WINDOW_MSM)
-  uint64_t* d_wave_times = nullptr;  // test build, KATETH_AMD_WAVE_TIMES=<units>: per-unit timestamps of the last k_msm_comb28 launch
-  uint64_t wave_times_cap = 0;
-#endif
+  const MsmOverride* msm_override = nullptr;  // test-only library, see above
+  void* override_state = nullptr;
   // class 22 only: a second, small comb for latency (blocks of 8 points, 64 plane groups of 4 planes: 3 doublings per lane
   // instead of 31, 403 MB) used by calls of at most KZG_LAT_MAX_BLOBS blobs, where a lane's chain -- not the chip -- is the cost
   CombGeom comb_lat{};
@@ -96,9 +111,6 @@ struct kzg_ctx {
   uint32_t num_cus = 256;
   hipStream_t side_stream = nullptr;  // non-blocking stream for work that overlaps the caller's stream
   hipStream_t copy_stream = nullptr;  // non-blocking stream for the chunked host-to-device copies of the host-buffer entry points
-  // window-table test build only: true = k_msm_fixed28 (2^392-Montgomery table), false (KATETH_AMD_MSM_RADIX=32) = k_msm_fixed
-  // on 12 x 32-bit limbs (2^384-Montgomery table)
-  bool msm_radix28 = true;
   EnvKnobs knobs;  // read once at kzg_ctx_create
   // workspace (grown on demand, guarded by lock)
   mutable std::mutex lock;
@@ -108,7 +120,7 @@ struct kzg_ctx {
   // profiling (kzg_profile_begin/end): event pairs around the launches of the kernels named by ProfKind, each pair on the
   // stream its kernel runs on; own lock (the verify entry points do not take `lock`)
   mutable std::mutex prof_lock;
-  mutable bool profiling = false;
+  mutable std::atomic<bool> profiling{false};  // read without prof_lock by ProfScope on every launch
   mutable std::vector<ProfEvent> prof_events;
   mutable size_t prof_used = 0;
   // pooled verify sessions (device scratch + side stream + events), engine_verify.hip
@@ -136,7 +148,7 @@ struct ProfScope {
   hipStream_t st;
   ProfScope(const kzg_ctx* ctx, int kind, hipStream_t s) : st(s) {
     hipEvent_t e0 = nullptr;
-    if (ctx->profiling && prof_next(ctx, kind, &e0, &e1) == 0 && e0) (void)hipEventRecord(e0, st);
+    if (ctx->profiling.load(std::memory_order_relaxed) && prof_next(ctx, kind, &e0, &e1) == 0 && e0) (void)hipEventRecord(e0, st);
   }
   ~ProfScope() {
     if (e1) (void)hipEventRecord(e1, st);
@@ -207,39 +219,20 @@ static inline size_t msm_scratch_bytes(const kzg_ctx* ctx, uint64_t n) { return 
 template <bool BE_BYTES>
 static int32_t msm_launch(const kzg_ctx* ctx, const uint8_t* d_scalars, uint64_t n, int32_t* d_status, g1_xyzz* partials, uint32_t splits,
                           uint32_t lpb, void* scratch, hipStream_t st) {
-  if (ctx->use_comb) {
-    uint64_t* masks = reinterpret_cast<uint64_t*>(scratch);
-    {
-      ProfScope ps(ctx, PROF_TRANSPOSE, st);
-      hipLaunchKernelGGL((k_comb_transpose<BE_BYTES>), dim3((unsigned)(n * 8)), dim3(512), 0, st, d_scalars, n, masks, d_status);
-    }
-    ProfScope ps(ctx, PROF_MSM_FIXED, st);
-    const bool lat = msm_uses_lat(ctx, splits);
-    const uint4* table = lat ? ctx->d_table_lat : ctx->d_table;
-    const CombGeom geom = lat ? ctx->comb_lat : ctx->comb;
-#if defined(KZG_TEST_WINDOW_MSM)
-    hipLaunchKernelGGL(k_msm_comb28, dim3((unsigned)msm_units(n, splits, lpb)), dim3(64), 0, st, masks, n, splits, lpb, table, geom, partials,
-                       msm_units(n, splits, lpb) <= ctx->wave_times_cap ? ctx->d_wave_times : (uint64_t*)nullptr);
-#else
-    hipLaunchKernelGGL(k_msm_comb28, dim3((unsigned)msm_units(n, splits, lpb)), dim3(64), 0, st, masks, n, splits, lpb, table, geom, partials);
-#endif
-    HIP_TRY(hipGetLastError());
-    return 0;
+  if (ctx->msm_override) return ctx->msm_override->launch(ctx, BE_BYTES, d_scalars, n, d_status, partials, splits, lpb, scratch, st);
+  uint64_t* masks = reinterpret_cast<uint64_t*>(scratch);
+  {
+    ProfScope ps(ctx, PROF_TRANSPOSE, st);
+    hipLaunchKernelGGL((k_comb_transpose<BE_BYTES>), dim3((unsigned)(n * 8)), dim3(512), 0, st, d_scalars, n, masks, d_status);
   }
-#if defined(KZG_TEST_WINDOW_MSM)
-  // test-only build (tests/window_msm): round 1's window-table kernels as independent cross-checks of the comb
   ProfScope ps(ctx, PROF_MSM_FIXED, st);
-  if (!ctx->msm_radix28)
-    hipLaunchKernelGGL((k_msm_fixed<BE_BYTES, 2>), dim3((unsigned)(n * splits)), dim3(64), 0, st, d_scalars, splits, ctx->d_table, ctx->geom,
-                       partials, d_status);
-  else
-    hipLaunchKernelGGL((k_msm_fixed28<BE_BYTES>), dim3((unsigned)(n * splits)), dim3(64), 0, st, d_scalars, splits, ctx->d_table, ctx->geom,
-                       partials, d_status);
+  const bool lat = msm_uses_lat(ctx, splits);
+  const uint4* table = lat ? ctx->d_table_lat : ctx->d_table;
+  const CombGeom geom = lat ? ctx->comb_lat : ctx->comb;
+  hipLaunchKernelGGL(k_msm_comb28<false>, dim3((unsigned)msm_units(n, splits, lpb)), dim3(64), 0, st, masks, n, splits, lpb, table, geom, partials,
+                     (uint64_t*)nullptr);
   HIP_TRY(hipGetLastError());
   return 0;
-#else
-  return fail(KZG_FAIL_ARGUMENT, "the window-table MSM exists only in the test build");
-#endif
 }
 // Lane sums of n blobs -> 48-byte encodings.  Two tree stages: the 64 lane sums of every (blob, split) unit, then the units
 // of a blob -- 6 + log2(splits) levels of latency instead of the splits + 5 a sequential walk over the splits costs (a
@@ -249,7 +242,7 @@ static inline int32_t msm_finish(const kzg_ctx* ctx, uint64_t n, uint8_t* d_out4
   ProfScope ps(ctx, PROF_REDUCE_COMPRESS, st);
   g1_xyzz* unit_sums = (splits == 1) ? sums : partials + (size_t)n * splits * 64;
   const uint64_t units = msm_units(n, splits, lpb);
-  hipLaunchKernelGGL(k_msm_reduce, dim3((unsigned)units), dim3(64), 0, st, partials, units, lpb, unit_sums);
+  hipLaunchKernelGGL(k_msm_reduce, dim3((unsigned)units), dim3(64), 0, st, partials, units, lpb, unit_sums, lpb == 64 ? units : n);
   if (splits > 1) hipLaunchKernelGGL(k_msm_reduce_splits, dim3((unsigned)n), dim3(64), 0, st, unit_sums, splits, n, sums);
   hipLaunchKernelGGL(k_g1_compress, dim3(blocks_for(n, 64)), dim3(64), 0, st, sums, n, d_status, d_out48, d_out_affine96, ctx->use_comb ? ctx->d_comb_k : (const uint4*)nullptr);
   HIP_TRY(hipGetLastError());

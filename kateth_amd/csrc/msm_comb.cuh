@@ -2,8 +2,8 @@
 // P1::lincomb_pippenger(setup.g1_lagrange_brp, scalars) (src/bls.rs:416-437, called from src/blob.rs:48-53 and
 // src/kzg/poly.rs:68).
 //
-// Round 1 took the windowed method to its fixed-base limit (msm_fixed.cuh: every signed c-bit multiple of every window
-// base, 192 GiB at c = 16, 65,536 additions per blob).  A table entry there serves ONE point; here an entry serves a BLOCK
+// Round 1 took the windowed method to its fixed-base limit (now tests/window_msm/window_msm.cuh: every signed c-bit multiple
+// of every window base, 192 GiB at c = 16, 65,536 additions per blob).  A table entry there serves ONE point; here an entry serves a BLOCK
 // of t points, which is t times more memory-efficient per index bit:
 //   * scalars are recoded to signed bits:  2e = sum_k s_k 2^k + (2^256 - 1),  s_k = 2 b_k - 1 = +-1  (k = 0..255), so
 //       sum_i e_i L_i = sum_k 2^k sum_i s_{i,k} (L_i / 2)  +  [(2^256 - 1)/2] sum_i L_i ,
@@ -22,8 +22,8 @@
 // mask = bit k of 64 consecutive scalars; it also performs Blob::from_slice's canonicity check, src/blob.rs:26-37).
 //
 // Work decomposition: one wave per (blob, split), or per PAIR of blobs from num_CUs x 16 blobs per launch on (half-wave
-// mode: 32 lanes per blob); lane = (plane group, block owner).  The hot loop is the radix-2^28 mixed addition of
-// msm_fixed.cuh (xyzz28_madd_fast, fp28.cuh) with the next table entry gathered while the current addition runs, the masks
+// mode: 32 lanes per blob); lane = (plane group, block owner).  The hot loop is the radix-2^28 mixed addition
+// (xyzz28_madd_fast, fp28.cuh) with the next table entry gathered while the current addition runs, the masks
 // of a lane's next four chunks fetched by one 32-byte load, and the two waves of a SIMD trading issue priority
 // (issue_fair.cuh) so that they finish together.
 #pragma once
@@ -135,18 +135,19 @@ struct CombWalker {
 // overhead.  Within a blob's lpb lanes: lane l = (group, owner); group grp = l / (lpb / G) walks planes
 // [grp H, grp H + H) of its own table; owner = split * (lpb / G) + l % (lpb / G) owns blocks [owner * bpo, owner * bpo + bpo)
 // of the 64 nb blocks.
+// TIMED: instantiated only by the test-only library (tests/window_msm): every unit records {wall start, wall end, cycles,
+// hw id} into wave_times (tools/gpu_wave_times.py); the product instantiates <false> and passes nullptr.
+template <bool TIMED>
 static __global__ __launch_bounds__(64, 2) void k_msm_comb28(const uint64_t* __restrict__ masks, uint64_t n, uint32_t splits, uint32_t lpb,
-                                                             const uint4* __restrict__ table, CombGeom g, g1_xyzz* __restrict__ partials
-#if defined(KZG_TEST_WINDOW_MSM)
-                                                             ,
-                                                             uint64_t* __restrict__ wave_times  // test build: {wall start, wall end, cycles, hw id} per unit
-#endif
-) {
+                                                             const uint4* __restrict__ table, CombGeom g, g1_xyzz* __restrict__ partials,
+                                                             uint64_t* __restrict__ wave_times) {
   const int lane = threadIdx.x;
   const uint64_t unit = blockIdx.x;
-#if defined(KZG_TEST_WINDOW_MSM)
-  const uint64_t wt_wall0 = wall_clock64(), wt_cyc0 = clock64();
-#endif
+  uint64_t wt_wall0 = 0, wt_cyc0 = 0;
+  if (TIMED) {
+    wt_wall0 = wall_clock64();
+    wt_cyc0 = clock64();
+  }
   const uint32_t l = (uint32_t)lane % lpb;
   const uint64_t blob = (lpb == 64u) ? unit / splits : unit * (64u / lpb) + (uint32_t)lane / lpb;
   const uint32_t split = (lpb == 64u) ? (uint32_t)(unit % splits) : 0u;
@@ -274,17 +275,17 @@ static __global__ __launch_bounds__(64, 2) void k_msm_comb28(const uint64_t* __r
   g1_xyzz out;
   xyzz28_to_xyzz(out, acc);  // back to canonical 2^384-Montgomery limbs for k_msm_reduce
   partials[unit * 64 + lane] = out;
-#if defined(KZG_TEST_WINDOW_MSM)
-  if (wave_times && lane == 0) {
-    uint32_t hwid, xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    wave_times[unit * 4 + 0] = wt_wall0;
-    wave_times[unit * 4 + 1] = wall_clock64();
-    wave_times[unit * 4 + 2] = clock64() - wt_cyc0;
-    wave_times[unit * 4 + 3] = ((uint64_t)xcc << 32) | hwid;
+  if (TIMED) {
+    if (wave_times && lane == 0) {
+      uint32_t hwid, xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      wave_times[unit * 4 + 0] = wt_wall0;
+      wave_times[unit * 4 + 1] = wall_clock64();
+      wave_times[unit * 4 + 2] = clock64() - wt_cyc0;
+      wave_times[unit * 4 + 3] = ((uint64_t)xcc << 32) | hwid;
+    }
   }
-#endif
 }
 
 // ---- table build -------------------------------------------------------------------------------------------------

@@ -1,5 +1,5 @@
 // Context-creation kernels: what Setup::load_json does after parsing
-// (src/kzg/setup.rs:52-81) plus the fixed-base table build of msm_fixed.cuh.
+// (src/kzg/setup.rs:52-81) plus the batch normaliser of the fixed-base table build (msm_comb.cuh).
 #pragma once
 #include "fr29.cuh"
 #include "msm_fixed.cuh"
@@ -23,67 +23,14 @@ static __global__ __launch_bounds__(64) void k_setup_g1(const uint8_t* __restric
   if (st == 0) store_affine96(bases_brp, bitrev12(t), x, y);
 }
 
-// thread i: window bases Q[j][i] = 2^(c*j) * L_i for j = 0..W-1 (affine).
-static __global__ __launch_bounds__(64) void k_table_window_bases(const uint4* __restrict__ bases_brp, uint4* __restrict__ win_bases, MsmGeom g) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 4096) return;
-  fp_t x, y;
-  load_affine96(x, y, bases_brp, i);
-  store_affine96(win_bases, i, x, y);
-  g1_xyzz acc;
-  xyzz_from_affine(acc, x, y);
-  for (uint32_t j = 1; j < g.W; j++) {
-    for (uint32_t q = 0; q < g.c; q++) xyzz_dbl(acc);
-    xyzz_to_affine(x, y, acc);
-    store_affine96(win_bases, (uint64_t)j * 4096u + i, x, y);
-    xyzz_from_affine(acc, x, y);
-  }
-}
-
-// thread (i, s) of window j: the chain d*Q for the s-th of `segs` slices of d = 1..entries, XYZZ results to tmp
-// (tmp index = i*entries + d-1).  A slice starts from [first]Q by double-and-add (15 steps at most) and then adds Q once
-// per entry; with one thread per base the 4,096 chains of 32,768 sequential additions were pure latency (0.44 s per
-// window at c = 16), sliced 32 ways they fill the chip.
-static __global__ __launch_bounds__(64) void k_table_chain(const uint4* __restrict__ win_bases, uint32_t j, uint32_t entries, uint32_t segs,
-                                                           g1_xyzz* __restrict__ tmp) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= 4096u * segs) return;
-  const uint32_t i = t / segs, sg = t % segs;
-  const uint32_t len = (entries + segs - 1) / segs;
-  const uint32_t first = sg * len + 1;  // d of this slice's first entry
-  if (first > entries) return;
-  const uint32_t last = (first + len - 1 < entries) ? first + len - 1 : entries;
-  fp_t x, y;
-  load_affine96(x, y, win_bases, (uint64_t)j * 4096u + i);
-  g1_xyzz acc;
-  xyzz_from_affine(acc, x, y);
-  if (first > 1) {  // acc = [first]Q, MSB-first
-    const int top = 31 - __builtin_clz(first);
-    for (int bit = top - 1; bit >= 0; bit--) {
-      xyzz_dbl(acc);
-      if ((first >> bit) & 1u) {
-        g1_xyzz mine = acc;
-        xyzz_madd(mine, x, y);
-        acc = mine;
-      }
-    }
-  }
-  g1_xyzz* o = tmp + (uint64_t)i * entries;
-  o[first - 1] = acc;
-#pragma unroll 1
-  for (uint32_t d = first; d < last; d++) {
-    xyzz_madd(acc, x, y);
-    o[d] = acc;
-  }
-}
-
-// thread: normalises KN consecutive XYZZ entries with one shared inversion; r392 selects the Montgomery radix of the stored
-// coordinates (2^392 for the radix-2^28 MSM kernel, 2^384 otherwise)
-//
-// (Montgomery's trick on zz*zzz) and writes affine table entries.
+// thread: normalises KN consecutive XYZZ entries with one shared inversion (Montgomery's trick on zz*zzz) and writes affine
+// table entries; r392 selects the Montgomery radix of the stored coordinates (2^392 for the radix-2^28 MSM kernel, 2^384
+// otherwise).  An entry at infinity (a vanishing subset sum: impossible for the ceremony, possible for a degenerate setup
+// such as repeated points) has no affine form: it is kept out of the shared inversion, stored as zeros and reported through
+// *inf_seen, and the caller rejects the setup (P1::lincomb, src/bls.rs:406-437, would accept it -- DESIGN.md section 2).
 template <int KN>
 static __global__ __launch_bounds__(64) void k_table_normalize(const g1_xyzz* __restrict__ tmp, uint64_t count, uint4* __restrict__ table, uint64_t table_off,
-                                                              bool r392) {
+                                                              bool r392, uint32_t* __restrict__ inf_seen) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t first = t * KN;
   if (first >= count) return;
@@ -96,6 +43,10 @@ static __global__ __launch_bounds__(64) void k_table_normalize(const g1_xyzz* __
     if (first + k < count) {
       const g1_xyzz& e = tmp[first + k];
       fp_mul(w[k], e.zz, e.zzz);
+      if (bn_is_zero(e.zz)) {
+        w[k] = fp_one();
+        atomicOr(inf_seen, 1u);
+      }
       if (k == 0)
         pre[k] = w[k];
       else
@@ -121,13 +72,39 @@ static __global__ __launch_bounds__(64) void k_table_normalize(const g1_xyzz* __
       fp_mul(a, wi, e.zzz);  // 1/zz
       fp_mul(x, e.x, a);
       fp_mul(a, wi, e.zz);  // 1/zzz
-      fp_mul(y, e.y, a);
-      if (r392) {  // table for k_msm_fixed28: coordinates times 2^392 instead of 2^384
+      fp_mul(y, e.y, a);  // an entry at infinity has x = y = 0 and stays (0, 0)
+      if (r392) {  // table of the radix-2^28 MSM kernels: coordinates times 2^392 instead of 2^384
         fp_to_r392(x, x);
         fp_to_r392(y, y);
       }
       store_affine96(table, table_off + first + k, x, y);
     }
+  }
+}
+
+// One wave: S = sum of the 4096 setup points (any order), affine 2^384-Montgomery, *inf = 1 if the sum is the identity.
+// The comb's constant term is [c0] S (msm_comb.cuh); for a Lagrange-basis setup S is the generator, but nothing in
+// Setup::load_json (src/kzg/setup.rs:46-82) requires that, so the engine does not assume it.
+static __global__ __launch_bounds__(64) void k_setup_sum_bases(const uint4* __restrict__ bases, uint4* __restrict__ sum_affine, uint32_t* __restrict__ inf) {
+  __shared__ g1_xyzz lds[32];
+  const int lane = threadIdx.x;
+  g1_xyzz acc;
+  xyzz_set_inf(acc);
+#pragma unroll 1
+  for (uint32_t k = 0; k < 64; k++) {
+    fp_t x, y;
+    load_affine96(x, y, bases, k * 64u + (uint32_t)lane);
+    g1_xyzz mine = acc;
+    xyzz_madd(mine, x, y);
+    acc = mine;
+  }
+  wave_reduce_xyzz(acc, lds, lane);
+  if (lane == 0) {
+    fp_t x, y;
+    bn_zero(x);
+    bn_zero(y);
+    *inf = xyzz_to_affine(x, y, acc) ? 0u : 1u;
+    store_affine96(sum_affine, 0, x, y);
   }
 }
 

@@ -226,8 +226,9 @@ class Setup {
   static constexpr size_t BLOB_BYTES = KZG_BYTES_PER_BLOB;  // Blob::<4096>::BYTES
 
   // g1_lagrange: 4096 x 48 B, g2_monomial: 65 x 96 B, in file order
-  static Setup load(const uint8_t* g1_lagrange, const uint8_t* g2_monomial, int device = 0, int window_bits = 0) {
-    kzg_config cfg{device, window_bits, 0, 0};
+  // window_bits = 0 / plane_groups = 0: the engine picks the fastest table class the device has room for (kzg_config)
+  static Setup load(const uint8_t* g1_lagrange, const uint8_t* g2_monomial, int device = 0, int window_bits = 0, int plane_groups = 0) {
+    kzg_config cfg{device, window_bits, 0, plane_groups};
     kzg_ctx* ctx = nullptr;
     int32_t rc = kzg_ctx_create(g1_lagrange, g2_monomial, &cfg, &ctx);
     if (rc != 0) throw EngineFailure("kzg_ctx_create", rc);  // includes LoadSetupError::Bls (-4 / -5)

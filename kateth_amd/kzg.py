@@ -95,7 +95,7 @@ def _kzg_error(code: int) -> KzgError:
 # library loading -- fails loudly, no fallback
 # ---------------------------------------------------------------------------
 class _Config(ctypes.Structure):
-    _fields_ = [("device", ctypes.c_int32), ("window_bits", ctypes.c_int32), ("flags", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+    _fields_ = [("device", ctypes.c_int32), ("window_bits", ctypes.c_int32), ("flags", ctypes.c_int32), ("plane_groups", ctypes.c_int32)]
 
 
 def library_path() -> str:
@@ -311,8 +311,9 @@ class Setup:
 
     # -- construction --------------------------------------------------------
     @classmethod
-    def load_json(cls, path, device: int = 0, window_bits: int = 0, lib_path: Optional[str] = None) -> "Setup":
-        """`Setup::load_json` (src/kzg/setup.rs:46-82)."""
+    def load_json(cls, path, device: int = 0, window_bits: int = 0, lib_path: Optional[str] = None, plane_groups: int = 0) -> "Setup":
+        """`Setup::load_json` (src/kzg/setup.rs:46-82).  window_bits = 0: the engine picks the fastest table class the device
+        has room for (include/kateth_amd.h, kzg_config)."""
         try:
             with open(path) as fh:
                 raw = json.load(fh)
@@ -325,11 +326,11 @@ class Setup:
             g2 = [_unhex(s) for s in raw["g2_monomial"]]
         except (KeyError, ValueError, AttributeError) as err:
             raise LoadSetupError("Serde(%s)" % err)
-        return cls.from_bytes(g1, g2, device=device, window_bits=window_bits, lib_path=lib_path)
+        return cls.from_bytes(g1, g2, device=device, window_bits=window_bits, lib_path=lib_path, plane_groups=plane_groups)
 
     @classmethod
     def from_bytes(cls, g1_lagrange: Sequence[bytes], g2_monomial: Sequence[bytes], device: int = 0, window_bits: int = 0,
-                   lib_path: Optional[str] = None) -> "Setup":
+                   lib_path: Optional[str] = None, plane_groups: int = 0) -> "Setup":
         if len(g1_lagrange) != cls.G1:
             raise LoadSetupError("InvalidLenG1Lagrange")  # src/kzg/setup.rs:52-54
         if len(g2_monomial) != cls.G2:
@@ -338,13 +339,15 @@ class Setup:
             raise LoadSetupError("Bls(ECGroup(InvalidEncoding))")
         lib = load_library(lib_path)
         window_bits = window_bits or int(os.environ.get("KATETH_AMD_WINDOW_BITS", "0"))
-        cfg = _Config(device, window_bits, 0, 0)
+        cfg = _Config(device, window_bits, 0, plane_groups)
         out = ctypes.c_void_p()
         rc = lib.kzg_ctx_create(b"".join(g1_lagrange), b"".join(g2_monomial), ctypes.byref(cfg), ctypes.byref(out))
         if rc in (-4, -5):  # LoadSetupError::Bls(bls::Error::ECGroup(..)), src/kzg/setup.rs:59-72
             code = lib.kzg_last_error_code()
             kind = str(error_from_status(code)) if code in _STATUS else "ECGroup"
             raise LoadSetupError("Bls(%s): %s" % (kind, lib.kzg_last_error().decode()))
+        if rc == -6:  # no counterpart in the reference: a setup whose points cancel within a comb block (include/kateth_amd.h)
+            raise LoadSetupError("Unsupported: %s" % lib.kzg_last_error().decode())
         if rc != 0:
             raise EngineError("kzg_ctx_create failed (%d): %s" % (rc, lib.kzg_last_error().decode()))
         return cls(out.value, lib)

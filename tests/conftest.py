@@ -41,3 +41,11 @@ def oracle_setup():
     from oracle.pyref.setup import Setup
 
     return Setup.load_json(TRUSTED_SETUP, subgroup_checks=False)
+
+
+@pytest.fixture(scope="session")
+def window_msm_lib():
+    """the TEST-ONLY library (tests/window_msm): the product's objects + round 1's window-table MSM kernels, built on demand"""
+    import __graft_entry__ as g
+
+    return g.build_test_engine()

@@ -173,3 +173,45 @@ def test_cpp_host_mirror_round_trip_on_gpu(tmp_path):
     out = subprocess.run([exe, str(g1), str(g2)], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "verify=1" in out.stdout
+
+
+def header_table_rows():
+    """rows of the table-class table in include/kateth_amd.h's kzg_config comment: class -> (blocks per 64 points,
+    entries per 64 points and group, default G, stated resident bytes, additions per blob)"""
+    rows = {}
+    for line in open(HEADER).read().splitlines():
+        m = re.match(r"\s*\*\s+(\d+)\s+\|([^|]+)\|([^|]+)\|\s*(\d+)[^|]*\|([^|]+)\|\s*([\d,]+)\s*$", line)
+        if not m:
+            continue
+        cls, blocks, e_txt, g, size_txt, adds = m.groups()
+        e = eval(e_txt.strip().replace("^", "**"), {"__builtins__": {}})  # "4 * 2^15"
+        nblocks = blocks.count("+") + 1 if "+" in blocks else int(blocks.split("x")[0])
+        val, unit = re.match(r"\s*([\d.]+)\s*(GiB|GB|MB)", size_txt).groups()
+        rows[int(cls)] = (nblocks, e, int(g), float(val) * {"GiB": 2**30, "GB": 1e9, "MB": 1e6}[unit], int(adds.replace(",", "")))
+    return rows
+
+
+def test_header_table_sizes_follow_the_geometry():
+    """the memory a maintainer provisions from the public header must be what the engine allocates: stated bytes =
+    G * 64 * e * 96 within rounding, additions per blob = 256 planes x blocks x 64 (tests/test_gpu_parity.py compares the same
+    rows with kzg_ctx_table_bytes / kzg_ctx_adds_per_blob on the device)"""
+    rows = header_table_rows()
+    assert sorted(rows) == [4, 8, 16, 22]
+    for cls, (nblocks, e, g, stated, adds) in rows.items():
+        assert abs(g * 64 * e * 96 - stated) / stated < 0.01, cls
+        assert adds == 256 * nblocks * 64, cls
+    assert rows[22][:3] == (3, 1 << 22, 8) and rows[16][:3] == (4, 4 << 15, 16)
+
+
+def test_product_sources_have_one_msm_path():
+    """the window-table cross-check kernels live under tests/window_msm and hook in through MsmOverride; the product sources
+    carry no conditional compilation for them and the product library none of their code"""
+    from kateth_amd import kzg
+
+    csrc = os.path.join(ROOT, "kateth_amd", "csrc")
+    for name in os.listdir(csrc):
+        if name.endswith((".hip", ".cuh", ".hpp", ".inc", ".h")):
+            text = open(os.path.join(csrc, name)).read()
+            assert "KZG_TEST_WINDOW_MSM" not in text and "k_msm_fixed28" not in text, name
+    syms = subprocess.check_output(["strings", kzg.library_path()], text=True)
+    assert "k_msm_comb28" in syms and "k_msm_fixed" not in syms and "kzg_test_read_wave_times" not in syms

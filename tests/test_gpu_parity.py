@@ -664,20 +664,20 @@ def test_evaluation_kernel_group_shapes_agree(engine, golden, torch_cuda, monkey
     assert zy["16"] == zy["64"]  # both shapes: the same challenges and evaluations, byte for byte
 
 
-def test_comb_and_window_table_kernels_agree_at_scale(torch_cuda, monkeypatch):
+def test_comb_and_window_table_kernels_agree_at_scale(torch_cuda, monkeypatch, window_msm_lib):
     """4,096 random blobs through three independent fixed-base MSMs must give identical commitments: the product's
-    subset-sum comb (msm_comb.cuh), and -- from the TEST-ONLY build (tests/window_msm, -DKZG_TEST_WINDOW_MSM) -- round 1's
-    window-table kernels on radix-2^28 limbs and on 12 x 32-bit limbs.  Different tables, different recodings (signed bits
+    subset-sum comb (msm_comb.cuh), and -- from the TEST-ONLY build (tests/window_msm) -- round 1's
+    window-table kernels on radix-2^28 limbs and on 12 x 32-bit limbs (tests/window_msm/window_msm.hip, hooked in through
+    the MsmOverride extension point).  Different tables, different recodings (signed bits
     vs signed windows), different field representations: 2e8 - 5e8 mixed additions each, including the few thousand that
     take the out-of-line complete adder."""
     import kateth_amd
-    import __graft_entry__ as g
 
     torch = torch_cuda
     n = 4096
     d_blobs = torch.empty(n * 131072, dtype=torch.uint8, device="cuda")
     outs = []
-    for env, lib in (({}, None), ({"KATETH_AMD_MSM": "window"}, g.TEST_LIB_WINDOW_MSM), ({"KATETH_AMD_MSM_RADIX": "32"}, g.TEST_LIB_WINDOW_MSM)):
+    for env, lib in (({}, None), ({"KATETH_AMD_MSM": "window"}, window_msm_lib), ({"KATETH_AMD_MSM_RADIX": "32"}, window_msm_lib)):
         for k in ("KATETH_AMD_MSM", "KATETH_AMD_MSM_RADIX"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
@@ -796,15 +796,14 @@ def test_mid_size_batches_take_the_unfused_preparation_path(engine, torch_cuda):
     assert engine.verify_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n - 1) is True
 
 
-def test_radix32_msm_kernel_is_bit_exact(golden, monkeypatch):
-    """the test-only build (tests/window_msm, -DKZG_TEST_WINDOW_MSM) with KATETH_AMD_MSM_RADIX=32 runs round 1's 12 x 32-bit-limb
+def test_radix32_msm_kernel_is_bit_exact(golden, monkeypatch, window_msm_lib):
+    """the test-only library (tests/window_msm) with KATETH_AMD_MSM_RADIX=32 runs round 1's 12 x 32-bit-limb
     window-table MSM kernel over a 2^384-Montgomery table -- an independent implementation of the same sum; the product
     library carries only the comb kernel (msm_comb.cuh).  Same bytes (the rest of this file runs the product)."""
     import kateth_amd
-    import __graft_entry__ as g
 
     monkeypatch.setenv("KATETH_AMD_MSM_RADIX", "32")
-    s = kateth_amd.Setup.load_json(TRUSTED_SETUP, window_bits=7, lib_path=g.TEST_LIB_WINDOW_MSM)
+    s = kateth_amd.Setup.load_json(TRUSTED_SETUP, window_bits=7, lib_path=window_msm_lib)
     try:
         recs = golden["blobs"][:3]
         blobs = b"".join(synth_blob(r["index"]) for r in recs) + be32(1) * 4096 + bytes(131072) + be32(R - 1) * 4096

@@ -19,8 +19,8 @@ import __graft_entry__ as g  # noqa: E402
 
 cls = int(sys.argv[2]) if len(sys.argv) > 2 else 22
 s28 = kateth_amd.Setup.load_json(SETUP, window_bits=cls)  # the product library: comb kernel (class 22: blocks of 22/21 points; 16: of 16 points)
-os.environ["KATETH_AMD_MSM_RADIX"] = "32"  # honoured only by the test-only build (tests/window_msm, -DKZG_TEST_WINDOW_MSM)
-s32 = kateth_amd.Setup.load_json(SETUP, window_bits=12, lib_path=g.TEST_LIB_WINDOW_MSM)
+os.environ["KATETH_AMD_MSM_RADIX"] = "32"  # honoured only by the test-only build (tests/window_msm)
+s32 = kateth_amd.Setup.load_json(SETUP, window_bits=12, lib_path=g.build_test_engine())
 d_blobs = torch.empty(n * 131072, dtype=torch.uint8, device="cuda")
 bufs = [torch.empty(n * 48, dtype=torch.uint8, device="cuda") for _ in range(4)]
 d_st = torch.empty(n, dtype=torch.int32, device="cuda")

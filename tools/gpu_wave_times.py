@@ -19,7 +19,7 @@ import torch  # noqa: E402
 import __graft_entry__ as ge  # noqa: E402
 import kateth_amd  # noqa: E402
 
-s = kateth_amd.Setup.load_json(os.path.join(ROOT, "tests", "golden", "trusted_setup_4096.json"), window_bits=c, lib_path=ge.TEST_LIB_WINDOW_MSM)
+s = kateth_amd.Setup.load_json(os.path.join(ROOT, "tests", "golden", "trusted_setup_4096.json"), window_bits=c, lib_path=ge.build_test_engine())
 d_blobs = torch.empty(n * 131072, dtype=torch.uint8, device="cuda")
 d_c = torch.empty(n * 48, dtype=torch.uint8, device="cuda")
 d_st = torch.empty(n, dtype=torch.int32, device="cuda")
