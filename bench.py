@@ -65,7 +65,72 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary proof/verify workloads")
     ap.add_argument("--cpu-sample", type=int, default=0, help="blobs in the CPU baseline sample (0 = auto, ~10-30 s)")
+    ap.add_argument("--spawn", action="store_true", help="start the rank processes through this script's launcher even for --gpus 1 (checks the launcher against the direct path)")
+    ap.add_argument("--rank-logs", default=os.path.join(ROOT, "gpurun_out", "bench_ranks"), help="launcher: directory for every rank's stdout/stderr (rank<k>.out / rank<k>.err)")
+    ap.add_argument("--dry-run", action="store_true", help="print every rank's HBM plan for --workload/--batch/--gpus as one JSON line and exit non-zero if it cannot fit; touches no GPU")
+    ap.add_argument("--assume-hbm-gib", type=float, default=0.0, help="--dry-run: HBM per GPU in GiB (default: 288 GB = 268.2 GiB, MI355X)")
     return ap.parse_args()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# memory plan: what one rank keeps resident, from the engine's own constants (include/kateth_amd.h, engine.hip)
+# ---------------------------------------------------------------------------------------------------------------
+GIB = float(1 << 30)
+MI355X_HBM_BYTES = 288e9
+TABLE_GROUP_BYTES = {22: 64 * (1 << 22) * 96, 16: 64 * (4 << 15) * 96, 8: 64 * (8 << 7) * 96, 4: 64 * (16 << 3) * 96}
+
+
+def table_plan(window_bits, free_bytes):
+    """(class, plane groups, table bytes) kzg_ctx_create builds for `window_bits` with `free_bytes` of HBM free
+    (engine.hip: 22/G8 from 232 GiB, 22/G4 from 136 GiB, 16 from 21 GiB, else 8; an explicit class is honoured)"""
+    g22 = TABLE_GROUP_BYTES[22]
+    c = window_bits
+    if c == 0:
+        c = 22 if free_bytes >= 4 * g22 + 40 * GIB else (16 if free_bytes >= 21 * GIB else 8)
+    cls = 22 if c >= 22 else (16 if c >= 16 else (8 if c >= 8 else 4))
+    groups = (8 if free_bytes >= 8 * g22 + 40 * GIB else 4) if cls == 22 else 16
+    return cls, groups, groups * TABLE_GROUP_BYTES[cls] + (403e6 if cls == 22 else 0)
+
+
+def memory_plan(workload, n, window_bits, total_bytes):
+    """bytes one rank holds for `n` blobs per step: caller buffers (blobs, results), the context's table and the engine's
+    workspace (fixed-base MSM: chunks of at most 16,384 blobs -> bit-plane masks 128 KiB + lane sums 65 x 192 B per blob;
+    proof: + 128 KiB of quotient scalars per blob of a chunk; verify: a pooled session of ~800 B per item)"""
+    cls, groups, table = table_plan(window_bits, total_bytes)
+    chunk = min(n, 16384)
+    msm_ws = chunk * (BYTES_PER_BLOB + 65 * 192 + 192)
+    plan = {"table_class": cls, "plane_groups": groups, "table": table, "table_build_scratch_transient": 13 * GIB if cls == 22 else 1.7 * GIB,
+            "blobs": n * BYTES_PER_BLOB, "results_and_status": n * (48 + 4)}
+    if workload == "commit":
+        plan["workspace"] = msm_ws
+    elif workload == "proof":
+        plan["commitments"] = n * 48
+        plan["workspace"] = msm_ws + chunk * (BYTES_PER_BLOB + 512)
+    else:
+        plan["commitments_and_proofs"] = n * 96
+        plan["workspace"] = n * 800 + (1 << 20)
+        plan["setup_phase_peak"] = msm_ws + chunk * (BYTES_PER_BLOB + 512)  # the triples are produced by commit + prove first
+    resident = sum(v for k, v in plan.items() if k not in ("table_class", "plane_groups", "table_build_scratch_transient"))
+    plan["resident_total"] = resident
+    plan["peak_total"] = max(resident, plan["table"] + plan["table_build_scratch_transient"])
+    plan["hbm_total"] = total_bytes
+    plan["fits"] = bool(plan["peak_total"] + 2 * GIB <= total_bytes)  # 2 GiB for the runtime, RCCL buffers and the allocator
+    return plan
+
+
+def dry_run(args):
+    wl = args.workload
+    n = args.batch or DEFAULT_BATCH[wl]
+    total = args.assume_hbm_gib * GIB if args.assume_hbm_gib else MI355X_HBM_BYTES
+    plan = memory_plan(wl, n, args.window_bits, total)
+    out = {"dry_run": True, "workload": wl, "gpus": args.gpus, "blobs_per_gpu": n, "blobs_total": n * args.gpus,
+           "ranks": [dict(plan, rank=r, first_blob=r * n) for r in range(args.gpus)],
+           "gib": {k: round(v / GIB, 2) for k, v in plan.items() if isinstance(v, (int, float)) and not isinstance(v, bool) and k not in ("table_class", "plane_groups")},
+           "exchange_bytes_per_step_per_rank": n * 48 if wl != "verify" else 32 + 32 + 192}
+    print(json.dumps(out), flush=True)
+    if not plan["fits"]:
+        sys.stderr.write("bench.py --dry-run: %.1f GiB needed per GPU, %.1f GiB of HBM: does not fit\n" % (plan["peak_total"] / GIB, total / GIB))
+        sys.exit(3)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -79,13 +144,19 @@ def launch_ranks(args):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    procs = []
+    procs, logs = [], []
+    os.makedirs(args.rank_logs, exist_ok=True)
+    child_args = [a for a in sys.argv[1:] if a != "--spawn"]
     for rank in range(args.gpus):
         env = dict(os.environ)
         env.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(args.gpus), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
                     "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
-        out = subprocess.PIPE if rank == 0 else subprocess.DEVNULL
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out))
+        # every rank's stdout and stderr survive in files (on an N-GPU failure the other ranks' output is the evidence);
+        # rank 0's stdout is also relayed
+        err = open(os.path.join(args.rank_logs, "rank%d.err" % rank), "wb")
+        out = subprocess.PIPE if rank == 0 else open(os.path.join(args.rank_logs, "rank%d.out" % rank), "wb")
+        logs.append((out, err))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + child_args, env=env, stdout=out, stderr=err))
     # relay rank 0's stdout; if ANY rank dies, stop the others (their collectives would otherwise wait for the timeout)
     import threading
 
@@ -111,12 +182,33 @@ def launch_ranks(args):
             break
         time.sleep(0.05)
     reader.join(timeout=10)
-    sys.stdout.write(b"".join(chunks).decode())
+    rank0_out = b"".join(chunks)
+    with open(os.path.join(args.rank_logs, "rank0.out"), "wb") as fh:
+        fh.write(rank0_out)
+    for out, err in logs:
+        err.close()
+        if out is not subprocess.PIPE:
+            out.close()
+    sys.stdout.write(rank0_out.decode())
     sys.stdout.flush()
     bad = [c for c in codes if c != 0]
     if bad:
-        sys.stderr.write("bench.py launcher: rank exit codes %r\n" % codes)
+        sys.stderr.write("bench.py launcher: rank exit codes %r; per-rank logs in %s\n" % (codes, args.rank_logs))
+        for rank, c in enumerate(codes):
+            if c != 0:
+                try:
+                    tail = open(os.path.join(args.rank_logs, "rank%d.err" % rank), "rb").read()[-1500:].decode(errors="replace")
+                except OSError:
+                    tail = ""
+                sys.stderr.write("---- rank %d (exit %r) stderr tail ----\n%s\n" % (rank, c, tail))
         sys.exit(bad[0] if bad[0] and bad[0] > 0 else 1)
+    for rank in range(args.gpus):  # a clean run still shows what the ranks said on stderr (warnings), rank 0 first
+        try:
+            txt = open(os.path.join(args.rank_logs, "rank%d.err" % rank), "rb").read().decode(errors="replace")
+        except OSError:
+            continue
+        if txt.strip() and rank == 0:
+            sys.stderr.write(txt)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -210,6 +302,21 @@ class Rank:
         self.local_dev = local_rank % max(1, ndev)  # ranks share a card only in the gloo rehearsal
         torch.cuda.set_device(self.local_dev)
         self.dev = torch.device("cuda", self.local_dev)
+        if world > 1:  # RCCL needs one GPU per rank: every rank of a host must sit on a card of its own
+            import socket
+
+            mine = (socket.gethostname(), torch.cuda.current_device(), getattr(torch.cuda.get_device_properties(self.local_dev), "pci_bus_id", -1))
+            seats = [None] * world
+            dist.all_gather_object(seats, mine)
+            self.seats = seats
+            if args.backend == "nccl" and len(set(seats)) != world:
+                raise SystemExit("bench.py: backend nccl but two ranks share a GPU: %r" % (seats,))
+        # the HBM plan of this rank, checked against the device BEFORE anything is allocated
+        wl = args.workload
+        free_b, total_b = torch.cuda.mem_get_info(self.local_dev)
+        self.plan = memory_plan(wl, args.batch or DEFAULT_BATCH[wl], args.window_bits, free_b)
+        if not self.plan["fits"] and world > 1 and args.backend == "nccl":
+            raise SystemExit("bench.py rank %d: plan needs %.1f GiB, device has %.1f GiB free (%.1f total)" % (rank, self.plan["peak_total"] / GIB, free_b / GIB, total_b / GIB))
         import kateth_amd
 
         self.kateth_amd = kateth_amd
@@ -445,6 +552,8 @@ def run_rank(args, rank, local_rank, world):
             "parallelism": "blob-sharded x%d, %s" % (world, "RCCL all-gather of 48-B results" if wl != "verify" else "all-gather of 32-B transcript roots + 192-B partial sums, one pairing"),
             "backend": args.backend if world > 1 else None,
             "setup_s": R.t_setup,
+            "plane_groups": setup.plane_groups,
+            "hbm_plan_gib": {k: round(v / GIB, 2) for k, v in R.plan.items() if k in ("table", "blobs", "workspace", "resident_total", "peak_total", "hbm_total")},
         },
     }
     if rank == 0:
@@ -491,9 +600,11 @@ def run_rank(args, rank, local_rank, world):
 
 def main():
     args = parse()
+    if args.dry_run:
+        return dry_run(args)
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None:
-        if args.gpus > 1:
+        if args.gpus > 1 or args.spawn:
             return launch_ranks(args)  # before any torch / HIP import in this process
         return run_rank(args, 0, 0, 1)
     world = int(env_world)

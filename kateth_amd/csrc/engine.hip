@@ -61,27 +61,58 @@ int32_t ws_release(const kzg_ctx* ctx, hipStream_t st) {
 
 const MsmOverride* (*g_msm_override_hook)(kzg_ctx* ctx, uint32_t window_bits) = nullptr;  // set only by the test-only library (tests/window_msm)
 
+// Shape of a fixed-base MSM launch over n blobs: (blob, split) units of 64 lanes, or -- splits = 1, lpb = 32 -- two blobs per
+// wave.  All waves of a launch are equally long, the chip holds S = num_CUs x 8 of them (two per SIMD), and they are dealt
+// out as slots free up, so a launch takes ceil(waves / S) rounds of one wave's length: A / v additions (A = planes per lane x
+// blocks per lane) + H - 1 Horner doublings (0.75 of an addition each), repeated by every split.  2,050 blobs as 2,050 waves
+// would run a second round for two waves; 6 splits make it 7 rounds of 151 instead of 2 of 791.  The cheapest shape wins; ties
+// go to fewer units (less lane-sum tree work, charged as 10 additions per round).
+struct MsmShapeCost {
+  uint32_t splits;
+  uint32_t lpb;
+  double cost;
+};
+static MsmShapeCost msm_shape(const kzg_ctx* ctx, uint64_t n) {
+  const double S = (double)ctx->num_cus * 8.0;
+  const uint32_t per_lane = (64u * ctx->comb.nb) / ctx->comb.lpg;  // blocks a lane owns at 64 lanes per blob, one split
+  const double A = (double)ctx->comb.H * per_lane, D = 0.75 * (ctx->comb.H - 1u);
+  auto rounds = [&](double waves) { return waves <= S ? 1.0 : (double)(uint64_t)((waves + S - 1) / S); };
+  MsmShapeCost best{1, 64, 0};
+  bool have = false;
+  for (uint32_t v = 1; v <= 64 && v <= per_lane; v++) {
+    if (per_lane % v != 0) continue;  // a lane owns a whole number of blocks; k_msm_reduce_splits sums <= 64 units
+    const double c = rounds((double)n * v) * (A / v + D + 10.0);
+    if (!have || c < best.cost) {
+      best = MsmShapeCost{v, 64, c};
+      have = true;
+    }
+  }
+  const bool half_ok = !ctx->knobs.comb_full_wave && ctx->comb.G <= 32 && (64u * ctx->comb.nb) % (32u / ctx->comb.G) == 0;
+  if (half_ok && n >= 2) {
+    const double c = rounds((double)((n + 1) / 2)) * (2.0 * A + D + 10.0);
+    if (c < best.cost) best = MsmShapeCost{1, 32, c};
+  }
+  return best;
+}
+
 uint32_t choose_splits(const kzg_ctx* ctx, uint64_t n) {
-  // aim for >= 4 waves per SIMD-slot-pair across the chip; splits is a power of two <= 64
-  const uint64_t target = (uint64_t)ctx->num_cus * 8;
-  if (ctx->use_comb) {  // a lane must own a whole number of blocks: splits divides (64 * nb) / lpg; k_msm_reduce_splits sums <= 64 units
+  if (ctx->use_comb) {
     if (ctx->d_table_lat && n <= KZG_LAT_MAX_BLOBS && !ctx->knobs.msm_splits) return KZG_LAT_SPLITS;  // the latency comb: 8 blocks x 4 planes per lane
     const uint32_t per_lane = (64u * ctx->comb.nb) / ctx->comb.lpg;
-    auto ok = [&](uint32_t v) { return v >= 1 && v <= 64 && per_lane % v == 0; };
-    if (ctx->knobs.msm_splits && ok(ctx->knobs.msm_splits)) return ctx->knobs.msm_splits;
-    uint32_t best = 1;
-    for (uint32_t v = 1; v <= 64 && v <= per_lane; v++) {
-      if (!ok(v)) continue;
-      best = v;
-      if (n * v >= target) break;  // smallest split count that fills the chip, else the largest allowed
-    }
-    return best;
+    if (ctx->knobs.msm_splits && ctx->knobs.msm_splits <= 64 && per_lane % ctx->knobs.msm_splits == 0) return ctx->knobs.msm_splits;
+    return msm_shape(ctx, n).splits;
   }
-  // test-only window-table override: any power of two
+  // test-only window-table override: any power of two, enough units for 8 waves per CU
   if (ctx->knobs.msm_splits) return ctx->knobs.msm_splits;
+  const uint64_t target = (uint64_t)ctx->num_cus * 8;
   uint32_t s = 1;
   while (s < 64 && n * s < target) s <<= 1;
   return s;
+}
+uint32_t msm_lanes_per_blob(const kzg_ctx* ctx, uint64_t n, uint32_t splits) {
+  if (!ctx->use_comb || splits != 1 || ctx->knobs.msm_splits) return 64;
+  if (msm_uses_lat(ctx, splits)) return 64;
+  return msm_shape(ctx, n).lpb;
 }
 
 extern "C" uint64_t kzg_ctx_adds_per_blob(const kzg_ctx* ctx) {
@@ -200,6 +231,7 @@ extern "C" void kzg_ctx_destroy(kzg_ctx* ctx) {
   if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   if (ctx->ws_event) (void)hipEventDestroy(ctx->ws_event);
+  for (auto e : ctx->proof_events) (void)hipEventDestroy(e);
   for (auto& pe : ctx->prof_events) {
     (void)hipEventDestroy(pe.e0);
     (void)hipEventDestroy(pe.e1);
@@ -506,112 +538,125 @@ extern "C" int32_t kzg_blob_to_commitment_batch_dev(const kzg_ctx* ctx, const vo
   return rc;
 }
 
-// Host-buffer entry point.  The blobs cross PCIe in chunks (plan below) through two device staging buffers: while the MSM
-// kernel of chunk k runs on a compute stream, chunk k+1 is copied in on a copy stream, so that the transfer (56-57 GB/s:
-// 9.4 ms per 4,096 blobs) hides behind the MSM instead of preceding it.  Only the MSM kernel is launched per chunk; the
-// latency-bound tail (lane-sum trees, inversion + encoding) runs once per group of chunks.
+// Host-buffer entry point.  The blobs cross PCIe in chunks through two device staging buffers: while the MSM of chunk k runs
+// on one compute stream, chunk k+1 is copied in on the copy stream and then runs on the OTHER compute stream, so the
+// transfer (56-57 GB/s: 9.4 ms per 4,096 blobs) hides behind the MSM and only the first chunk's copy is exposed.
+//
+// Chunk plan: a RAMP.  The exposed copy should be short, but a small chunk is an inefficient MSM launch (it needs split
+// units to fill the chip, and every split repeats a lane's Horner doublings: 31 per 192 additions at 512 blobs, per 1,536 in
+// half-wave mode), and a chunk's copy must finish inside the previous chunk's MSM (a blob copies in 2.3 us and commits in
+// 7.3 us: the next chunk may be up to 3x as large).  So chunks grow 512, 512, 1,024, 2,048, then 4,096 (half-wave mode) --
+// every one a launch that fills the chip once or an exact number of times, each with the splits choose_splits gives its size.
+// Every chunk is its own group (its lane-sum trees and encoding follow its MSM on its stream, beside the next chunk's MSM).
+// The staging buffer of a slot is free again as soon as the chunk's bit-plane transposition has read it.
+// Measured at n = 4,096 on one box: 4 equal chunks 36.0 ms (profiles/r03/host_commit_timeline_equal_chunks.txt), ramp: see
+// DESIGN.md section 7.
+static std::vector<uint64_t> commit_host_plan(uint64_t n) {
+  std::vector<uint64_t> plan;
+  if (n <= 768) {
+    plan.push_back(n);
+    return plan;
+  }
+  // the ramp as far as it fits, then half-wave chunks of 4,096; a remainder below 256 blobs joins the first chunk (three
+  // splits still run 682 blobs in one round), a longer one is the last chunk with a shape of its own
+  const uint64_t ramp[4] = {512, 512, 1024, 2048};
+  uint64_t rest = n;
+  for (uint64_t r : ramp) {
+    if (rest < r) break;
+    plan.push_back(r);
+    rest -= r;
+  }
+  if (plan.size() == 4)
+    for (; rest >= 4096; rest -= 4096) plan.push_back(4096);
+  if (rest >= 256)
+    plan.push_back(rest);
+  else
+    plan[0] += rest;
+  return plan;
+}
+
 static int32_t commit_host(const kzg_ctx* ctx, const uint8_t* blobs, uint64_t n, uint8_t* out48, uint8_t* out_affine96, int32_t* status) {
   if (!ctx || (n && (!blobs || (!out48 && !out_affine96) || !status))) return fail(KZG_FAIL_ARGUMENT, "null argument");
   if (n == 0) return 0;
   HIP_TRY(hipSetDevice(ctx->device));
-  // Chunk plan: the copy of chunk k+1 (57 GB/s: 2.3 ms per 1,024 blobs) runs beside the MSM of chunk k (7-8 ms per 1,024),
-  // so only the first copy is exposed -- but small chunks pay for it with MSM efficiency (64 lanes per blob, split units
-  // that repeat the Horner doublings).  A quarter of the batch per chunk; from 16,384 blobs on chunks of 4,096, which run in
-  // the comb's half-wave mode.  A group of chunks shares the lane-sum trees and the encoding (and therefore its unit shape):
-  // half-wave chunks are their own group, so a short last chunk gets splits of its own instead of a few 29-ms waves.
-  uint64_t chunk = n;  // up to 512 blobs: one chunk
-  if (n > 8192)
-    chunk = n < 16384 ? 2048 : 4096;
-  else if (n > 512)
-    chunk = (n + 3) / 4 < 512 ? 512 : (((n + 3) / 4 + 1) & ~(uint64_t)1);
-  const bool half_wave = msm_lanes_per_blob(ctx, chunk, choose_splits(ctx, chunk)) == 32;
-  const uint64_t group = half_wave ? chunk : (n < 8192 ? n : 8192);  // a multiple of the chunk size when n > 8192
-  uint64_t max_units = 1;  // (blob, split) units of the largest group: its lane sums live in the workspace
-  for (uint64_t gbase = 0; gbase < n; gbase += group) {
-    const uint64_t gm = (n - gbase < group) ? (n - gbase) : group;
-    const uint64_t units = gm * choose_splits(ctx, gm < chunk ? gm : chunk);
-    if (units > max_units) max_units = units;
+  const std::vector<uint64_t> plan = commit_host_plan(n);
+  uint64_t max_chunk = 0, max_units = 1;
+  for (uint64_t m : plan) {
+    const uint32_t sp = choose_splits(ctx, m);
+    const uint64_t units = msm_units(m, sp, msm_lanes_per_blob(ctx, m, sp));
+    max_chunk = m > max_chunk ? m : max_chunk;
+    max_units = units > max_units ? units : max_units;
   }
-  uint8_t* stage[2] = {nullptr, nullptr};
-  uint8_t* d_out = nullptr;
-  uint8_t* d_aff = nullptr;
-  int32_t* d_status = nullptr;
-  hipStream_t copy_st = ctx->copy_stream, comp_st = ctx->side_stream;
-  hipEvent_t done[2] = {nullptr, nullptr};
-  int32_t rc = 0;
-  auto cleanup = [&]() {
-    for (int k = 0; k < 2; k++) {
-      if (stage[k]) (void)hipFree(stage[k]);
-      if (done[k]) (void)hipEventDestroy(done[k]);
-    }
-    if (d_out) (void)hipFree(d_out);
-    if (d_aff) (void)hipFree(d_aff);
-    if (d_status) (void)hipFree(d_status);
-  };
-  std::lock_guard<std::mutex> guard(ctx->lock);  // the workspace holds a whole group's lane sums
+  // Pooled resources: the staging arena, the result buffers, the streams and the events belong to the context
+  // (stage_lock), so a steady-state call allocates nothing; the streams are ordered by events only -- the host never waits
+  // inside the loop.
+  std::lock_guard<std::mutex> stage_guard(ctx->stage_lock);
+  int32_t rc = stage_init(ctx);
+  if (rc) return rc;
+  const uint64_t nslots = plan.size() > 1 ? 2 : 1;
+  const size_t slot_bytes = (size_t)max_chunk * KZG_BYTES_PER_BLOB;
+  const size_t out_bytes = align_up((size_t)n * (out48 ? 48 : 96), 256);
+  rc = stage_reserve(ctx, nslots * slot_bytes, out_bytes + (size_t)n * sizeof(int32_t));
+  if (rc) return rc;
+  uint8_t* d_res = ctx->hostio;
+  int32_t* d_status = reinterpret_cast<int32_t*>(ctx->hostio + out_bytes);
+  hipStream_t copy_st = ctx->stage_copy_stream;
+  hipStream_t comp[2] = {ctx->stage_streams[0], ctx->stage_streams[1]};
+  std::lock_guard<std::mutex> guard(ctx->lock);  // the workspace: per slot the lane sums, the sums and the bit-plane masks of a chunk
   do {
-    if (hipMalloc(&stage[0], chunk * (size_t)KZG_BYTES_PER_BLOB) != hipSuccess ||
-        (n > chunk && hipMalloc(&stage[1], chunk * (size_t)KZG_BYTES_PER_BLOB) != hipSuccess) ||
-        (out48 && hipMalloc(&d_out, n * 48) != hipSuccess) || (out_affine96 && hipMalloc(&d_aff, n * 96) != hipSuccess) ||
-        hipMalloc(&d_status, n * sizeof(int32_t)) != hipSuccess || hipEventCreateWithFlags(&done[0], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&done[1], hipEventDisableTiming) != hipSuccess) {
-      rc = fail(KZG_FAIL_HIP, "host-buffer commitment: allocation failed");
-      break;
-    }
     const size_t partial_bytes = align_up((size_t)max_units * 65 * sizeof(g1_xyzz), 256);
-    const size_t sums_bytes = align_up((size_t)group * sizeof(g1_xyzz), 256);
-    rc = ws_reserve(ctx, partial_bytes + sums_bytes + 2 * msm_scratch_bytes(ctx, chunk));
+    const size_t sums_bytes = align_up((size_t)max_chunk * sizeof(g1_xyzz), 256);
+    const size_t scratch_bytes = align_up(msm_scratch_bytes(ctx, max_chunk), 256);
+    const size_t per_slot = partial_bytes + sums_bytes + scratch_bytes;
+    rc = ws_reserve(ctx, nslots * per_slot);
     if (rc) break;
-    g1_xyzz* partials = reinterpret_cast<g1_xyzz*>(ctx->ws);
-    g1_xyzz* sums = reinterpret_cast<g1_xyzz*>(reinterpret_cast<uint8_t*>(ctx->ws) + partial_bytes);
-    uint8_t* msm_scratch = reinterpret_cast<uint8_t*>(ctx->ws) + partial_bytes + sums_bytes;  // one per staging slot
-    rc = ws_acquire(ctx, comp_st);
+    rc = ws_acquire(ctx, comp[0]);
+    if (rc == 0) rc = ws_acquire(ctx, comp[1]);
     if (rc) break;
-    if (hipMemsetAsync(d_status, 0, n * sizeof(int32_t), comp_st) != hipSuccess) {
+    if (hipMemsetAsync(d_status, 0, n * sizeof(int32_t), comp[0]) != hipSuccess || hipEventRecord(ctx->stage_join[0], comp[0]) != hipSuccess ||
+        hipStreamWaitEvent(comp[1], ctx->stage_join[0], 0) != hipSuccess) {
       rc = fail(KZG_FAIL_HIP, "memset failed");
       break;
     }
-    uint64_t k = 0;  // running chunk counter (staging slot = k & 1)
-    for (uint64_t gbase = 0; gbase < n && rc == 0; gbase += group) {
-      const uint64_t gm = (n - gbase < group) ? (n - gbase) : group;
-      const uint32_t splits = choose_splits(ctx, gm < chunk ? gm : chunk);
-      const uint32_t lpb = msm_lanes_per_blob(ctx, gm < chunk ? gm : chunk, splits);
-      for (uint64_t off = 0; off < gm && rc == 0; off += chunk, k++) {
-        const int slot = (int)(k & 1);
-        const uint64_t base = gbase + off;
-        const uint64_t m = (gm - off < chunk) ? (gm - off) : chunk;
-        if (k >= 2 && hipEventSynchronize(done[slot]) != hipSuccess) {  // chunk k-2 no longer reads this staging buffer
-          rc = fail(KZG_FAIL_HIP, "event synchronize failed");
-          break;
-        }
-        if (hipMemcpyAsync(stage[slot], blobs + base * (size_t)KZG_BYTES_PER_BLOB, m * (size_t)KZG_BYTES_PER_BLOB, hipMemcpyHostToDevice,
-                           copy_st) != hipSuccess ||
-            hipStreamSynchronize(copy_st) != hipSuccess) {
-          rc = fail(KZG_FAIL_HIP, "host-to-device copy failed");
-          break;
-        }
-        rc = msm_launch<true>(ctx, stage[slot], m, d_status + base, partials + (size_t)off * splits * lpb, splits, lpb,
-                              msm_scratch + (size_t)slot * msm_scratch_bytes(ctx, chunk), comp_st);
-        if (rc == 0 && hipEventRecord(done[slot], comp_st) != hipSuccess) rc = fail(KZG_FAIL_HIP, "event record failed");
+    uint64_t base = 0;
+    for (size_t k = 0; k < plan.size() && rc == 0; base += plan[k], k++) {
+      const int slot = (int)(k & 1);  // staging slot = workspace slot = compute stream
+      const uint64_t m = plan[k];
+      const uint32_t splits = choose_splits(ctx, m);
+      const uint32_t lpb = msm_lanes_per_blob(ctx, m, splits);
+      uint8_t* wslot = reinterpret_cast<uint8_t*>(ctx->ws) + (size_t)slot * per_slot;
+      g1_xyzz* partials = reinterpret_cast<g1_xyzz*>(wslot);
+      g1_xyzz* sums = reinterpret_cast<g1_xyzz*>(wslot + partial_bytes);
+      // chunk k-2 (same slot) must have been transposed out of the staging buffer before it is overwritten
+      if (k >= 2 && hipStreamWaitEvent(copy_st, ctx->stage_done[slot], 0) != hipSuccess) {
+        rc = fail(KZG_FAIL_HIP, "stream wait failed");
+        break;
       }
+      if (hipMemcpyAsync(ctx->stage + (size_t)slot * slot_bytes, blobs + base * (size_t)KZG_BYTES_PER_BLOB, m * (size_t)KZG_BYTES_PER_BLOB,
+                         hipMemcpyHostToDevice, copy_st) != hipSuccess ||
+          hipEventRecord(ctx->stage_copied[slot], copy_st) != hipSuccess || hipStreamWaitEvent(comp[slot], ctx->stage_copied[slot], 0) != hipSuccess) {
+        rc = fail(KZG_FAIL_HIP, "host-to-device copy failed");
+        break;
+      }
+      rc = msm_launch<true>(ctx, ctx->stage + (size_t)slot * slot_bytes, m, d_status + base, partials, splits, lpb, wslot + partial_bytes + sums_bytes,
+                            comp[slot], ctx->stage_done[slot]);
       if (rc == 0)
-        rc = msm_finish(ctx, gm, d_out ? d_out + gbase * 48 : nullptr, d_aff ? d_aff + gbase * 96 : nullptr, d_status + gbase, partials, sums, splits,
-                        lpb, comp_st);
+        rc = msm_finish(ctx, m, out48 ? d_res + base * 48 : nullptr, out_affine96 ? d_res + base * 96 : nullptr, d_status + base, partials, sums, splits, lpb,
+                        comp[slot]);
     }
     if (rc) break;
-    rc = ws_release(ctx, comp_st);
-    if (rc) break;
-    if (hipStreamSynchronize(comp_st) != hipSuccess) {
-      rc = fail(KZG_FAIL_HIP, "stream synchronize failed");
+    if (hipEventRecord(ctx->stage_join[1], comp[1]) != hipSuccess || hipStreamWaitEvent(comp[0], ctx->stage_join[1], 0) != hipSuccess) {
+      rc = fail(KZG_FAIL_HIP, "stream join failed");
       break;
     }
-    if ((out48 && hipMemcpy(out48, d_out, n * 48, hipMemcpyDeviceToHost) != hipSuccess) ||
-        (out_affine96 && hipMemcpy(out_affine96, d_aff, n * 96, hipMemcpyDeviceToHost) != hipSuccess) ||
-        hipMemcpy(status, d_status, n * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess)
+    rc = ws_release(ctx, comp[0]);
+    if (rc) break;
+    if (hipMemcpyAsync(out48 ? out48 : out_affine96, d_res, (size_t)n * (out48 ? 48 : 96), hipMemcpyDeviceToHost, comp[0]) != hipSuccess ||
+        hipMemcpyAsync(status, d_status, n * sizeof(int32_t), hipMemcpyDeviceToHost, comp[0]) != hipSuccess ||
+        hipStreamSynchronize(comp[0]) != hipSuccess)
       rc = fail(KZG_FAIL_HIP, "device-to-host copy failed");
   } while (0);
   if (rc) (void)hipDeviceSynchronize();
-  cleanup();
   return rc;
 }
 

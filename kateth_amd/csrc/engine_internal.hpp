@@ -117,6 +117,7 @@ struct kzg_ctx {
   mutable void* ws = nullptr;
   mutable size_t ws_bytes = 0;
   mutable hipEvent_t ws_event = nullptr;  // recorded after the last enqueued user of `ws`; the next user's stream waits on it
+  mutable std::vector<hipEvent_t> proof_events;  // pooled fork/join events of the proof path's chunk pipeline (guarded by lock)
   // profiling (kzg_profile_begin/end): event pairs around the launches of the kernels named by ProfKind, each pair on the
   // stream its kernel runs on; own lock (the verify entry points do not take `lock`)
   mutable std::mutex prof_lock;
@@ -126,16 +127,21 @@ struct kzg_ctx {
   // pooled verify sessions (device scratch + side stream + events), engine_verify.hip
   mutable std::mutex pool_lock;
   mutable std::vector<kzg_verify_session*> session_pool;
-  // host-buffer verification pipeline (engine_verify.hip), guarded by stage_lock: a staging arena of up to
+  // host-buffer pipelines (verification: engine_verify.hip; commitments: engine.hip; proofs: engine_proof.hip), guarded by
+  // stage_lock, so that a steady-state host-buffer call allocates nothing: a staging arena of up to
   // KZG_STAGE_SLOTS chunk slots, a copy stream, rotating compute streams and their events; created on first use
   mutable std::mutex stage_lock;
   mutable uint8_t* stage = nullptr;
   mutable size_t stage_bytes = 0;
+  mutable uint8_t* hostio = nullptr;  // pooled device buffers for the small inputs/outputs of the host-buffer commit/proof calls (48-96 B per item)
+  mutable size_t hostio_bytes = 0;
   mutable bool stage_ready = false;
   mutable hipStream_t verify_stream = nullptr, stage_copy_stream = nullptr, stage_streams[KZG_STAGE_STREAMS] = {};
   mutable hipEvent_t stage_copied[KZG_STAGE_SLOTS] = {}, stage_done[KZG_STAGE_SLOTS] = {}, stage_join[KZG_STAGE_STREAMS] = {};
 };
 void session_pool_clear(const kzg_ctx* ctx);
+int32_t stage_init(const kzg_ctx* ctx);                                             // caller holds stage_lock
+int32_t stage_reserve(const kzg_ctx* ctx, size_t arena_bytes, size_t io_bytes);   // caller holds stage_lock
 void stage_destroy(const kzg_ctx* ctx);
 
 int32_t ws_reserve(const kzg_ctx* ctx, size_t bytes);
@@ -199,32 +205,36 @@ static inline void launch_challenge_and_decode(const kzg_ctx* ctx, hipStream_t s
                      n_b, status_b, affine, inf);
 }
 
-// The comb's half-wave mode: once a batch fills the chip with two blobs per wave, a blob takes 32 lanes (each lane owns
-// twice the blocks for the same number of Horner doublings).  Units = waves of the MSM kernel = rows of 64 lane sums.
+// The comb's half-wave mode: when two blobs per wave is the cheaper shape (engine.hip, msm_shape: from num_CUs x 16 = 4,096
+// blobs per launch on, when that fills whole rounds), a blob takes 32 lanes (each lane owns twice the blocks for the same
+// number of Horner doublings).  Units = waves of the MSM kernel = rows of 64 lane sums.
 constexpr uint64_t KZG_LAT_MAX_BLOBS = 16;
 constexpr uint32_t KZG_LAT_SPLITS = 64;  // the main class-22 comb never splits 64 ways (24 blocks per lane), so the split count names the table
 static inline bool msm_uses_lat(const kzg_ctx* ctx, uint32_t splits) { return ctx->d_table_lat != nullptr && splits == KZG_LAT_SPLITS; }
-static inline uint32_t msm_lanes_per_blob(const kzg_ctx* ctx, uint64_t n, uint32_t splits) {
-  if (!ctx->use_comb || splits != 1 || ctx->knobs.comb_full_wave) return 64;
-  if (ctx->comb.G > 32 || (64u * ctx->comb.nb) % (32u / ctx->comb.G) != 0) return 64;
-  return n >= (uint64_t)ctx->num_cus * 16 ? 32 : 64;  // 2 waves per SIMD x 4 SIMDs x 2 blobs per wave
-}
+uint32_t msm_lanes_per_blob(const kzg_ctx* ctx, uint64_t n, uint32_t splits);  // engine.hip (msm_shape)
 static inline uint64_t msm_units(uint64_t n, uint32_t splits, uint32_t lpb) { return lpb == 64 ? n * splits : (n + 1) / 2; }
 
 // Scratch the fixed-base MSM needs besides the lane sums: the comb's bit-plane masks (the blob transposed, 128 KiB per blob).
 static inline size_t msm_scratch_bytes(const kzg_ctx* ctx, uint64_t n) { return ctx->use_comb ? (size_t)n * KZG_BYTES_PER_BLOB : 0; }
 
 // The fixed-base MSM alone over `n` scalar vectors on the device: 64 lane sums per (blob, split) unit into
-// partials[unit * 64 + lane].  `scratch`: msm_scratch_bytes(ctx, n) bytes.
+// partials[unit * 64 + lane].  `scratch`: msm_scratch_bytes(ctx, n) bytes.  `scalars_consumed` (optional): recorded on `st` as
+// soon as d_scalars is no longer read (after the bit-plane transposition; the MSM kernel reads the masks), so that a staging
+// buffer can be refilled while the MSM runs.
 template <bool BE_BYTES>
 static int32_t msm_launch(const kzg_ctx* ctx, const uint8_t* d_scalars, uint64_t n, int32_t* d_status, g1_xyzz* partials, uint32_t splits,
-                          uint32_t lpb, void* scratch, hipStream_t st) {
-  if (ctx->msm_override) return ctx->msm_override->launch(ctx, BE_BYTES, d_scalars, n, d_status, partials, splits, lpb, scratch, st);
+                          uint32_t lpb, void* scratch, hipStream_t st, hipEvent_t scalars_consumed = nullptr) {
+  if (ctx->msm_override) {
+    int32_t rco = ctx->msm_override->launch(ctx, BE_BYTES, d_scalars, n, d_status, partials, splits, lpb, scratch, st);
+    if (rco == 0 && scalars_consumed) HIP_TRY(hipEventRecord(scalars_consumed, st));
+    return rco;
+  }
   uint64_t* masks = reinterpret_cast<uint64_t*>(scratch);
   {
     ProfScope ps(ctx, PROF_TRANSPOSE, st);
     hipLaunchKernelGGL((k_comb_transpose<BE_BYTES>), dim3((unsigned)(n * 8)), dim3(512), 0, st, d_scalars, n, masks, d_status);
   }
+  if (scalars_consumed) HIP_TRY(hipEventRecord(scalars_consumed, st));
   ProfScope ps(ctx, PROF_MSM_FIXED, st);
   const bool lat = msm_uses_lat(ctx, splits);
   const uint4* table = lat ? ctx->d_table_lat : ctx->d_table;

@@ -57,27 +57,21 @@ static int32_t proof_dev_locked(const kzg_ctx* ctx, const uint8_t* d_blobs, cons
   g1_xyzz* partials = reinterpret_cast<g1_xyzz*>(ws + o_part);
   g1_xyzz* sums = reinterpret_cast<g1_xyzz*>(ws + o_sum);
   hipStream_t side = overlap ? ctx->side_stream : st;
-  std::vector<hipEvent_t> ev_prep(nchunks, nullptr), ev_done(nchunks, nullptr), ev_fork(nchunks, nullptr), ev_join(nchunks, nullptr);
-  hipEvent_t ev_start = nullptr;
-  auto cleanup = [&]() {
-    for (auto* v : {&ev_prep, &ev_done, &ev_fork, &ev_join})
-      for (auto e : *v)
-        if (e) (void)hipEventDestroy(e);
-    if (ev_start) (void)hipEventDestroy(ev_start);
-  };
+  // events come from the context's pool (guarded by ctx->lock, which the caller holds): 4 per chunk + 1, created once
+  std::vector<hipEvent_t>& pool = ctx->proof_events;
+  while (pool.size() < 4 * nchunks + 1) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail(KZG_FAIL_HIP, "event create failed");
+    pool.push_back(e);
+  }
+  hipEvent_t* ev_prep = pool.data();
+  hipEvent_t* ev_done = pool.data() + nchunks;
+  hipEvent_t* ev_fork = pool.data() + 2 * nchunks;
+  hipEvent_t* ev_join = pool.data() + 3 * nchunks;
+  hipEvent_t ev_start = pool[4 * nchunks];
   HIP_TRY(hipMemsetAsync(d_status, 0, n * sizeof(int32_t), st));
-  if (hipEventCreateWithFlags(&ev_start, hipEventDisableTiming) != hipSuccess) return fail(KZG_FAIL_HIP, "event create failed");
   (void)hipEventRecord(ev_start, st);
   (void)hipStreamWaitEvent(side, ev_start, 0);
-  for (uint64_t k = 0; k < nchunks && rc == 0; k++) {
-    if (hipEventCreateWithFlags(&ev_prep[k], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ev_done[k], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ev_fork[k], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ev_join[k], hipEventDisableTiming) != hipSuccess) {
-      rc = fail(KZG_FAIL_HIP, "event create failed");
-      break;
-    }
-  }
   auto prep = [&](uint64_t k) {  // enqueue chunk k's preparation on the side stream
     const int sl = (int)(k & 1);
     const uint64_t base = k * cn;
@@ -140,7 +134,6 @@ static int32_t proof_dev_locked(const kzg_ctx* ctx, const uint8_t* d_blobs, cons
     if (rc == 0 && hipGetLastError() != hipSuccess) rc = fail(KZG_FAIL_HIP, "proof pipeline launch failed");
   }
   if (rc != 0) (void)hipStreamSynchronize(side);
-  cleanup();
   return rc;
 }
 
@@ -158,49 +151,60 @@ extern "C" int32_t kzg_compute_blob_proof_batch_dev(const kzg_ctx* ctx, const vo
   return rc;
 }
 
-// host-buffer wrapper shared by the two proof entry points
+// Host-buffer wrapper shared by the proof entry points.  Device buffers come from the context's pools (stage_lock): the
+// staging arena holds the blobs of one pass (at most 16,384 = 2 GiB; larger batches take several passes), the small inputs
+// and results live in the host-i/o pool -- a steady-state call allocates nothing.  "Copy, then compute": the
+// floor of a pass is copy + preparation + one MSM pass, because every wave of the MSM kernel holds its slot for the whole
+// pass; splitting the batch only moves the first piece's MSM earlier while the last piece still pays all three.
 static int32_t proof_host(const kzg_ctx* ctx, const uint8_t* blobs, const uint8_t* side, size_t side_bytes, bool side_is_commitment, uint64_t n,
                           uint8_t* out48, uint8_t* out_affine96, uint8_t* out_y32, int32_t* status) {
   if (n == 0) return 0;
   HIP_TRY(hipSetDevice(ctx->device));
-  uint8_t *d_blobs = nullptr, *d_side = nullptr, *d_out = nullptr, *d_aff = nullptr, *d_y = nullptr;
-  int32_t* d_status = nullptr;
-  auto cleanup = [&]() {  // every exit path frees every allocation (a failed hipMalloc of the n * 128 KiB buffer is the likely failure)
-    for (void* p : {(void*)d_blobs, (void*)d_side, (void*)d_out, (void*)d_aff, (void*)d_y, (void*)d_status})
-      if (p) (void)hipFree(p);
+  std::lock_guard<std::mutex> stage_guard(ctx->stage_lock);
+  int32_t rc = stage_init(ctx);
+  if (rc) return rc;
+  const uint64_t pass_max = 16384;
+  const uint64_t pn = n < pass_max ? n : pass_max;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    size_t o = off;
+    off = align_up(off + bytes, 256);
+    return o;
   };
-  int32_t rc = 0;
-  do {
-    if (hipMalloc(&d_blobs, n * (size_t)KZG_BYTES_PER_BLOB) != hipSuccess || hipMalloc(&d_side, n * side_bytes) != hipSuccess ||
-        (out48 && hipMalloc(&d_out, n * 48) != hipSuccess) || (out_affine96 && hipMalloc(&d_aff, n * 96) != hipSuccess) ||
-        hipMalloc(&d_y, n * 32) != hipSuccess || hipMalloc(&d_status, n * sizeof(int32_t)) != hipSuccess) {
-      rc = fail(KZG_FAIL_HIP, "host-buffer proof: device allocation failed");
-      break;
-    }
-    if (hipMemcpy(d_blobs, blobs, n * (size_t)KZG_BYTES_PER_BLOB, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(d_side, side, n * side_bytes, hipMemcpyHostToDevice) != hipSuccess) {
+  const size_t o_side = take(pn * side_bytes), o_out = take(pn * 48), o_aff = take(pn * 96), o_y = take(pn * 32), o_st = take(pn * sizeof(int32_t));
+  rc = stage_reserve(ctx, pn * (size_t)KZG_BYTES_PER_BLOB, off);
+  if (rc) return rc;
+  uint8_t* d_blobs = ctx->stage;
+  uint8_t* d_side = ctx->hostio + o_side;
+  uint8_t* d_out = out48 ? ctx->hostio + o_out : nullptr;
+  uint8_t* d_aff = out_affine96 ? ctx->hostio + o_aff : nullptr;
+  uint8_t* d_y = ctx->hostio + o_y;
+  int32_t* d_status = reinterpret_cast<int32_t*>(ctx->hostio + o_st);
+  hipStream_t st = ctx->stage_streams[0];  // an idle non-blocking stream (the null stream would serialise against every blocking stream of the process)
+  for (uint64_t base = 0; base < n && rc == 0; base += pn) {
+    const uint64_t m = (n - base < pn) ? (n - base) : pn;
+    if (hipMemcpyAsync(d_side, side + base * side_bytes, m * side_bytes, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(d_blobs, blobs + base * (size_t)KZG_BYTES_PER_BLOB, m * (size_t)KZG_BYTES_PER_BLOB, hipMemcpyHostToDevice, st) != hipSuccess) {
       rc = fail(KZG_FAIL_HIP, "host-to-device copy failed");
       break;
     }
     {
       std::lock_guard<std::mutex> guard(ctx->lock);
-      hipStream_t st = ctx->copy_stream;  // an idle non-blocking stream (the null stream would serialise against every blocking stream of the process)
       rc = ws_acquire(ctx, st);
       if (rc == 0)
-        rc = proof_dev_locked(ctx, d_blobs, side_is_commitment ? d_side : nullptr, side_is_commitment ? nullptr : d_side, n, d_out, d_aff,
+        rc = proof_dev_locked(ctx, d_blobs, side_is_commitment ? d_side : nullptr, side_is_commitment ? nullptr : d_side, m, d_out, d_aff,
                               out_y32 ? d_y : nullptr, d_status, st);
       if (rc == 0) rc = ws_release(ctx, st);
-      if (rc == 0 && hipStreamSynchronize(st) != hipSuccess) rc = fail(KZG_FAIL_HIP, "stream synchronize failed");
     }
     if (rc) break;
-    if ((out48 && hipMemcpy(out48, d_out, n * 48, hipMemcpyDeviceToHost) != hipSuccess) ||
-        (out_affine96 && hipMemcpy(out_affine96, d_aff, n * 96, hipMemcpyDeviceToHost) != hipSuccess) ||
-        (out_y32 && hipMemcpy(out_y32, d_y, n * 32, hipMemcpyDeviceToHost) != hipSuccess) ||
-        hipMemcpy(status, d_status, n * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess)
+    if ((out48 && hipMemcpyAsync(out48 + base * 48, d_out, m * 48, hipMemcpyDeviceToHost, st) != hipSuccess) ||
+        (out_affine96 && hipMemcpyAsync(out_affine96 + base * 96, d_aff, m * 96, hipMemcpyDeviceToHost, st) != hipSuccess) ||
+        (out_y32 && hipMemcpyAsync(out_y32 + base * 32, d_y, m * 32, hipMemcpyDeviceToHost, st) != hipSuccess) ||
+        hipMemcpyAsync(status + base, d_status, m * sizeof(int32_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)  // the next pass reuses the arena and the pools
       rc = fail(KZG_FAIL_HIP, "device-to-host copy failed");
-  } while (0);
+  }
   if (rc) (void)hipDeviceSynchronize();
-  cleanup();
   return rc;
 }
 

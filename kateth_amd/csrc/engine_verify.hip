@@ -515,7 +515,7 @@ extern "C" int32_t kzg_verify_phase1_dev(const kzg_ctx* ctx, const void* d_blobs
   return 0;
 }
 
-static int32_t stage_init(const kzg_ctx* ctx) {  // caller holds stage_lock
+int32_t stage_init(const kzg_ctx* ctx) {  // caller holds stage_lock
   if (ctx->stage_ready) return 0;
   bool ok = hipStreamCreateWithFlags(&ctx->verify_stream, hipStreamNonBlocking) == hipSuccess &&
             hipStreamCreateWithFlags(&ctx->stage_copy_stream, hipStreamNonBlocking) == hipSuccess;
@@ -532,10 +532,38 @@ static int32_t stage_init(const kzg_ctx* ctx) {  // caller holds stage_lock
   ctx->stage_ready = true;
   return 0;
 }
+// the arena and the small-result pool only grow; a call that needs more than any before re-allocates (caller holds stage_lock)
+int32_t stage_reserve(const kzg_ctx* ctx, size_t arena_bytes, size_t io_bytes) {
+  if (ctx->stage_bytes < arena_bytes) {
+    if (ctx->stage) {
+      HIP_TRY(hipDeviceSynchronize());
+      (void)hipFree(ctx->stage);
+    }
+    ctx->stage = nullptr;
+    ctx->stage_bytes = 0;
+    if (hipMalloc(&ctx->stage, arena_bytes) != hipSuccess) return fail(KZG_FAIL_HIP, "hipMalloc(staging arena) failed");
+    ctx->stage_bytes = arena_bytes;
+  }
+  if (ctx->hostio_bytes < io_bytes) {
+    if (ctx->hostio) {
+      HIP_TRY(hipDeviceSynchronize());
+      (void)hipFree(ctx->hostio);
+    }
+    ctx->hostio = nullptr;
+    ctx->hostio_bytes = 0;
+    const size_t want = io_bytes + io_bytes / 4;
+    if (hipMalloc(&ctx->hostio, want) != hipSuccess) return fail(KZG_FAIL_HIP, "hipMalloc(host i/o pool) failed");
+    ctx->hostio_bytes = want;
+  }
+  return 0;
+}
 void stage_destroy(const kzg_ctx* ctx) {
   if (ctx->stage) (void)hipFree(ctx->stage);
   ctx->stage = nullptr;
   ctx->stage_bytes = 0;
+  if (ctx->hostio) (void)hipFree(ctx->hostio);
+  ctx->hostio = nullptr;
+  ctx->hostio_bytes = 0;
   if (ctx->verify_stream) (void)hipStreamDestroy(ctx->verify_stream);
   if (ctx->stage_copy_stream) (void)hipStreamDestroy(ctx->stage_copy_stream);
   ctx->verify_stream = ctx->stage_copy_stream = nullptr;
@@ -583,16 +611,8 @@ static int32_t verify_phase1_host(const kzg_ctx* ctx, const uint8_t* blobs, cons
   const uint64_t slots = nchunks < KZG_STAGE_SLOTS ? nchunks : KZG_STAGE_SLOTS;
   const size_t slot_bytes = (size_t)chunk * KZG_BYTES_PER_BLOB;
   do {
-    if (ctx->stage_bytes < slots * slot_bytes) {
-      if (ctx->stage) (void)hipFree(ctx->stage);
-      ctx->stage = nullptr;
-      ctx->stage_bytes = 0;
-      if (hipMalloc(&ctx->stage, slots * slot_bytes) != hipSuccess) {
-        rc = fail(KZG_FAIL_HIP, "hipMalloc(staging arena) failed");
-        break;
-      }
-      ctx->stage_bytes = slots * slot_bytes;
-    }
+    rc = stage_reserve(ctx, slots * slot_bytes, 0);
+    if (rc) break;
     uint8_t* prf = s->pts48;
     uint8_t* com = s->pts48 + n * 48;
     if (hipMemcpyAsync(prf, proofs48, n * 48, hipMemcpyHostToDevice, st) != hipSuccess ||

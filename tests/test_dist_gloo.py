@@ -106,3 +106,34 @@ def test_world2_gloo(bad_rank):
     else:
         for _, _, res in outs:  # every rank raises the same reference-shaped error
             assert res[0] == "err" and res[1] == "KzgError" and "InvalidEncoding" in res[2]
+
+
+def _bench(*argv):
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + list(argv), capture_output=True, text=True, timeout=120, env=env)
+
+
+def test_bench_dry_run_prints_every_ranks_memory_plan():
+    """`bench.py --dry-run` (no GPU, no torch): BASELINE configs[4] = 2^20 blobs over 8 GPUs is 131,072 blobs = 16 GiB per
+    rank beside the 192-GiB table and fits a 288-GB part; a batch that cannot fit fails BEFORE any allocation"""
+    import json
+
+    out = _bench("--dry-run", "--workload", "commit", "--batch", "131072", "--gpus", "8")
+    assert out.returncode == 0, out.stderr
+    rec = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rec["blobs_total"] == 1 << 20 and len(rec["ranks"]) == 8
+    assert [r["first_blob"] for r in rec["ranks"]] == [131072 * k for k in range(8)]
+    r0 = rec["ranks"][0]
+    assert r0["fits"] and (r0["table_class"], r0["plane_groups"]) == (22, 8)
+    assert r0["blobs"] == 16 << 30 and r0["table"] >= 192 * (1 << 30) and 2 << 30 <= r0["workspace"] < 3 << 30
+    assert r0["resident_total"] <= r0["hbm_total"] - (2 << 30)
+    assert rec["exchange_bytes_per_step_per_rank"] == 131072 * 48
+    # a part with 160 GiB of HBM steps down to 4 plane groups; a batch that cannot fit is refused with exit code 3
+    small = json.loads(_bench("--dry-run", "--workload", "commit", "--batch", "4096", "--assume-hbm-gib", "160").stdout.strip().splitlines()[-1])
+    assert (small["ranks"][0]["table_class"], small["ranks"][0]["plane_groups"]) == (22, 4)
+    bad = _bench("--dry-run", "--workload", "commit", "--batch", "700000", "--gpus", "8")
+    assert bad.returncode == 3 and "does not fit" in bad.stderr

@@ -1236,11 +1236,17 @@ def test_bench_rank_launcher_two_real_engine_ranks_on_one_card(workload):
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import tempfile
+
+    logdir = tempfile.mkdtemp(prefix="bench_ranks_")
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--workload", workload, "--batch", "96", "--window-bits", "8",
-           "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extra"]
+           "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extra", "--rank-logs", logdir]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    # every rank's stdout and stderr are kept (rank 0's stdout is also what was relayed)
+    assert sorted(os.listdir(logdir)) == ["rank0.err", "rank0.out", "rank1.err", "rank1.out"]
+    assert open(os.path.join(logdir, "rank0.out")).read() == out.stdout
     rec = json.loads(out.stdout.strip().splitlines()[-1])
     assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0
     assert rec["config"]["blobs_per_gpu"] == 96 and rec["config"]["backend"] == "gloo"
@@ -1249,6 +1255,32 @@ def test_bench_rank_launcher_two_real_engine_ranks_on_one_card(workload):
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], capture_output=True, text=True, timeout=120,
                          env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
     assert bad.returncode != 0 and "WORLD_SIZE=2" in (bad.stdout + bad.stderr)
+    # two ranks on ONE card over the nccl backend must be refused before any collective hangs (RCCL needs a GPU per rank)
+    if workload == "commit":
+        dup = subprocess.run([c if c != "gloo" else "nccl" for c in cmd], capture_output=True, text=True, timeout=300, env=env)
+        assert dup.returncode != 0
+        errs = "".join(open(os.path.join(logdir, f)).read() for f in ("rank0.err", "rank1.err")) + dup.stderr
+        assert "GPUs visible" in errs or "share a GPU" in errs
+
+
+def test_bench_launcher_single_rank_matches_the_direct_run():
+    """`bench.py --gpus 1 --spawn` goes through the launcher (child process, per-rank logs, relayed JSON line); its number must
+    be the direct run's within noise -- the launcher adds nothing to the timed region"""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--batch", "1024", "--window-bits", "8", "--steps", "8", "--warmup", "2",
+            "--no-cpu-baseline", "--no-extra"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    vals = {}
+    for name, extra in (("direct", []), ("spawn", ["--spawn"])):
+        out = subprocess.run(base + extra, capture_output=True, text=True, timeout=600, env=env)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+        rec = json.loads(out.stdout.strip().splitlines()[-1])
+        assert rec["n_gpus"] == 1 and rec["config"]["blobs_per_gpu"] == 1024
+        vals[name] = rec["value"]
+    assert abs(vals["spawn"] / vals["direct"] - 1.0) < 0.10, vals
 
 
 def test_latency_comb_of_the_class_22_table(engine, torch_cuda, monkeypatch):
@@ -1302,11 +1334,12 @@ def test_latency_comb_of_the_class_22_table(engine, torch_cuda, monkeypatch):
 
 
 def test_half_wave_mode_on_an_odd_batch(engine, torch_cuda):
-    """from 4,096 blobs on, the comb MSM carries two blobs per wave (32 lanes each); an odd batch leaves the last wave half
-    empty.  Commitments and proofs of 4,099 blobs equal, item for item, those of the same blobs computed in small batches
-    (one blob per wave / several waves per blob)."""
+    """when two blobs per wave (32 lanes each) is the cheaper launch shape -- 4,095 blobs = 2,048 waves = one round -- an odd
+    batch leaves the last wave half empty.  Commitments and proofs of 4,095 blobs equal, item for item, those of the same blobs
+    computed in small batches (one blob per wave / several waves per blob), among them 2,050 blobs, which run as four split
+    units per blob: five short rounds instead of a second long round for two waves (engine.hip, msm_shape)."""
     torch = torch_cuda
-    n = 4099
+    n = 4095
     d_blobs = torch.empty(n * 131072, dtype=torch.uint8, device="cuda")
     engine.synth_blobs_dev(0x0DD, 0, n, d_blobs.data_ptr())
     d_c = torch.empty(n * 48, dtype=torch.uint8, device="cuda")
@@ -1317,7 +1350,7 @@ def test_half_wave_mode_on_an_odd_batch(engine, torch_cuda):
     torch.cuda.synchronize()
     assert int(d_st.abs().sum()) == 0
     big_c, big_p = d_c.cpu().numpy().tobytes(), d_p.cpu().numpy().tobytes()
-    for first, m in ((0, 3), (2047, 130), (4090, 9)):
+    for first, m in ((0, 3), (2047, 130), (4086, 9), (0, 2050)):  # 2,050 blobs: four split units per blob (five short rounds)
         c2 = torch.empty(m * 48, dtype=torch.uint8, device="cuda")
         p2 = torch.empty(m * 48, dtype=torch.uint8, device="cuda")
         engine.blob_to_commitment_batch_dev(d_blobs.data_ptr() + first * 131072, m, c2.data_ptr(), d_st.data_ptr())
