@@ -65,6 +65,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary proof/verify workloads")
     ap.add_argument("--cpu-sample", type=int, default=0, help="blobs in the CPU baseline sample (0 = auto, ~10-30 s)")
+    ap.add_argument("--no-live-traffic", action="store_true", help="do not run the two rocprofv3 --pmc child passes (FETCH_SIZE, WRITE_SIZE) that measure roofline.traffic in this run")
     ap.add_argument("--spawn", action="store_true", help="start the rank processes through this script's launcher even for --gpus 1 (checks the launcher against the direct path)")
     ap.add_argument("--rank-logs", default=os.path.join(ROOT, "gpurun_out", "bench_ranks"), help="launcher: directory for every rank's stdout/stderr (rank<k>.out / rank<k>.err)")
     ap.add_argument("--dry-run", action="store_true", help="print every rank's HBM plan for --workload/--batch/--gpus as one JSON line and exit non-zero if it cannot fit; touches no GPU")
@@ -228,11 +229,10 @@ def cpu_baseline(sample_blobs, setup_path, gpu_out48):
 
 
 def pmc_traffic(workload, n, window_bits):
-    """HBM bytes per launch of the workload's dominant kernel from the committed rocprofv3 PMC passes (separate --pmc
-    FETCH_SIZE / WRITE_SIZE runs of this same command, corrected as MI355X_MICROARCH.md prescribes; see the note in the
-    file).  bench.py cannot run the profiler on itself, so this is the profiled value for the same (workload, batch,
-    window) configuration, or null when none has been recorded."""
-    for rel in (("profiles", "r02", "pmc_traffic.json"), ("profiles", "r01", "pmc_traffic.json")):
+    """HBM bytes per launch of the workload's dominant kernel from the COMMITTED rocprofv3 PMC passes (profiles/r0N/
+    pmc_traffic.json): the fallback when the live passes (live_pmc_traffic) are switched off or fail.  None when no profile of
+    this (workload, batch, class) configuration has been recorded."""
+    for rel in (("profiles", "r03", "pmc_traffic.json"), ("profiles", "r02", "pmc_traffic.json"), ("profiles", "r01", "pmc_traffic.json")):
         try:
             rec = json.load(open(os.path.join(ROOT, *rel)))
         except (OSError, ValueError):
@@ -243,9 +243,63 @@ def pmc_traffic(workload, n, window_bits):
     return None
 
 
-def roofline_object(workload, n, prof, window_bits):
-    """`roofline` for one workload from the library's HIP-event kernel times: achieved = algorithmic bytes per launch
-    (SURVEY.md section 8(d) bytes per blob x blobs per launch) / the dominant kernel's average launch duration."""
+PMC_KERNEL = {"commit": "k_msm_comb28", "proof": "k_msm_comb28", "verify": "k_challenge"}
+
+
+def live_pmc_traffic(args, workload, n, timeout_s=200):
+    """roofline.traffic measured IN THIS RUN: two child processes `rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py ...`
+    (separate passes, counters only, no tracing -- MI355X_MICROARCH.md, HBM section) of the same workload, batch and table class,
+    started after this process has released its context (two 192-GiB tables do not fit one card).  Per launch of the dominant
+    kernel: FETCH_SIZE (KiB) x 1024 x c + WRITE_SIZE (KiB) x 1024 with the guide's gfx950 correction c = 2 for wide coalesced
+    streaming reads (k_challenge: every lane streams its blob) and c = 1 for k_msm_comb28, whose reads are 96-byte gathers of
+    table entries (the count matches the known gather bytes at c = 1, profiles/r02/pmc_traffic.json).  Returns a dict or None."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [prof, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__), "--workload", workload,
+                   "--batch", str(n), "--window-bits", str(args.window_bits), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extra", "--no-live-traffic"]
+            res = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            if res.returncode != 0:
+                return {"error": "rocprofv3 --pmc %s exited %d: %s" % (counter, res.returncode, (res.stderr or res.stdout)[-300:])}
+            vals = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if PMC_KERNEL[workload] in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                        vals.append(float(row["Counter_Value"]))
+            if not vals:
+                return {"error": "no %s rows for %s" % (counter, PMC_KERNEL[workload])}
+            out[counter] = {"kib_per_launch": sum(vals) / len(vals), "launches": len(vals)}
+    except (subprocess.TimeoutExpired, OSError) as err:
+        return {"error": repr(err)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    corr = 2.0 if workload == "verify" else 1.0
+    fetch = out["FETCH_SIZE"]["kib_per_launch"] * 1024.0 * corr
+    write = out["WRITE_SIZE"]["kib_per_launch"] * 1024.0
+    return {"hbm_bytes_per_launch": fetch + write, "fetch_bytes": fetch, "write_bytes": write, "fetch_correction": corr, "kernel": PMC_KERNEL[workload],
+            "launches_sampled": out["FETCH_SIZE"]["launches"], "how": "two rocprofv3 --pmc child passes of this bench.py run (FETCH_SIZE, WRITE_SIZE; KiB per dispatch)"}
+
+
+def roofline_object(workload, n, prof, window_bits, call_ms=None):
+    """`roofline` for one workload from the library's HIP-event kernel times (events recorded on the stream each kernel is
+    launched on).  commit / proof: the dominant kernel is the fixed-base MSM; achieved = algorithmic bytes per launch (SURVEY.md
+    section 8(d) bytes per blob x blobs per launch) / its average launch duration.  verify: several kernels share the call (the
+    SHA-256 challenge alone on the chip, then point decoding and evaluation side by side on two streams, then the lincombs), so
+    `frac` is the CALL-level figure -- algorithmic bytes of the batch / wall time of the call, host pairing included -- and the
+    stand-alone SHA-256 kernel's own figure is reported beside it (`dominant_kernel_*`)."""
     kinds = {k: v for k, v in prof["kinds"].items() if v[1]}
     if not kinds:
         return None
@@ -261,14 +315,16 @@ def roofline_object(workload, n, prof, window_bits):
     alg = ALG_BYTES[workload] * blobs_per_launch
     ach = alg / (k_ms * 1e-3) / 1e9
     summed = sum(v[0] for v in kinds.values())
-    return {
+    roof = {
         "kernel": dominant,
         "bound": "hbm",
+        "limiter": "valu-issue (integer v_mad_u64_u32 / SHA-256 bit ops), not HBM: see valu_frac and DESIGN.md section 5",
         "achieved": ach,
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
         "frac": ach / HBM_PEAK_GBS,
         "traffic": pmc_traffic(workload, n, window_bits),
+        "traffic_source": "committed rocprofv3 --pmc profile of this configuration (profiles/)",
         "kernel_ms": k_ms,
         "launches": launches,
         "blobs_per_launch": blobs_per_launch,
@@ -276,9 +332,14 @@ def roofline_object(workload, n, prof, window_bits):
         "kernel_ms_by_class_per_call": {k: v[0] / calls for k, v in kinds.items()},
         "summed_kernel_ms_per_call": summed / calls,
         "achieved_over_summed_kernels": ALG_BYTES[workload] * n / (summed / calls * 1e-3) / 1e9,
-        "note": "integer-ALU bound, not HBM bound (DESIGN.md section 5): frac is the algorithmic HBM rate the north star asks for"
+        "note": "frac is the algorithmic HBM rate the north star asks for; the kernels are integer-ALU bound (DESIGN.md section 5)"
         + ("; k_g1_decompress and k_eval_frac overlap on two streams (their spans are not additive)" if workload == "verify" else ""),
     }
+    if workload == "verify" and call_ms:
+        call_ach = ALG_BYTES[workload] * n / (call_ms * 1e-3) / 1e9
+        roof.update({"dominant_kernel_achieved": ach, "dominant_kernel_frac": ach / HBM_PEAK_GBS, "achieved": call_ach, "frac": call_ach / HBM_PEAK_GBS,
+                     "call_ms": call_ms, "scope": "whole verify_blob_kzg_proof_batch call (all kernels + host pairing); dominant_kernel_* is k_challenge alone"})
+    return roof
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -460,7 +521,7 @@ def extra_workloads(R, d_blobs, d_com, n):
     dt, prof = R.measure(lambda: R.verify(vb, vc, vp, nv, 0, nv), 3)
     rec = {"workload": "batch=%d distinct (blob, commitment, proof) triples resident in HBM, includes the host pairing (BASELINE configs[3])" % nv,
            "blobs_per_s": nv / dt, "ms_per_batch": 1e3 * dt, "result": bool(ok), "algorithmic_GBps": nv * ALG_BYTES["verify"] / dt / 1e9,
-           "hbm_frac_of_8TBps": nv * ALG_BYTES["verify"] / dt / 8e12, "roofline": roofline_object("verify", nv, prof, setup.window_bits)}
+           "hbm_frac_of_8TBps": nv * ALG_BYTES["verify"] / dt / 8e12, "roofline": roofline_object("verify", nv, prof, setup.window_bits, call_ms=1e3 * dt)}
     rec["cpu_baseline"] = verify_cpu_baseline(R, vb, vc, vp, nv)
     # a corrupted proof must flip the result
     saved = vp[48 * 40000:48 * 40001].clone()
@@ -557,7 +618,7 @@ def run_rank(args, rank, local_rank, world):
         },
     }
     if rank == 0:
-        roof = roofline_object(wl, n, prof, setup.window_bits)
+        roof = roofline_object(wl, n, prof, setup.window_bits, call_ms=1e3 * elapsed / args.steps)
         if wl in ("commit", "proof") and roof and prof["msm_launches"]:
             roof["kernel"] = setup.msm_kernel_name
             # measured integer-ALU ceiling: dependent Fp Montgomery multiplies with the multiply of the MSM kernel
@@ -591,6 +652,23 @@ def run_rank(args, rank, local_rank, world):
                         result["cpu_baseline"]["note"] = "commitment path of the C port (the proof's second MSM has the same cost); no separate proof port is timed"
             except Exception as err:  # the baseline is reporting only; never hide the GPU number
                 result["cpu_baseline"] = {"value": None, "error": repr(err)}
+        live_wanted = world == 1 and not args.no_live_traffic and roof is not None
+        if live_wanted:  # the PMC child passes need the card: release this process's 192-GiB context and caches first
+            del d_blobs, d_out, d_status
+            if wl != "commit":
+                del d_com
+            if wl == "verify":
+                del d_prf
+            setup.close()
+            torch.cuda.empty_cache()
+            live = live_pmc_traffic(args, wl, n)
+            if live and "hbm_bytes_per_launch" in live:
+                roof["traffic"] = live["hbm_bytes_per_launch"]
+                roof["traffic_source"] = "live: " + live["how"]
+                roof["traffic_detail"] = live
+                roof["traffic_over_algorithmic"] = live["hbm_bytes_per_launch"] / (ALG_BYTES[wl] * roof["blobs_per_launch"])
+            elif live:
+                roof["traffic_live_error"] = live.get("error")
         print(json.dumps(result), flush=True)
     setup.close()
     if world > 1:

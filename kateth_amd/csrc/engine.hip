@@ -97,7 +97,7 @@ static MsmShapeCost msm_shape(const kzg_ctx* ctx, uint64_t n) {
 
 uint32_t choose_splits(const kzg_ctx* ctx, uint64_t n) {
   if (ctx->use_comb) {
-    if (ctx->d_table_lat && n <= KZG_LAT_MAX_BLOBS && !ctx->knobs.msm_splits) return KZG_LAT_SPLITS;  // the latency comb: 8 blocks x 4 planes per lane
+    if (ctx->d_table_lat && n <= KZG_LAT_MAX_BLOBS && !ctx->knobs.msm_splits) return lat_splits(n);  // the latency comb: 2 to 8 blocks x 4 planes per lane
     const uint32_t per_lane = (64u * ctx->comb.nb) / ctx->comb.lpg;
     if (ctx->knobs.msm_splits && ctx->knobs.msm_splits <= 64 && per_lane % ctx->knobs.msm_splits == 0) return ctx->knobs.msm_splits;
     return msm_shape(ctx, n).splits;

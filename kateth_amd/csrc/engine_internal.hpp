@@ -209,8 +209,11 @@ static inline void launch_challenge_and_decode(const kzg_ctx* ctx, hipStream_t s
 // blobs per launch on, when that fills whole rounds), a blob takes 32 lanes (each lane owns twice the blocks for the same
 // number of Horner doublings).  Units = waves of the MSM kernel = rows of 64 lane sums.
 constexpr uint64_t KZG_LAT_MAX_BLOBS = 16;
-constexpr uint32_t KZG_LAT_SPLITS = 64;  // the main class-22 comb never splits 64 ways (24 blocks per lane), so the split count names the table
-static inline bool msm_uses_lat(const kzg_ctx* ctx, uint32_t splits) { return ctx->d_table_lat != nullptr && splits == KZG_LAT_SPLITS; }
+// Units per blob on the latency comb (512 blocks x 4 planes per blob): 256 for up to 4 blobs (a lane chains 8 additions + 3
+// doublings, and 1,024 waves are one per SIMD), 128 up to 8, 64 up to 16.  The main class-22 comb never splits more than 24
+// ways (24 blocks per lane), so a split count >= 64 names the table.
+static inline uint32_t lat_splits(uint64_t n) { return n <= 4 ? 256u : (n <= 8 ? 128u : 64u); }
+static inline bool msm_uses_lat(const kzg_ctx* ctx, uint32_t splits) { return ctx->d_table_lat != nullptr && splits >= 64u; }
 uint32_t msm_lanes_per_blob(const kzg_ctx* ctx, uint64_t n, uint32_t splits);  // engine.hip (msm_shape)
 static inline uint64_t msm_units(uint64_t n, uint32_t splits, uint32_t lpb) { return lpb == 64 ? n * splits : (n + 1) / 2; }
 
@@ -252,9 +255,17 @@ static inline int32_t msm_finish(const kzg_ctx* ctx, uint64_t n, uint8_t* d_out4
   ProfScope ps(ctx, PROF_REDUCE_COMPRESS, st);
   g1_xyzz* unit_sums = (splits == 1) ? sums : partials + (size_t)n * splits * 64;
   const uint64_t units = msm_units(n, splits, lpb);
+  const uint4* comb_k = ctx->use_comb ? ctx->d_comb_k : (const uint4*)nullptr;
   hipLaunchKernelGGL(k_msm_reduce, dim3((unsigned)units), dim3(64), 0, st, partials, units, lpb, unit_sums, lpb == 64 ? units : n);
-  if (splits > 1) hipLaunchKernelGGL(k_msm_reduce_splits, dim3((unsigned)n), dim3(64), 0, st, unit_sums, splits, n, sums);
-  hipLaunchKernelGGL(k_g1_compress, dim3(blocks_for(n, 64)), dim3(64), 0, st, sums, n, d_status, d_out48, d_out_affine96, ctx->use_comb ? ctx->d_comb_k : (const uint4*)nullptr);
+  if (splits > 64) {  // latency shape (a few blobs over up to 256 units each): tree + constant term + encoding in one launch
+    hipLaunchKernelGGL((k_msm_reduce_splits<256, true>), dim3((unsigned)n), dim3(256), 0, st, unit_sums, splits, n, sums, d_status, d_out48, d_out_affine96, comb_k);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
+  if (splits > 1)
+    hipLaunchKernelGGL((k_msm_reduce_splits<64, false>), dim3((unsigned)n), dim3(64), 0, st, unit_sums, splits, n, sums, (const int32_t*)nullptr,
+                       (uint8_t*)nullptr, (uint8_t*)nullptr, (const uint4*)nullptr);
+  hipLaunchKernelGGL(k_g1_compress, dim3(blocks_for(n, 64)), dim3(64), 0, st, sums, n, d_status, d_out48, d_out_affine96, comb_k);
   HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -103,36 +103,19 @@ static __global__ __launch_bounds__(64) void k_msm_reduce(const g1_xyzz* __restr
     unit_sums[slot] = out;
   }
 }
-// One wave per blob: sums the blob's `splits` (<= 64) unit sums.
-static __global__ __launch_bounds__(64) void k_msm_reduce_splits(const g1_xyzz* __restrict__ unit_sums, uint32_t splits, uint64_t n,
-                                                                 g1_xyzz* __restrict__ sums) {
-  __shared__ g1_xyzz lds[32];
-  const int lane = threadIdx.x;
-  const uint64_t b = blockIdx.x;
-  if (b >= n) return;
-  g1_xyzz acc;
-  xyzz_set_inf(acc);
-  if ((uint32_t)lane < splits) acc = unit_sums[b * splits + lane];
-  wave_reduce_xyzz(acc, lds, lane);
-  if (lane == 0) sums[b] = acc;
-}
-
-// One thread per item: XYZZ -> affine -> 48-byte compressed encoding
-// (K3: blst_p1_compress, src/bls.rs:499) and/or the 96-byte blst_p1_affine image (so that a caller that wants the
-// reference's `P1` back -- Commitment = Proof = P1, src/kzg/mod.rs:9-10 -- needs no square root).  Items whose status
-// is non-zero get zero bytes.  Either output pointer may be null.
-// `comb_k` (nullable): the comb MSM's constant term K (affine, 2^384-Montgomery), added to every sum first (msm_comb.cuh).
-static __global__ __launch_bounds__(64) void k_g1_compress(const g1_xyzz* __restrict__ sums, uint64_t n, const int32_t* __restrict__ status,
-                                                    uint8_t* __restrict__ out48, uint8_t* __restrict__ out_affine96, const uint4* __restrict__ comb_k) {
-  const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= n) return;
+// XYZZ sum of one blob -> affine -> 48-byte compressed encoding (K3: blst_p1_compress, src/bls.rs:499) and/or the 96-byte
+// blst_p1_affine image (so that a caller that wants the reference's `P1` back -- Commitment = Proof = P1,
+// src/kzg/mod.rs:9-10 -- needs no square root).  An item whose status is non-zero gets zero bytes.  Either output pointer may
+// be null.  `comb_k` (nullable): the comb MSM's constant term K (affine, 2^384-Montgomery), added to the sum first (msm_comb.cuh).
+__device__ __noinline__ void g1_finish_item(const g1_xyzz& sum, uint64_t b, const int32_t* __restrict__ status, uint8_t* __restrict__ out48,
+                                            uint8_t* __restrict__ out_affine96, const uint4* __restrict__ comb_k) {
   uint8_t tmp[48];
   uint32_t aff[24];
   if (status != nullptr && status[b] != 0) {
     for (int q = 0; q < 48; q++) tmp[q] = 0;
     for (int q = 0; q < 24; q++) aff[q] = 0;
   } else {
-    g1_xyzz acc = sums[b];
+    g1_xyzz acc = sum;
     if (comb_k != nullptr) {
       fp_t kx, ky;
       load_affine96(kx, ky, comb_k, 0);
@@ -151,6 +134,56 @@ static __global__ __launch_bounds__(64) void k_g1_compress(const g1_xyzz* __rest
     uint32_t* o = reinterpret_cast<uint32_t*>(out_affine96 + b * 96);
     for (int q = 0; q < 24; q++) o[q] = aff[q];
   }
+}
+
+// One workgroup of BS threads per blob: sums the blob's `splits` (<= BS) unit sums by a tree through LDS in the radix-2^28
+// field.  FINISH: thread 0 then adds the comb's constant term and encodes the point itself (the latency shape: a single blob
+// is spread over up to 256 units, and a separate one-thread k_g1_compress launch would cost a launch and a cold start);
+// otherwise sums[b] is written for k_g1_compress.
+template <int BS, bool FINISH>
+static __global__ __launch_bounds__(BS) void k_msm_reduce_splits(const g1_xyzz* __restrict__ unit_sums, uint32_t splits, uint64_t n, g1_xyzz* __restrict__ sums,
+                                                                 const int32_t* __restrict__ status, uint8_t* __restrict__ out48,
+                                                                 uint8_t* __restrict__ out_affine96, const uint4* __restrict__ comb_k) {
+  __shared__ g1_xyzz28 lds[BS / 2];
+  const int t = threadIdx.x;
+  const uint64_t b = blockIdx.x;
+  if (b >= n) return;
+  g1_xyzz28 acc;
+  xyzz28_set_inf(acc);
+  if ((uint32_t)t < splits) {
+    const g1_xyzz in = unit_sums[b * splits + t];
+    xyzz28_from_xyzz(acc, in);
+  }
+#pragma unroll 1
+  for (int step = 1; step < BS && (uint32_t)step < splits; step <<= 1) {
+    const int m = 2 * step - 1;
+    if ((t & m) == step) lds[t >> 1] = acc;
+    __syncthreads();
+    if ((t & m) == 0) {
+      g1_xyzz28 other = lds[(t + step) >> 1];
+      g1_xyzz28 mine = acc;  // copies: the out-of-line adder takes addresses
+      xyzz28_add_complete(mine, other);
+      acc = mine;
+    }
+    __syncthreads();
+  }
+  if (t == 0) {
+    g1_xyzz out;
+    xyzz28_to_xyzz(out, acc);
+    if (FINISH)
+      g1_finish_item(out, b, status, out48, out_affine96, comb_k);
+    else
+      sums[b] = out;
+  }
+}
+
+// One thread per item: g1_finish_item over n sums.
+static __global__ __launch_bounds__(64) void k_g1_compress(const g1_xyzz* __restrict__ sums, uint64_t n, const int32_t* __restrict__ status,
+                                                    uint8_t* __restrict__ out48, uint8_t* __restrict__ out_affine96, const uint4* __restrict__ comb_k) {
+  const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n) return;
+  const g1_xyzz acc = sums[b];
+  g1_finish_item(acc, b, status, out48, out_affine96, comb_k);
 }
 
 #endif  // __HIPCC__
