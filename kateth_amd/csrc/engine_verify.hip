@@ -420,7 +420,7 @@ static int32_t phase1_items(kzg_verify_session* s, const uint8_t* blobs, const u
     const uint64_t hash_waves = hash_wgs <= ctx->num_cus ? 3 * hash_wgs : (m <= split_max ? 2 * hash_wgs : hash_wgs);
     const uint64_t simds = (uint64_t)ctx->num_cus * 4;
     uint64_t beside = 0;  // points decoded beside the hash
-    if (decode_here && !ctx->knobs.verify_serial && !ctx->knobs.challenge_split_max && hash_waves + 64 <= simds)
+    if (decode_here && !ctx->knobs.verify_serial && !ctx->knobs.challenge_split_max && (hash_waves + 64 <= simds || (ctx->knobs.verify_cohash && m > split_max)))
       beside = 2 * n;  // all of them: what does not fit beside the hash is at least queued AHEAD of the evaluation kernel's waves
                        // (measured, ms per call at 24,000 / 28,000 / 30,000 / 32,768 triples: only what fits 10.5 / 11.4 / 11.9 / 10.9,
                        // everything 9.0 / 10.0 / 10.6 / 11.6 -- so not when the hash fills the chip)
