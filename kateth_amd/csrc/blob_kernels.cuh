@@ -2,7 +2,6 @@
 // challenge (K4), barycentric evaluation (K5), quotient polynomial (K6),
 // point decompression (K7).  See each kernel for the reference lines it replaces.
 #pragma once
-#include "issue_fair.cuh"
 #include "g1_decode28.cuh"
 #include "sha256.cuh"
 
@@ -188,75 +187,6 @@ static __global__ __launch_bounds__(64) void k_challenge(const uint8_t* __restri
   load_be_words16(w + 12, com + 16);
   sha256_block(s, w);
   // block 2049: last 16 commitment bytes, padding, bit length of 131152 bytes
-  load_be_words16(w, com + 32);
-  w[4] = 0x80000000u;
-#pragma unroll
-  for (int q = 5; q < 15; q++) w[q] = 0;
-  w[15] = 131152u * 8u;
-  sha256_block(s, w);
-  fr_t v;
-#pragma unroll
-  for (int q = 0; q < 8; q++) v.v[7 - q] = s.h[q];
-  fr_reduce_256(v);
-  z_plain[b] = v;
-}
-
-// The same hash under 256 VGPRs (128-byte chunks: two blocks per step) so that ANOTHER kernel's wave can share its SIMD, with
-// the issue priority traded every 2^fair shader cycles (issue_fair.cuh).  Used only when KATETH_AMD_VERIFY_COHASH asks for
-// point decoding beside the full-chip hash (n > 32,768); measured against the plain kernel in profiles/r03.
-__device__ __forceinline__ void load_be_chunk128(uint32_t* c, const uint8_t* __restrict__ p) {  // 128 B, 16-B aligned
-  const uint4* q = reinterpret_cast<const uint4*>(p);
-#pragma unroll
-  for (int k = 0; k < 8; k++) {
-    uint4 v = q[k];
-    c[4 * k] = __builtin_bswap32(v.x);
-    c[4 * k + 1] = __builtin_bswap32(v.y);
-    c[4 * k + 2] = __builtin_bswap32(v.z);
-    c[4 * k + 3] = __builtin_bswap32(v.w);
-  }
-}
-static __global__ __launch_bounds__(64, 2) void k_challenge_shared(const uint8_t* __restrict__ blobs, const uint8_t* __restrict__ commitments48, uint64_t n,
-                                                                   fr_t* __restrict__ z_plain, uint32_t fair) {
-  const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= n) return;
-  const uint8_t* blob = blobs + b * 131072ull;
-  const uint8_t* com = commitments48 + b * 48;
-  sha256_state s;
-  sha256_init(s);
-  uint32_t carry[8];
-  carry[0] = 0x4653424cu;  // "FSBL"
-  carry[1] = 0x4f425645u;  // "OBVE"
-  carry[2] = 0x52494659u;  // "RIFY"
-  carry[3] = 0x5f56315fu;  // "_V1_"
-  carry[4] = 0;
-  carry[5] = 0;
-  carry[6] = 0;
-  carry[7] = 4096;  // u128 big-endian degree
-  uint32_t cur[32], nxt[32];
-  load_be_chunk128(nxt, blob);
-#pragma unroll 1
-  for (uint32_t j = 0; j < 1024; j++) {
-    if (fair) issue_fair_tick(fair);
-#pragma unroll
-    for (int q = 0; q < 32; q++) cur[q] = nxt[q];
-    if (j + 1 < 1024) load_be_chunk128(nxt, blob + 128u * (j + 1));
-    uint32_t w[16];
-#pragma unroll
-    for (int q = 0; q < 8; q++) {
-      w[q] = carry[q];
-      w[8 + q] = cur[q];
-    }
-    sha256_block(s, w);
-    sha256_block(s, cur + 8);
-#pragma unroll
-    for (int q = 0; q < 8; q++) carry[q] = cur[24 + q];
-  }
-  uint32_t w[16];
-#pragma unroll
-  for (int q = 0; q < 8; q++) w[q] = carry[q];
-  load_be_words16(w + 8, com);
-  load_be_words16(w + 12, com + 16);
-  sha256_block(s, w);
   load_be_words16(w, com + 32);
   w[4] = 0x80000000u;
 #pragma unroll

@@ -45,8 +45,6 @@ struct EnvKnobs {
   bool comb_full_wave = false;   // KATETH_AMD_COMB_FULL_WAVE: never use the comb's two-blobs-per-wave mode (measurement aid)
   uint32_t msm_splits = 0;       // KATETH_AMD_MSM_SPLITS: force the (blob, split) decomposition of the fixed-base MSM (power of two <= 64; 0 = automatic)
   uint64_t challenge_split_max = 0;  // KATETH_AMD_CHALLENGE_SPLIT_MAX: largest batch hashed by the two-wave SHA-256 kernel (0 = default)
-  uint32_t verify_cohash = 0;    // KATETH_AMD_VERIFY_COHASH=s (experiment, profiles/r03): beyond 32,768 blobs hash with the <= 256-VGPR kernel and decode the
-                                 // points BESIDE it, the two kernels' waves trading issue priority every 2^s cycles (0 = off: hash alone, then decode || evaluation)
 };
 EnvKnobs read_env_knobs();
 
@@ -177,8 +175,6 @@ static inline void launch_challenge(const kzg_ctx* ctx, hipStream_t st, const ui
     hipLaunchKernelGGL(k_challenge_pair, dim3(blocks_for(n, 64)), dim3(192), 0, st, blobs, commitments48, n, z);  // three waves per 64 blobs, a SIMD each
   else if (n <= split_max)
     hipLaunchKernelGGL(k_challenge_split, dim3(blocks_for(n, 64)), dim3(128), 0, st, blobs, commitments48, n, z);
-  else if (ctx->knobs.verify_cohash)
-    hipLaunchKernelGGL(k_challenge_shared, dim3(blocks_for(n, 64)), dim3(64), 0, st, blobs, commitments48, n, z, ctx->knobs.verify_cohash);
   else
     hipLaunchKernelGGL(k_challenge, dim3(blocks_for(n, 64)), dim3(64), 0, st, blobs, commitments48, n, z);
 }

@@ -413,14 +413,15 @@ static int32_t phase1_items(kzg_verify_session* s, const uint8_t* blobs, const u
     // 5.9 instead of 4.0 ms at 32,768).  The SIMDs they leave free -- a quarter of the chip at 16,384 blobs -- take decode waves,
     // two each: while the hash leaves SIMDs free the decode kernel is released as soon as the hash is enqueued and runs beside
     // it; when the hash fills the chip (from ~30,700 blobs on, and always with the one-lane hash) it waits for the hash and runs
-    // beside the evaluation kernel.
+    // beside the evaluation kernel.  (Decoding beside the full-chip hash with traded issue priority was measured and lost:
+    // 19.2-20.5 instead of 18.1 ms per 65,536 triples, profiles/r03/verify_cohash_traded_priority_rejected.json.)
     const uint64_t hash_wgs = blocks_for(m, 64);
     const uint64_t split_max = ctx->knobs.challenge_split_max ? ctx->knobs.challenge_split_max : (uint64_t)ctx->num_cus * 128;
     // lane-pair kernel (three waves per 64 blobs), producer/consumer pairs (two), one lane per blob (one wave, 292 VGPRs)
     const uint64_t hash_waves = hash_wgs <= ctx->num_cus ? 3 * hash_wgs : (m <= split_max ? 2 * hash_wgs : hash_wgs);
     const uint64_t simds = (uint64_t)ctx->num_cus * 4;
     uint64_t beside = 0;  // points decoded beside the hash
-    if (decode_here && !ctx->knobs.verify_serial && !ctx->knobs.challenge_split_max && (hash_waves + 64 <= simds || (ctx->knobs.verify_cohash && m > split_max)))
+    if (decode_here && !ctx->knobs.verify_serial && !ctx->knobs.challenge_split_max && hash_waves + 64 <= simds)
       beside = 2 * n;  // all of them: what does not fit beside the hash is at least queued AHEAD of the evaluation kernel's waves
                        // (measured, ms per call at 24,000 / 28,000 / 30,000 / 32,768 triples: only what fits 10.5 / 11.4 / 11.9 / 10.9,
                        // everything 9.0 / 10.0 / 10.6 / 11.6 -- so not when the hash fills the chip)

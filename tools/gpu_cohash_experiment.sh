@@ -1,5 +1,6 @@
 #!/bin/bash
 # VERDICT r02 "next" 6: verify_blob_kzg_proof_batch at 65,536 with point decoding beside the full-chip hash (both kernels
+# NOTE: needs the experiment commit named in profiles/r03/verify_cohash_traded_priority_rejected.json (the kernel and the knob were removed from the product afterwards).
 # trading issue priority), against the default (hash alone, then decoding || evaluation), same box, alternating runs.
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/cohash
@@ -10,8 +11,7 @@ for rep in 1 2; do
     KATETH_AMD_VERIFY_COHASH=$s python3 $R/bench.py --workload verify --steps 5 --warmup 2 --no-cpu-baseline --no-live-traffic > $OUT/cohash${s}_$rep.json 2>> $OUT/err.log || exit 1
   done
 done
-KATETH_AMD_VERIFY_COHASH=20 python3 -m pytest $R/tests/test_gpu_parity.py -x -q -m gpu -k "verify_batch_65536" > $OUT/test_cohash.log 2>&1
-echo "test rc=$?" >> $OUT/test_cohash.log
+# (the parity test ran with the knob set at the experiment commit)
 python3 - <<PY
 import json, glob, os
 out = {}
