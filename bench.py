@@ -639,6 +639,13 @@ def run_rank(args, rank, local_rank, world):
         if wl == "commit" and not args.no_extra and world == 1:
             try:
                 result["extra"] = extra_workloads(R, d_blobs, d_out, n)
+                # BASELINE.json's metric names TWO functions: the second one at top level too, with its own roofline fraction
+                v, p = result["extra"]["verify_blob_kzg_proof_batch"], result["extra"]["compute_blob_kzg_proof"]
+                result["secondary_metrics"] = [
+                    {"metric": METRIC["verify"], "value": v["blobs_per_s"], "unit": "blobs/s", "ms_per_step": v["ms_per_batch"], "workload": v["workload"],
+                     "roofline_frac": v["roofline"]["frac"] if v.get("roofline") else None, "result": v["result"]},
+                    {"metric": METRIC["proof"], "value": p["blobs_per_s"], "unit": "blobs/s", "ms_per_step": p["ms_per_batch"], "workload": p["workload"],
+                     "roofline_frac": p["roofline"]["frac"] if p.get("roofline") else None}]
             except Exception as err:  # secondary numbers never hide the headline
                 result["extra"] = {"error": repr(err)}
         if not args.no_cpu_baseline and world == 1:
