@@ -225,6 +225,7 @@ extern "C" void kzg_ctx_destroy(kzg_ctx* ctx) {
   if (ctx->d_eval_tab) (void)hipFree(ctx->d_eval_tab);
   if (ctx->d_gen_affine) (void)hipFree(ctx->d_gen_affine);
   if (ctx->d_comb_k) (void)hipFree(ctx->d_comb_k);
+  if (ctx->d_comb_k_lat) (void)hipFree(ctx->d_comb_k_lat);
   if (ctx->msm_override && ctx->msm_override->destroy) ctx->msm_override->destroy(ctx);
   delete ctx->pairing;
   if (ctx->ws) (void)hipFree(ctx->ws);
@@ -325,28 +326,48 @@ static int32_t comb_build(kzg_ctx* ctx, ScratchAllocs& scratch, TraceTimer& tt) 
     uint32_t h[24], sum_inf = 0;
     HIP_TRY(hipMemcpy(h, d_sum, 96, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(&sum_inf, d_sum_inf, sizeof(uint32_t), hipMemcpyDeviceToHost));
-    if (!sum_inf) {  // S = O: K = O, k_g1_compress adds nothing (d_comb_k stays null)
-      const uint32_t c0[8] = KZG_FR_COMB_C0_PLAIN;
+    if (!sum_inf) {  // S = O: K = O, no lane starts from it (d_comb_k stays null)
       fp_t x, y;
       for (int q = 0; q < 12; q++) {
         x.v[q] = h[q];
         y.v[q] = h[12 + q];
       }
-      g1_xyzz acc;
-      xyzz_set_inf(acc);
-      for (int bit = 255; bit >= 0; bit--) {
-        xyzz_dbl(acc);
-        if ((c0[bit >> 5] >> (bit & 31)) & 1u) xyzz_madd(acc, x, y);
-      }
-      fp_t kx, ky;
-      if (xyzz_to_affine(kx, ky, acc)) {
-        for (int q = 0; q < 12; q++) {
-          h[q] = kx.v[q];
-          h[12 + q] = ky.v[q];
+      // One lane per blob STARTS from the constant term (k_msm_comb28).  That lane doubles its accumulator H - 1 times on
+      // its way down the planes, so it is given [c0 / 2^(H-1)] S: one point per table geometry (main comb, latency comb).
+      auto constant_for = [&](uint32_t H, uint4** d_out) -> int32_t {
+        const uint32_t c0p[8] = KZG_FR_COMB_C0_PLAIN;
+        fr_t c0, two, pw, inv, k;
+        for (int q = 0; q < 8; q++) c0.v[q] = c0p[q];
+        to_mont<FrParams>(c0, c0);
+        two = fr_one();
+        add_mod<FrParams>(two, two, two);
+        pw = fr_one();
+        for (uint32_t i = 0; i + 1 < H; i++) fr_mul(pw, pw, two);  // 2^(H-1)
+        fr_inv(inv, pw);
+        fr_mul(k, c0, inv);
+        from_mont<FrParams>(k, k);  // plain scalar c0 / 2^(H-1) mod r
+        g1_xyzz acc;
+        xyzz_set_inf(acc);
+        for (int bit = 255; bit >= 0; bit--) {
+          xyzz_dbl(acc);
+          if ((k.v[bit >> 5] >> (bit & 31)) & 1u) xyzz_madd(acc, x, y);
         }
-        HIP_TRY(hipMalloc(&ctx->d_comb_k, 96));
-        HIP_TRY(hipMemcpy(ctx->d_comb_k, h, 96, hipMemcpyHostToDevice));
-      }
+        fp_t kx, ky;
+        if (!xyzz_to_affine(kx, ky, acc)) return 0;  // the identity: nothing to start from
+        fp_to_r392(kx, kx);  // the table's format: k_msm_comb28 loads K like an entry
+        fp_to_r392(ky, ky);
+        uint32_t hk[24];
+        for (int q = 0; q < 12; q++) {
+          hk[q] = kx.v[q];
+          hk[12 + q] = ky.v[q];
+        }
+        HIP_TRY(hipMalloc(d_out, 96));
+        HIP_TRY(hipMemcpy(*d_out, hk, 96, hipMemcpyHostToDevice));
+        return 0;
+      };
+      int32_t rck = constant_for(ctx->comb.H, &ctx->d_comb_k);
+      if (rck == 0 && ctx->d_table_lat) rck = constant_for(ctx->comb_lat.H, &ctx->d_comb_k_lat);
+      if (rck) return rck;
     }
   }
   HIP_TRY(hipDeviceSynchronize());
@@ -430,51 +451,16 @@ static int32_t ctx_build(kzg_ctx* ctx, const uint8_t* g1_lagrange, const uint8_t
   return 0;
 }
 
-extern "C" int32_t kzg_ctx_create(const uint8_t* g1_lagrange, const uint8_t* g2_monomial, const kzg_config* cfg, kzg_ctx** out) {
-  if (!g1_lagrange || !g2_monomial || !out) return fail(KZG_FAIL_ARGUMENT, "null argument");
-  *out = nullptr;
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-    return fail(KZG_FAIL_NO_DEVICE, "no HIP device visible: the kateth_amd engine has no CPU fallback");
-  int device = cfg ? cfg->device : 0;
-  if (device < 0 || device >= ndev) return fail(KZG_FAIL_ARGUMENT, "device ordinal out of range");
-  HIP_TRY(hipSetDevice(device));
-  // Table class (index bits per lookup = points per block of the comb).  window_bits = 0 -- what Setup::load_json's drop-in
-  // passes, INTEGRATION.md section 5 -- takes the fastest class the device has room for RIGHT NOW, so that the default
-  // context is the benchmarked one on a 288-GB part:
-  //   class 22 (blocks of 22 + 21 + 21 points, 49,152 additions per blob), G = 8 plane groups = 192 GiB  if >= 232 GiB are free
-  //   class 22, G = 4 = 96 GiB (63 instead of 31 Horner doublings per lane: -2 %)                         if >= 136 GiB
-  //   class 16 (blocks of 16, G = 16, 65,536 additions per blob: -25 %) = 12.9 GB                         if >=  21 GiB
-  //   class 8  (blocks of 8, G = 16) = 100 MB                                                             otherwise
-  // (the margins cover the build's 13 GB of staging, the 0.4-GB latency comb, the call workspace and the caller's blobs).
-  // An explicit window_bits is honoured as given; kzg_ctx_window_bits / kzg_ctx_plane_groups report the choice.
-  constexpr size_t GiB = (size_t)1 << 30;
-  constexpr size_t GROUP22_BYTES = (size_t)64 * ((size_t)1 << 22) * 96;  // one plane group of class 22: 24 GiB
-  size_t free_b = 0, total_b = 0;
-  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
-  uint32_t c = cfg ? (uint32_t)cfg->window_bits : 0u;
-  if (c == 0) c = free_b >= 4 * GROUP22_BYTES + 40 * GiB ? 22u : (free_b >= 21 * GiB ? 16u : 8u);
-  if (c < 4 || c > 22) return fail(KZG_FAIL_ARGUMENT, "window_bits must be 0 (automatic) or in [4,22]");
+// one attempt at a context with table class c (>= 4) and G plane groups
+static int32_t ctx_create_with(const uint8_t* g1_lagrange, const uint8_t* g2_monomial, int device, uint32_t c, uint32_t G, kzg_ctx** out) {
   kzg_ctx* ctx = new (std::nothrow) kzg_ctx();
   if (!ctx) return fail(KZG_FAIL_ARGUMENT, "out of host memory");
   ctx->device = device;
-  {
-    // 22: blocks of 22 + 21 + 21; 16..21: 4 x 16; 8..15: 8 x 8; 4..7: 16 x 4 (the small classes keep test contexts cheap)
-    const uint32_t nb = c >= 22 ? 3u : (c >= 16 ? 4u : (c >= 8 ? 8u : 16u));
-    // plane groups G (one table each, H = 256/G planes and H - 1 accumulator doublings per lane): 16 for the small classes;
-    // for blocks of 22/21 8 groups when the device has the room, else 4
-    uint32_t G = 16;
-    if (nb == 3) G = free_b >= 8 * GROUP22_BYTES + 40 * GiB ? 8u : 4u;
-    if (cfg && cfg->plane_groups) G = (uint32_t)cfg->plane_groups;
-    if (const char* e = getenv("KATETH_AMD_COMB_GROUPS")) G = (uint32_t)atoi(e);
-    if (!(G == 1 || G == 2 || G == 4 || G == 8 || G == 16)) {
-      delete ctx;
-      return fail(KZG_FAIL_ARGUMENT, "plane groups must be 1, 2, 4, 8 or 16");
-    }
-    ctx->comb = comb_make_geom(nb, G);
-    ctx->comb.fair = read_env_knobs().comb_fair;
-    ctx->window_class = nb == 3 ? 22u : 64u / nb;
-  }
+  // 22: blocks of 22 + 21 + 21; 16..21: 4 x 16; 8..15: 8 x 8; 4..7: 16 x 4 (the small classes keep test contexts cheap)
+  const uint32_t nb = c >= 22 ? 3u : (c >= 16 ? 4u : (c >= 8 ? 8u : 16u));
+  ctx->comb = comb_make_geom(nb, G);
+  ctx->comb.fair = read_env_knobs().comb_fair;
+  ctx->window_class = nb == 3 ? 22u : 64u / nb;
   if (hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess) {
     delete ctx;
@@ -495,6 +481,57 @@ extern "C" int32_t kzg_ctx_create(const uint8_t* g1_lagrange, const uint8_t* g2_
   }
   *out = ctx;
   return 0;
+}
+
+extern "C" int32_t kzg_ctx_create(const uint8_t* g1_lagrange, const uint8_t* g2_monomial, const kzg_config* cfg, kzg_ctx** out) {
+  if (!g1_lagrange || !g2_monomial || !out) return fail(KZG_FAIL_ARGUMENT, "null argument");
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(KZG_FAIL_NO_DEVICE, "no HIP device visible: the kateth_amd engine has no CPU fallback");
+  int device = cfg ? cfg->device : 0;
+  if (device < 0 || device >= ndev) return fail(KZG_FAIL_ARGUMENT, "device ordinal out of range");
+  HIP_TRY(hipSetDevice(device));
+  // Table class (index bits per lookup = points per block of the comb).  window_bits = 0 -- what Setup::load_json's drop-in
+  // passes, INTEGRATION.md section 5 -- takes the fastest class the device has room for RIGHT NOW, so that the default
+  // context is the benchmarked one on a 288-GB part:
+  //   class 22 (blocks of 22 + 21 + 21 points, 49,152 additions per blob), G = 8 plane groups = 192 GiB  if >= 232 GiB are free
+  //   class 22, G = 4 = 96 GiB (63 instead of 31 Horner doublings per lane: -2 %)                         if >= 136 GiB
+  //   class 16 (blocks of 16, G = 16, 65,536 additions per blob: -25 %) = 12.9 GB                         if >=  21 GiB
+  //   class 8  (blocks of 8, G = 16) = 100 MB                                                             otherwise
+  // (the margins cover the build's 13 GB of staging, the 0.4-GB latency comb, the call workspace and the caller's blobs).
+  // If the allocation of an automatically chosen table fails all the same (fragmentation, another process), the next
+  // smaller choice is tried.  An explicit window_bits is honoured as given (and fails if it cannot be built);
+  // kzg_ctx_window_bits / kzg_ctx_plane_groups report the choice.
+  constexpr size_t GiB = (size_t)1 << 30;
+  constexpr size_t GROUP22_BYTES = (size_t)64 * ((size_t)1 << 22) * 96;  // one plane group of class 22: 24 GiB
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+  const uint32_t want = cfg ? (uint32_t)cfg->window_bits : 0u;
+  if (want != 0 && (want < 4 || want > 22)) return fail(KZG_FAIL_ARGUMENT, "window_bits must be 0 (automatic) or in [4,22]");
+  uint32_t G_fixed = (cfg && cfg->plane_groups) ? (uint32_t)cfg->plane_groups : 0u;
+  if (const char* e = getenv("KATETH_AMD_COMB_GROUPS")) G_fixed = (uint32_t)atoi(e);
+  if (G_fixed && !(G_fixed == 1 || G_fixed == 2 || G_fixed == 4 || G_fixed == 8 || G_fixed == 16))
+    return fail(KZG_FAIL_ARGUMENT, "plane groups must be 1, 2, 4, 8 or 16");
+  // candidates (class, plane groups), fastest first
+  struct Choice {
+    uint32_t c, G;
+    size_t need;
+  };
+  const Choice ladder[4] = {{22, 8, 8 * GROUP22_BYTES + 40 * GiB}, {22, 4, 4 * GROUP22_BYTES + 40 * GiB}, {16, 16, 21 * GiB}, {8, 16, 0}};
+  if (want != 0) {
+    uint32_t G = want >= 22 ? (free_b >= ladder[0].need ? 8u : 4u) : 16u;
+    if (G_fixed) G = G_fixed;
+    return ctx_create_with(g1_lagrange, g2_monomial, device, want, G, out);
+  }
+  int32_t rc = fail(KZG_FAIL_HIP, "no table class fits");
+  for (const Choice& ch : ladder) {
+    if (free_b < ch.need) continue;
+    rc = ctx_create_with(g1_lagrange, g2_monomial, device, ch.c, G_fixed ? G_fixed : ch.G, out);
+    if (rc != KZG_FAIL_HIP) return rc;  // built, or rejected for a reason a smaller table would not cure (bad setup point, ...)
+    (void)hipGetLastError();             // an allocation failed: clear it and step down
+  }
+  return rc;
 }
 
 // ---------------------------------------------------------------------------

@@ -100,7 +100,11 @@ struct kzg_ctx {
   // instead of 31, 403 MB) used by calls of at most KZG_LAT_MAX_BLOBS blobs, where a lane's chain -- not the chip -- is the cost
   CombGeom comb_lat{};
   uint4* d_table_lat = nullptr;
-  uint4* d_comb_k = nullptr;     // the comb's constant term K = [(2^256-1)/2] G, affine, canonical 2^384-Montgomery (96 B)
+  // the comb's constant term K = [(2^256-1)/2] * (sum of the setup points) as the STARTING VALUE of one lane per blob: that lane
+  // doubles its accumulator H - 1 times, so the stored point is [c0 / 2^(H-1)] S (affine, table format: 2^392-Montgomery, 96 B;
+  // null = identity), one per table geometry
+  uint4* d_comb_k = nullptr;
+  uint4* d_comb_k_lat = nullptr;
   uint32_t window_class = 0;     // what kzg_ctx_window_bits reports
   uint4* d_bases_brp = nullptr;  // 4096 affine Lagrange points, BRP order
   fr_t* d_roots_brp = nullptr;   // 4096 roots of unity, Montgomery, BRP order
@@ -243,7 +247,7 @@ static int32_t msm_launch(const kzg_ctx* ctx, const uint8_t* d_scalars, uint64_t
   const uint4* table = lat ? ctx->d_table_lat : ctx->d_table;
   const CombGeom geom = lat ? ctx->comb_lat : ctx->comb;
   hipLaunchKernelGGL(k_msm_comb28<false>, dim3((unsigned)msm_units(n, splits, lpb)), dim3(64), 0, st, masks, n, splits, lpb, table, geom, partials,
-                     (uint64_t*)nullptr);
+                     (const uint4*)(lat ? ctx->d_comb_k_lat : ctx->d_comb_k), (uint64_t*)nullptr);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -255,17 +259,16 @@ static inline int32_t msm_finish(const kzg_ctx* ctx, uint64_t n, uint8_t* d_out4
   ProfScope ps(ctx, PROF_REDUCE_COMPRESS, st);
   g1_xyzz* unit_sums = (splits == 1) ? sums : partials + (size_t)n * splits * 64;
   const uint64_t units = msm_units(n, splits, lpb);
-  const uint4* comb_k = ctx->use_comb ? ctx->d_comb_k : (const uint4*)nullptr;
   hipLaunchKernelGGL(k_msm_reduce, dim3((unsigned)units), dim3(64), 0, st, partials, units, lpb, unit_sums, lpb == 64 ? units : n);
   if (splits > 64) {  // latency shape (a few blobs over up to 256 units each): tree + constant term + encoding in one launch
-    hipLaunchKernelGGL((k_msm_reduce_splits<256, true>), dim3((unsigned)n), dim3(256), 0, st, unit_sums, splits, n, sums, d_status, d_out48, d_out_affine96, comb_k);
+    hipLaunchKernelGGL((k_msm_reduce_splits<256, true>), dim3((unsigned)n), dim3(256), 0, st, unit_sums, splits, n, sums, d_status, d_out48, d_out_affine96);
     HIP_TRY(hipGetLastError());
     return 0;
   }
   if (splits > 1)
     hipLaunchKernelGGL((k_msm_reduce_splits<64, false>), dim3((unsigned)n), dim3(64), 0, st, unit_sums, splits, n, sums, (const int32_t*)nullptr,
-                       (uint8_t*)nullptr, (uint8_t*)nullptr, (const uint4*)nullptr);
-  hipLaunchKernelGGL(k_g1_compress, dim3(blocks_for(n, 64)), dim3(64), 0, st, sums, n, d_status, d_out48, d_out_affine96, comb_k);
+                       (uint8_t*)nullptr, (uint8_t*)nullptr);
+  hipLaunchKernelGGL(k_g1_compress, dim3(blocks_for(n, 64)), dim3(64), 0, st, sums, n, d_status, d_out48, d_out_affine96);
   HIP_TRY(hipGetLastError());
   return 0;
 }

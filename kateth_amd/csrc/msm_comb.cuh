@@ -7,7 +7,8 @@
 // of t points, which is t times more memory-efficient per index bit:
 //   * scalars are recoded to signed bits:  2e = sum_k s_k 2^k + (2^256 - 1),  s_k = 2 b_k - 1 = +-1  (k = 0..255), so
 //       sum_i e_i L_i = sum_k 2^k sum_i s_{i,k} (L_i / 2)  +  [(2^256 - 1)/2] sum_i L_i ,
-//     and sum_i L_i is the G1 generator (the Lagrange basis sums to 1): the last term is the constant point K = [c0]G;
+//     and sum_i L_i is the G1 generator for a Lagrange basis (it sums to 1): the last term is the constant point K = [c0] sum_i L_i
+//     (computed from the actual sum at context creation; one lane per blob starts from it);
 //   * the 4096 points are cut into blocks of t consecutive points (per 64 points: 22 + 21 + 21, or 4 x 16, 8 x 8, 16 x 4);
 //     for a block the table holds every sign combination  S[m] = sum_p s_p(m) (L_p / 2)  with the top sign fixed to -1
 //     (S[~m] = -S[m]: a negation is free), 2^(t-1) affine entries;
@@ -140,7 +141,7 @@ struct CombWalker {
 template <bool TIMED>
 static __global__ __launch_bounds__(64, 2) void k_msm_comb28(const uint64_t* __restrict__ masks, uint64_t n, uint32_t splits, uint32_t lpb,
                                                              const uint4* __restrict__ table, CombGeom g, g1_xyzz* __restrict__ partials,
-                                                             uint64_t* __restrict__ wave_times) {
+                                                             const uint4* __restrict__ comb_k, uint64_t* __restrict__ wave_times) {
   const int lane = threadIdx.x;
   const uint64_t unit = blockIdx.x;
   uint64_t wt_wall0 = 0, wt_cyc0 = 0;
@@ -170,6 +171,18 @@ static __global__ __launch_bounds__(64, 2) void k_msm_comb28(const uint64_t* __r
 
   g1_xyzz28 acc;
   xyzz28_set_inf(acc);
+  // The recoding's constant term K = [c0] * (sum of the setup points) is the STARTING VALUE of one lane per blob -- lane 0 of
+  // the blob's first unit, plane group 0 -- so no later step has to add it.  The lane doubles its accumulator H - 1 times on
+  // its way down the planes: comb_k holds [c0 / 2^(H-1)] * sum (affine, table format; null when it is the identity).
+  if (comb_k != nullptr && l == 0u && split == 0u) {
+    fp_t kx, ky;
+    load_affine96(kx, ky, comb_k, 0);
+    f28_from_bn(acc.x, kx);
+    f28_from_bn(acc.y, ky);
+    acc.zz = f28_one();
+    acc.zzz = acc.zz;
+    acc.inf = 0;
+  }
 
   CombWalker w;  // next mask to load
   w.h = g.H - 1u;

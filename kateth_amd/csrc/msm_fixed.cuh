@@ -106,24 +106,16 @@ static __global__ __launch_bounds__(64) void k_msm_reduce(const g1_xyzz* __restr
 // XYZZ sum of one blob -> affine -> 48-byte compressed encoding (K3: blst_p1_compress, src/bls.rs:499) and/or the 96-byte
 // blst_p1_affine image (so that a caller that wants the reference's `P1` back -- Commitment = Proof = P1,
 // src/kzg/mod.rs:9-10 -- needs no square root).  An item whose status is non-zero gets zero bytes.  Either output pointer may
-// be null.  `comb_k` (nullable): the comb MSM's constant term K (affine, 2^384-Montgomery), added to the sum first (msm_comb.cuh).
+// be null.  (The comb MSM's constant term K is already in the sum: one lane per blob starts from it, msm_comb.cuh.)
 __device__ __noinline__ void g1_finish_item(const g1_xyzz& sum, uint64_t b, const int32_t* __restrict__ status, uint8_t* __restrict__ out48,
-                                            uint8_t* __restrict__ out_affine96, const uint4* __restrict__ comb_k) {
+                                            uint8_t* __restrict__ out_affine96) {
   uint8_t tmp[48];
   uint32_t aff[24];
   if (status != nullptr && status[b] != 0) {
     for (int q = 0; q < 48; q++) tmp[q] = 0;
     for (int q = 0; q < 24; q++) aff[q] = 0;
   } else {
-    g1_xyzz acc = sum;
-    if (comb_k != nullptr) {
-      fp_t kx, ky;
-      load_affine96(kx, ky, comb_k, 0);
-      g1_xyzz mine = acc;  // copy: keeps the complete adder's operands addressable
-      xyzz_madd(mine, kx, ky);
-      acc = mine;
-    }
-    g1_compress_xyzz28(tmp, out_affine96 ? aff : nullptr, acc);  // inversion in the radix-2^28 field (g1_decode28.cuh)
+    g1_compress_xyzz28(tmp, out_affine96 ? aff : nullptr, sum);  // inversion in the radix-2^28 field (g1_decode28.cuh)
   }
   if (out48) {
     uint32_t* o = reinterpret_cast<uint32_t*>(out48 + b * 48);
@@ -137,13 +129,13 @@ __device__ __noinline__ void g1_finish_item(const g1_xyzz& sum, uint64_t b, cons
 }
 
 // One workgroup of BS threads per blob: sums the blob's `splits` (<= BS) unit sums by a tree through LDS in the radix-2^28
-// field.  FINISH: thread 0 then adds the comb's constant term and encodes the point itself (the latency shape: a single blob
+// field.  FINISH: thread 0 then encodes the point itself (the latency shape: a single blob
 // is spread over up to 256 units, and a separate one-thread k_g1_compress launch would cost a launch and a cold start);
 // otherwise sums[b] is written for k_g1_compress.
 template <int BS, bool FINISH>
 static __global__ __launch_bounds__(BS) void k_msm_reduce_splits(const g1_xyzz* __restrict__ unit_sums, uint32_t splits, uint64_t n, g1_xyzz* __restrict__ sums,
                                                                  const int32_t* __restrict__ status, uint8_t* __restrict__ out48,
-                                                                 uint8_t* __restrict__ out_affine96, const uint4* __restrict__ comb_k) {
+                                                                 uint8_t* __restrict__ out_affine96) {
   __shared__ g1_xyzz28 lds[BS / 2];
   const int t = threadIdx.x;
   const uint64_t b = blockIdx.x;
@@ -171,7 +163,7 @@ static __global__ __launch_bounds__(BS) void k_msm_reduce_splits(const g1_xyzz* 
     g1_xyzz out;
     xyzz28_to_xyzz(out, acc);
     if (FINISH)
-      g1_finish_item(out, b, status, out48, out_affine96, comb_k);
+      g1_finish_item(out, b, status, out48, out_affine96);
     else
       sums[b] = out;
   }
@@ -179,11 +171,11 @@ static __global__ __launch_bounds__(BS) void k_msm_reduce_splits(const g1_xyzz* 
 
 // One thread per item: g1_finish_item over n sums.
 static __global__ __launch_bounds__(64) void k_g1_compress(const g1_xyzz* __restrict__ sums, uint64_t n, const int32_t* __restrict__ status,
-                                                    uint8_t* __restrict__ out48, uint8_t* __restrict__ out_affine96, const uint4* __restrict__ comb_k) {
+                                                    uint8_t* __restrict__ out48, uint8_t* __restrict__ out_affine96) {
   const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= n) return;
   const g1_xyzz acc = sums[b];
-  g1_finish_item(acc, b, status, out48, out_affine96, comb_k);
+  g1_finish_item(acc, b, status, out48, out_affine96);
 }
 
 #endif  // __HIPCC__

@@ -108,7 +108,7 @@ int32_t timed_comb_launch(const kzg_ctx* ctx, bool be_bytes, const uint8_t* d_sc
   const bool lat = msm_uses_lat(ctx, splits);
   const uint64_t units = msm_units(n, splits, lpb);
   hipLaunchKernelGGL(k_msm_comb28<true>, dim3((unsigned)units), dim3(64), 0, st, masks, n, splits, lpb, lat ? ctx->d_table_lat : ctx->d_table,
-                     lat ? ctx->comb_lat : ctx->comb, partials, units <= ws->wave_times_cap ? ws->d_wave_times : (uint64_t*)nullptr);
+                     lat ? ctx->comb_lat : ctx->comb, partials, (const uint4*)(lat ? ctx->d_comb_k_lat : ctx->d_comb_k), units <= ws->wave_times_cap ? ws->d_wave_times : (uint64_t*)nullptr);
   HIP_TRY(hipGetLastError());
   return 0;
 }
