@@ -69,8 +69,12 @@ def test_native_library_is_loaded(engine):
 
 def test_commitment_known_answers(engine):
     d = json.load(open(TRUSTED_SETUP))
-    blobs = [be32(1) * 4096, bytes(131072)]
-    want = [GEN48, INF48]
+    # [2]G and [3]G: the public BLS keys of the secret keys 2 and 3 (constants from outside this repository, tests/test_oracle_kat.py);
+    # r - 1 everywhere = -G
+    g2x = bytes.fromhex("a572cbea904d67468808c8eb50a9450c9721db309128012543902d0ac358a62ae28f75bb8f1c7c42c39a8c5529bf0f4e")
+    g3x = bytes.fromhex("89ece308f9d1f0131765212deca99697b112d61f9be9a5f1f3780a51335b3ff981747a0b2ca2179b96d2c0c9024e5224")
+    blobs = [be32(1) * 4096, bytes(131072), be32(2) * 4096, be32(3) * 4096, be32(R - 1) * 4096]
+    want = [GEN48, INF48, g2x, g3x, bytes([GEN48[0] ^ 0x20]) + GEN48[1:]]
     for i in (0, 1, 2, 3, 4095):
         blob = bytearray(131072)
         blob[32 * i + 31] = 1
@@ -1226,7 +1230,7 @@ def test_load_setup_rejects_bad_points_with_the_reference_error():
     assert "g2_monomial[3]" in str(e.value)
 
 
-@pytest.mark.parametrize("workload", ["commit", "verify"])
+@pytest.mark.parametrize("workload", ["commit", "proof", "verify"])
 def test_bench_rank_launcher_two_real_engine_ranks_on_one_card(workload):
     """`python bench.py --gpus 2` starts two rank processes itself (before anything in the launcher touches HIP); here they
     share the one card and exchange through gloo (RCCL needs a GPU per rank): the REAL engine in every rank -- blob-sharded
@@ -1250,7 +1254,7 @@ def test_bench_rank_launcher_two_real_engine_ranks_on_one_card(workload):
     rec = json.loads(out.stdout.strip().splitlines()[-1])
     assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0
     assert rec["config"]["blobs_per_gpu"] == 96 and rec["config"]["backend"] == "gloo"
-    assert rec["roofline"]["kernel"] == ("k_msm_comb28" if workload == "commit" else "k_challenge*")
+    assert rec["roofline"]["kernel"] == ("k_challenge*" if workload == "verify" else "k_msm_comb28")
     # a rendezvous that disagrees with --gpus must fail loudly instead of silently running one rank
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], capture_output=True, text=True, timeout=120,
                          env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))

@@ -121,6 +121,23 @@ def test_pairing_bilinear_and_ceremony_consistency(oracle_setup):
 
 
 # ---- SURVEY 8(c) items 2-6 ---------------------------------------------------
+# Public constants the oracle did not produce: the compressed G1 points [2]G and [3]G are the Ethereum consensus-layer BLS
+# public keys of the secret keys 2 and 3 (every eth2 BLS test suite carries them); -G is G with the sign bit flipped.
+G2X48 = bytes.fromhex("a572cbea904d67468808c8eb50a9450c9721db309128012543902d0ac358a62ae28f75bb8f1c7c42c39a8c5529bf0f4e")
+G3X48 = bytes.fromhex("89ece308f9d1f0131765212deca99697b112d61f9be9a5f1f3780a51335b3ff981747a0b2ca2179b96d2c0c9024e5224")
+
+
+def test_small_multiples_of_the_generator_match_public_constants(oracle_setup):
+    """[2]G and [3]G against the well-known public keys of secret keys 2 and 3 -- pins doubling, addition and the encoding to
+    data outside this repository; and, through the Lagrange basis summing to one, the commitments of the constant blobs 2 and 3
+    (SURVEY.md section 8(c) item 2 extended): commit(all elements = c) = [c]G"""
+    assert bls.g1_compress(bls.g1_mul(bls.G1_GEN, 2)) == G2X48
+    assert bls.g1_compress(bls.g1_add(bls.g1_mul(bls.G1_GEN, 2), bls.G1_GEN)) == G3X48
+    assert bls.g1_compress(bls.g1_neg(bls.G1_GEN)) == bytes([GEN48[0] ^ 0x20]) + GEN48[1:]
+    assert bls.g1_compress(oracle_setup.blob_to_commitment((2).to_bytes(32, "big") * 4096)) == G2X48
+    assert bls.g1_compress(oracle_setup.blob_to_commitment((3).to_bytes(32, "big") * 4096)) == G3X48
+
+
 def test_commitment_known_answers(oracle_setup):
     d = json.load(open(TRUSTED_SETUP))
     ones = be32(1) * 4096
