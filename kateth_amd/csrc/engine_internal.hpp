@@ -253,7 +253,7 @@ static int32_t msm_launch(const kzg_ctx* ctx, const uint8_t* d_scalars, uint64_t
 }
 // Lane sums of n blobs -> 48-byte encodings.  Two tree stages: the 64 lane sums of every (blob, split) unit, then the units
 // of a blob -- 6 + log2(splits) levels of latency instead of the splits + 5 a sequential walk over the splits costs (a
-// single blob uses 64 splits).  `partials` must have room for n * splits unit sums after the n * splits * 64 lane sums.
+// single blob uses up to 256 units on the latency comb).  `partials` must have room for n * splits unit sums after the n * splits * 64 lane sums.
 static inline int32_t msm_finish(const kzg_ctx* ctx, uint64_t n, uint8_t* d_out48, uint8_t* d_out_affine96, const int32_t* d_status, g1_xyzz* partials,
                                  g1_xyzz* sums, uint32_t splits, uint32_t lpb, hipStream_t st) {
   ProfScope ps(ctx, PROF_REDUCE_COMPRESS, st);

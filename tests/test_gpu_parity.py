@@ -886,7 +886,7 @@ def test_production_windows_against_golden_and_c_port(window_bits, golden, torch
             b = rec["index"]
             assert z_gpu[32 * b:32 * b + 32].hex() == rec["challenge_z"] and y_gpu[32 * b:32 * b + 32].hex() == rec["eval_y"]
         assert s.verify_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n) is True
-        # the single-blob shape of the same window (64 splits per blob) gives the same bytes
+        # the single-blob shape of the same window (many split units per blob; 256 on the latency comb) gives the same bytes
         assert s.blob_to_commitment(host[:131072]).hex() == golden["blobs"][0]["commitment"]
     finally:
         s.close()
