@@ -2,7 +2,6 @@
 // challenge (K4), barycentric evaluation (K5), quotient polynomial (K6),
 // point decompression (K7).  See each kernel for the reference lines it replaces.
 #pragma once
-#include "fr29.cuh"
 #include "g1_decode28.cuh"
 #include "sha256.cuh"
 
@@ -599,230 +598,6 @@ static __global__ __launch_bounds__(512, 4) void k_poly(const uint8_t* __restric
   }
 }
 
-
-// The same kernel with the six products per element in the carry-free radix-2^29 representation of Fr (fr29.cuh, Montgomery
-// radix 2^261: 81 + 81 v_mad_u64_u32 and no carry instruction per product instead of 2 x 128 mad/addc).  Elements stay plain
-// 8 x 32-bit limbs (mont_mul(plain, X R) = plain X), the prefix products / inverses are 9-limb values, the roots come from
-// eval_tab (w R for the root at the even position of a pair; the odd position's root is -w, so d = z - root = z + w there and
-// the thread -- whose eight elements all have its own parity -- negates its partial sum once).  16 live field elements per
-// thread need ~200 VGPRs: one 8-wave workgroup per CU instead of two.
-template <bool QUOTIENT>
-static __global__ __launch_bounds__(512, 1) void k_poly29(const uint8_t* __restrict__ blobs, const fr_t* __restrict__ z_plain,
-                                                          const fr_t* __restrict__ roots_brp, const uint32_t* __restrict__ eval_tab,
-                                                          const fr_t* __restrict__ inv_root, fr_t* __restrict__ y_plain, fr_t* __restrict__ q_plain,
-                                                          int32_t* __restrict__ status) {
-  __shared__ fr29 tree[1024];
-  __shared__ fr_t ytree[512];
-  __shared__ int sh_domain;
-  __shared__ int sh_bad;
-  __shared__ fr_t sh_y;
-  const int t = threadIdx.x;
-  const bool odd = (t & 1) != 0;
-  const uint64_t b = blockIdx.x;
-  const uint8_t* blob = blobs + b * 131072ull;
-  if (t == 0) {
-    sh_domain = -1;
-    sh_bad = 0;
-  }
-  __syncthreads();
-  const fr29 one = f29_const_one();
-  fr29 z;
-  {
-    fr29 zp;
-    f29_from_bn(zp, z_plain[b]);
-    f29_to_mont(z, zp);  // N-form
-  }
-  auto load_w = [&](int pr, fr29& w) {  // w R, canonical, strictly normalised
-    const uint4* tp = reinterpret_cast<const uint4*>(eval_tab + (uint64_t)pr * EVAL_TAB_DWORDS);
-    const uint4 t0 = tp[0], t1 = tp[1];
-    const uint32_t t8 = eval_tab[(uint64_t)pr * EVAL_TAB_DWORDS + 8];
-    w.l[0] = t0.x; w.l[1] = t0.y; w.l[2] = t0.z; w.l[3] = t0.w;
-    w.l[4] = t1.x; w.l[5] = t1.y; w.l[6] = t1.z; w.l[7] = t1.w;
-    w.l[8] = t8;
-  };
-  auto denom = [&](fr29& d, const fr29& w) {  // z - root: limbs < 3 * 2^29, value < 4r
-    if (odd)
-      f29_add(d, z, w);
-    else
-      f29_sub_2r(d, z, w);
-  };
-  fr_t e[8];
-  fr29 pre[8];
-  fr29 run = one;
-  bool bad = false;
-#pragma unroll
-  for (int k = 0; k < 8; k++) {
-    const int i = k * 512 + t;
-    uint32_t sc[8];
-    load_scalar_be_(sc, blob + (uint64_t)i * 32u);
-    fr_t v;
-#pragma unroll
-    for (int q = 0; q < 8; q++) v.v[q] = sc[q];
-    if (!fr_is_canonical(v)) {
-      bad = true;
-      bn_zero(v);
-    }
-    e[k] = v;
-    fr29 w, d;
-    load_w(i >> 1, w);
-    denom(d, w);
-    if (f29_maybe_zero(d)) {
-      if (f29_is_zero_exact(d)) {
-        sh_domain = i;  // at most one index can match
-        d = one;
-      }
-    }
-    f29_mul(run, run, d);
-    pre[k] = run;
-  }
-  if (bad) sh_bad = 1;
-  tree[512 + t] = run;
-  __syncthreads();
-  for (int width = 256; width >= 1; width >>= 1) {  // product tree: node j = node 2j * node 2j+1
-    if (t < width) {
-      const fr29 a = tree[2 * (width + t)], c = tree[2 * (width + t) + 1];
-      fr29 r;
-      f29_mul(r, a, c);
-      tree[width + t] = r;
-    }
-    __syncthreads();
-  }
-  if (t == 0) {  // = 1 / tree[1], from k_poly_root_inverse (Montgomery radix 2^256): a 2^256 * 2^266 / 2^261 = a 2^261
-    fr29 x, k266;
-    f29_from_bn(x, inv_root[b]);
-    {
-      constexpr uint32_t c[F29_N] = KZG_FR29_R266;
-#pragma unroll
-      for (int q = 0; q < F29_N; q++) k266.l[q] = c[q];
-    }
-    f29_mul(x, x, k266);
-    tree[1] = x;
-  }
-  __syncthreads();
-  for (int width = 1; width <= 256; width <<= 1) {  // push inverses down: children of j get inv(j) * sibling product
-    if (t < width) {
-      const int j = width + t;
-      const fr29 ip = tree[j], a = tree[2 * j], c = tree[2 * j + 1];
-      fr29 ra, rc;
-      f29_mul(ra, ip, c);
-      f29_mul(rc, ip, a);
-      tree[2 * j] = ra;
-      tree[2 * j + 1] = rc;
-    }
-    __syncthreads();
-  }
-  const int domain = sh_domain;
-  fr29 inv_run = tree[512 + t];  // inverse of this thread's total product
-  fr29 ysum;
-#pragma unroll
-  for (int q = 0; q < F29_N; q++) ysum.l[q] = 0;
-#pragma unroll
-  for (int k = 7; k >= 0; k--) {
-    const int i = k * 512 + t;
-    fr29 w, d, inv_d, term, x;
-    load_w(i >> 1, w);
-    denom(d, w);
-    if (i == domain) d = one;
-    if (k == 0) {
-      inv_d = inv_run;
-    } else {
-      f29_mul(inv_d, inv_run, pre[k - 1]);
-      f29_mul(inv_run, inv_run, d);
-    }
-    pre[k] = inv_d;  // slot k now holds R / (z - root_i)
-    f29_mul(term, w, inv_d);  // (w R)(inv_d R) / R = w inv_d R
-    f29_from_bn(x, e[k]);
-    f29_mul(term, x, term);   // plain e * (w inv_d R) / R = plain e w / (z - root)   (sign of the odd positions: below)
-    if (i != domain) f29_add(ysum, ysum, term);  // eight N-form terms: limbs < 2^32
-  }
-  {  // this thread's partial sum as a canonical plain value; the odd positions' roots are -w
-    f29_carry_pass(ysum);
-    fr29 tn;
-    f29_mul(tn, ysum, one);  // x R / R = x, N-form
-    fr_t ys;
-    f29_to_canonical_bn(ys, tn);
-    if (odd) fr_neg(ys, ys);
-    ytree[t] = ys;
-  }
-  __syncthreads();
-  for (int width = 256; width >= 1; width >>= 1) {
-    if (t < width) {
-      fr_t a = ytree[t], c = ytree[t + width], r;
-      fr_add(r, a, c);
-      ytree[t] = r;
-    }
-    __syncthreads();
-  }
-  if (t == 0) {
-    fr_t total = ytree[0], zm, zn, f;
-    to_mont<FrParams>(zm, z_plain[b]);
-    zn = zm;
-    for (int q = 0; q < 12; q++) fr_sqr(zn, zn);  // z^4096
-    fr_sub(zn, zn, fr_one());
-    {
-      const uint32_t c4096[8] = KZG_FR_INV4096_MONT;
-#pragma unroll
-      for (int q = 0; q < 8; q++) f.v[q] = c4096[q];
-    }
-    fr_mul(f, f, zn);
-    fr_mul(total, total, f);  // plain sum * Montgomery factor = plain y
-    sh_y = total;
-  }
-  __syncthreads();
-  if (domain >= 0 && (domain & 511) == t) {
-#pragma unroll
-    for (int k = 0; k < 8; k++)
-      if (k == (domain >> 9)) sh_y = e[k];  // y = e_m (poly.rs:14-18)
-  }
-  __syncthreads();
-  const fr_t y = sh_y;  // plain
-  if (t == 0) {
-    y_plain[b] = y;
-    if (sh_bad) atomicOr(&status[b], KZG_ERR_BLOB_INVALID_FIELD_ELEMENT);
-  }
-  if (QUOTIENT) {
-    fr_t* qout = q_plain + b * 4096ull;
-    fr_t ssum;
-    bn_zero(ssum);
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-      const int i = k * 512 + t;
-      fr_t ye, q;
-      fr_sub(ye, y, e[k]);  // plain, canonical
-      fr29 x, q29;
-      f29_from_bn(x, ye);
-      f29_mul(q29, x, pre[k]);  // plain * (R / (z - root_i)) / R: the plain quotient element
-      f29_to_canonical_bn(q, q29);
-      if (i == domain) bn_zero(q);
-      if (domain >= 0) {  // block-uniform
-        fr_t qw;
-        fr_mul(qw, q, roots_brp[i]);  // plain q_i w_i
-        fr_add(ssum, ssum, qw);
-      }
-      qout[i] = q;
-    }
-    if (domain >= 0) {  // rare in-domain branch (poly.rs:50-64)
-      __syncthreads();
-      ytree[t] = ssum;
-      __syncthreads();
-      for (int width = 256; width >= 1; width >>= 1) {
-        if (t < width) {
-          fr_t a = ytree[t], c = ytree[t + width], r;
-          fr_add(r, a, c);
-          ytree[t] = r;
-        }
-        __syncthreads();
-      }
-      if (t == 0) {
-        fr_t wm = roots_brp[domain], wi, qm;
-        fr_inv_fermat(wi, wm);
-        fr_mul(qm, ytree[0], wi);  // plain sum * Montgomery 1/w_m = plain
-        fr_neg(qm, qm);
-        qout[domain] = qm;
-      }
-    }
-  }
-}
 
 #endif
 }  // namespace kzg

@@ -206,7 +206,6 @@ EnvKnobs read_env_knobs() {
       const int v = atoi(e);
       if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) k.msm_splits = (uint32_t)v;
     }
-    if (const char* e = getenv("KATETH_AMD_POLY_RADIX")) k.poly_radix32 = atoi(e) == 32;
     if (const char* e = getenv("KATETH_AMD_CHALLENGE_SPLIT_MAX")) k.challenge_split_max = (uint64_t)atoll(e) > 0 ? (uint64_t)atoll(e) : 0;
     return k;
   }

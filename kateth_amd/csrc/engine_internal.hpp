@@ -44,7 +44,6 @@ struct EnvKnobs {
   bool lat_table = true;         // KATETH_AMD_LAT_TABLE=0: no latency comb beside a class-22 table (measurement aid)
   bool comb_full_wave = false;   // KATETH_AMD_COMB_FULL_WAVE: never use the comb's two-blobs-per-wave mode (measurement aid)
   uint32_t msm_splits = 0;       // KATETH_AMD_MSM_SPLITS: force the (blob, split) decomposition of the fixed-base MSM (power of two <= 64; 0 = automatic)
-  bool poly_radix32 = false;     // KATETH_AMD_POLY_RADIX=32: the quotient kernel on 8 x 32-bit limbs (k_poly) instead of radix 2^29 (k_poly29): cross-check
   uint64_t challenge_split_max = 0;  // KATETH_AMD_CHALLENGE_SPLIT_MAX: largest batch hashed by the two-wave SHA-256 kernel (0 = default)
 };
 EnvKnobs read_env_knobs();

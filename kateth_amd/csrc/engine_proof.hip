@@ -110,10 +110,7 @@ static int32_t proof_dev_locked(const kzg_ctx* ctx, const uint8_t* d_blobs, cons
     {
       ProfScope ps(ctx, PROF_POLY, side);
       hipLaunchKernelGGL(k_poly_root_inverse, dim3(blocks_for(m, 64)), dim3(64), 0, side, z, m, invr);
-      if (ctx->knobs.poly_radix32)
-        hipLaunchKernelGGL(k_poly<true>, dim3((unsigned)m), dim3(512), 0, side, blobs, z, ctx->d_roots_brp, invr, y, q, d_status + base);
-      else
-        hipLaunchKernelGGL(k_poly29<true>, dim3((unsigned)m), dim3(512), 0, side, blobs, z, ctx->d_roots_brp, ctx->d_eval_tab, invr, y, q, d_status + base);
+      hipLaunchKernelGGL(k_poly<true>, dim3((unsigned)m), dim3(512), 0, side, blobs, z, ctx->d_roots_brp, invr, y, q, d_status + base);
     }
     hipLaunchKernelGGL(k_merge_status, dim3(blocks_for(m, 256)), dim3(256), 0, side, d_status + base, cstat, m);
     (void)hipEventRecord(ev_prep[k], side);

@@ -57,19 +57,6 @@ KZG_HD void f29_sub_2r(fr29& r, const fr29& a, const fr29& b) {
     r.l[i] = a.l[i] + f29_2r_t1(i) - b.l[i];
   }
 }
-// one carry pass, all limbs at once (no serial chain): limbs 0..7 end up <= 2^29 - 1 + (max limb >> 29)
-KZG_HD void f29_carry_pass(fr29& a) {
-  uint32_t hi[F29_N];
-  KZG_UNROLL_FULL
-  for (int i = 0; i < F29_N - 1; i++) hi[i] = a.l[i] >> F29_W;
-  KZG_UNROLL_FULL
-  for (int i = F29_N - 1; i >= 1; i--) {
-    const uint32_t lo = (i < F29_N - 1) ? (a.l[i] & F29_MASK) : a.l[i];
-    RDX_ADDCHK(lo, hi[i - 1]);
-    a.l[i] = lo + hi[i - 1];
-  }
-  a.l[0] &= F29_MASK;
-}
 KZG_HD fr29 f29_const_one() {
   fr29 r;
   KZG_UNROLL_FULL
