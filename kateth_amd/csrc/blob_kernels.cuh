@@ -2,6 +2,7 @@
 // challenge (K4), barycentric evaluation (K5), quotient polynomial (K6),
 // point decompression (K7).  See each kernel for the reference lines it replaces.
 #pragma once
+#include "issue_fair.cuh"
 #include "g1_decode28.cuh"
 #include "sha256.cuh"
 
@@ -255,6 +256,7 @@ __device__ __forceinline__ void challenge_producer(uint32_t (*wk)[64 * 64], int 
 // instruction count is slightly higher, so batches that fill the chip keep k_challenge.
 __device__ __forceinline__ void challenge_split_workgroup(uint32_t (*wk)[64 * 64], uint64_t wg, const uint8_t* __restrict__ blobs,
                                                           const uint8_t* __restrict__ commitments48, uint64_t n, fr_t* __restrict__ z_plain) {
+  issue_priority_latency();  // a latency-bound stream: never behind an MSM wave of another stream (issue_fair.cuh)
   const int lane = threadIdx.x & 63;
   const bool producer = threadIdx.x >= 64;
   uint64_t b = wg * 64 + lane;
@@ -293,6 +295,7 @@ static __global__ __launch_bounds__(128) void k_challenge_split(const uint8_t* _
 // take two consumer waves + the producer wave.  Y lanes read their W + K from an all-zero LDS region.
 __device__ __forceinline__ void challenge_pair_workgroup(uint32_t (*wk)[64 * 64], uint32_t* zeros, uint64_t wg, const uint8_t* __restrict__ blobs,
                                                          const uint8_t* __restrict__ commitments48, uint64_t n, fr_t* __restrict__ z_plain) {
+  issue_priority_latency();  // a latency-bound stream: never behind an MSM wave of another stream (issue_fair.cuh)
   const int tid = threadIdx.x;  // 192 threads: [0, 128) consumer lane pairs, [128, 192) producer
   const bool producer = tid >= 128;
   const int p = producer ? tid - 128 : tid >> 1;  // blob within the workgroup
@@ -410,6 +413,7 @@ static __global__ __launch_bounds__(64) void k_fr_parse(const uint8_t* __restric
 // replaced by 1 for an in-domain z = w_m: prod_{i != m} (w_m - w_i) = 4096 / w_m).  Its inverse is
 // therefore computed here, one blob per lane, instead of serially inside every workgroup.
 static __global__ __launch_bounds__(64) void k_poly_root_inverse(const fr_t* __restrict__ z_plain, uint64_t n, fr_t* __restrict__ inv_root) {
+  issue_priority_latency();
   const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= n) return;
   fr_t z, zn, r;
@@ -438,6 +442,7 @@ static __global__ __launch_bounds__(512, 4) void k_poly(const uint8_t* __restric
   __shared__ int sh_domain;
   __shared__ int sh_bad;
   __shared__ fr_t sh_y;
+  issue_priority_latency();  // short beside an MSM launch of another stream (host-buffer proof pipeline)
   const int t = threadIdx.x;
   const uint64_t b = blockIdx.x;
   const uint8_t* blob = blobs + b * 131072ull;

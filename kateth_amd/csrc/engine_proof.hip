@@ -151,11 +151,20 @@ extern "C" int32_t kzg_compute_blob_proof_batch_dev(const kzg_ctx* ctx, const vo
   return rc;
 }
 
-// Host-buffer wrapper shared by the proof entry points.  Device buffers come from the context's pools (stage_lock): the
-// staging arena holds the blobs of one pass (at most 16,384 = 2 GiB; larger batches take several passes), the small inputs
-// and results live in the host-i/o pool -- a steady-state call allocates nothing.  "Copy, then compute": the
-// floor of a pass is copy + preparation + one MSM pass, because every wave of the MSM kernel holds its slot for the whole
-// pass; splitting the batch only moves the first piece's MSM earlier while the last piece still pays all three.
+// Host-buffer wrapper shared by the proof entry points.  Device buffers come from the context's pools (stage_lock): two
+// staging slots of up to 4,096 blobs, the small inputs and results in the host-i/o pool -- a steady-state call allocates
+// nothing.
+//
+// The batch is walked in PASSES, double-buffered: while the device path (proof_dev_locked: hash + commitment check,
+// evaluation + quotient, MSM, encoding) works on pass k on the compute stream, pass k+1 is copied in on the copy stream --
+// events only, the host never waits inside the loop.  Passes are 4,096 blobs (the MSM's most efficient shape); batches
+// above 5,120 blobs start with a pass of 1,024 so that only 2.3 ms of the transfer are exposed.  16,384 blobs: 105.3 k
+// blobs/s (99.8 k with "copy everything, then compute"); up to 5,120 blobs one pass: copy, then compute (87-92 k at 4,096).
+// Measured alternatives at 4,096 blobs (round 3, profiles/r03/host_proof_variants.json): one pass 46.2 ms; passes of 1,024 +
+// 3,072: 47.0 ms (the second hash latency costs what the hidden copy saves); a pipeline of 1,024-blob chunks on four
+// streams, every chunk's MSM as one wave per SIMD: 44.7 ms at 4,096 but 170 ms at 16,384 -- the short kernels of later chunks
+// (k_poly: 8-wave workgroups of 126 VGPRs) find no register space beside two resident MSM chunks (2 x 232 VGPRs per SIMD)
+// and wait for a whole chunk to drain, so the pipeline degenerates to two-deep serial passes.
 static int32_t proof_host(const kzg_ctx* ctx, const uint8_t* blobs, const uint8_t* side, size_t side_bytes, bool side_is_commitment, uint64_t n,
                           uint8_t* out48, uint8_t* out_affine96, uint8_t* out_y32, int32_t* status) {
   if (n == 0) return 0;
@@ -163,47 +172,73 @@ static int32_t proof_host(const kzg_ctx* ctx, const uint8_t* blobs, const uint8_
   std::lock_guard<std::mutex> stage_guard(ctx->stage_lock);
   int32_t rc = stage_init(ctx);
   if (rc) return rc;
-  const uint64_t pass_max = 16384;
-  const uint64_t pn = n < pass_max ? n : pass_max;
+  constexpr uint64_t PASS = 4096;
+  std::vector<uint64_t> plan;
+  {
+    uint64_t rest = n;
+    if (n > PASS + 1024) {  // a short first pass only where later passes can hide behind it (measured: at 4,096 blobs two passes cost what they save)
+      plan.push_back(1024);
+      rest -= 1024;
+    }
+    for (; rest > PASS; rest -= PASS) plan.push_back(PASS);
+    if (rest) plan.push_back(rest);
+  }
+  uint64_t max_pass = 0;
+  for (uint64_t m : plan) max_pass = m > max_pass ? m : max_pass;
+  const uint64_t nslots = plan.size() > 1 ? 2 : 1;
+  const size_t slot_bytes = (size_t)max_pass * KZG_BYTES_PER_BLOB;
   size_t off = 0;
   auto take = [&](size_t bytes) {
     size_t o = off;
     off = align_up(off + bytes, 256);
     return o;
   };
-  const size_t o_side = take(pn * side_bytes), o_out = take(pn * 48), o_aff = take(pn * 96), o_y = take(pn * 32), o_st = take(pn * sizeof(int32_t));
-  rc = stage_reserve(ctx, pn * (size_t)KZG_BYTES_PER_BLOB, off);
+  const size_t o_side = take(n * side_bytes), o_out = take(n * 48), o_aff = take(n * 96), o_y = take(n * 32), o_st = take(n * sizeof(int32_t));
+  rc = stage_reserve(ctx, nslots * slot_bytes, off);
   if (rc) return rc;
-  uint8_t* d_blobs = ctx->stage;
   uint8_t* d_side = ctx->hostio + o_side;
   uint8_t* d_out = out48 ? ctx->hostio + o_out : nullptr;
   uint8_t* d_aff = out_affine96 ? ctx->hostio + o_aff : nullptr;
   uint8_t* d_y = ctx->hostio + o_y;
   int32_t* d_status = reinterpret_cast<int32_t*>(ctx->hostio + o_st);
+  hipStream_t copy_st = ctx->stage_copy_stream;
   hipStream_t st = ctx->stage_streams[0];  // an idle non-blocking stream (the null stream would serialise against every blocking stream of the process)
-  for (uint64_t base = 0; base < n && rc == 0; base += pn) {
-    const uint64_t m = (n - base < pn) ? (n - base) : pn;
-    if (hipMemcpyAsync(d_side, side + base * side_bytes, m * side_bytes, hipMemcpyHostToDevice, st) != hipSuccess ||
-        hipMemcpyAsync(d_blobs, blobs + base * (size_t)KZG_BYTES_PER_BLOB, m * (size_t)KZG_BYTES_PER_BLOB, hipMemcpyHostToDevice, st) != hipSuccess) {
+  std::lock_guard<std::mutex> guard(ctx->lock);
+  do {
+    if (hipMemcpyAsync(d_side, side, n * side_bytes, hipMemcpyHostToDevice, st) != hipSuccess) {
       rc = fail(KZG_FAIL_HIP, "host-to-device copy failed");
       break;
     }
-    {
-      std::lock_guard<std::mutex> guard(ctx->lock);
-      rc = ws_acquire(ctx, st);
-      if (rc == 0)
-        rc = proof_dev_locked(ctx, d_blobs, side_is_commitment ? d_side : nullptr, side_is_commitment ? nullptr : d_side, m, d_out, d_aff,
-                              out_y32 ? d_y : nullptr, d_status, st);
-      if (rc == 0) rc = ws_release(ctx, st);
+    rc = ws_acquire(ctx, st);
+    uint64_t base = 0;
+    for (size_t k = 0; k < plan.size() && rc == 0; base += plan[k], k++) {
+      const int slot = (int)(k & 1);
+      const uint64_t m = plan[k];
+      uint8_t* d_blobs = ctx->stage + (size_t)slot * slot_bytes;
+      // pass k-2 (same slot) must be done with the staging buffer before it is overwritten
+      if (k >= 2 && hipStreamWaitEvent(copy_st, ctx->stage_done[slot], 0) != hipSuccess) {
+        rc = fail(KZG_FAIL_HIP, "stream wait failed");
+        break;
+      }
+      if (hipMemcpyAsync(d_blobs, blobs + base * (size_t)KZG_BYTES_PER_BLOB, m * (size_t)KZG_BYTES_PER_BLOB, hipMemcpyHostToDevice, copy_st) != hipSuccess ||
+          hipEventRecord(ctx->stage_copied[slot], copy_st) != hipSuccess || hipStreamWaitEvent(st, ctx->stage_copied[slot], 0) != hipSuccess) {
+        rc = fail(KZG_FAIL_HIP, "host-to-device copy failed");
+        break;
+      }
+      rc = proof_dev_locked(ctx, d_blobs, side_is_commitment ? d_side + base * side_bytes : nullptr, side_is_commitment ? nullptr : d_side + base * side_bytes,
+                            m, d_out ? d_out + base * 48 : nullptr, d_aff ? d_aff + base * 96 : nullptr, out_y32 ? d_y + base * 32 : nullptr,
+                            d_status + base, st);
+      if (rc == 0 && hipEventRecord(ctx->stage_done[slot], st) != hipSuccess) rc = fail(KZG_FAIL_HIP, "event record failed");
     }
     if (rc) break;
-    if ((out48 && hipMemcpyAsync(out48 + base * 48, d_out, m * 48, hipMemcpyDeviceToHost, st) != hipSuccess) ||
-        (out_affine96 && hipMemcpyAsync(out_affine96 + base * 96, d_aff, m * 96, hipMemcpyDeviceToHost, st) != hipSuccess) ||
-        (out_y32 && hipMemcpyAsync(out_y32 + base * 32, d_y, m * 32, hipMemcpyDeviceToHost, st) != hipSuccess) ||
-        hipMemcpyAsync(status + base, d_status, m * sizeof(int32_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
-        hipStreamSynchronize(st) != hipSuccess)  // the next pass reuses the arena and the pools
+    rc = ws_release(ctx, st);
+    if (rc) break;
+    if ((out48 && hipMemcpyAsync(out48, d_out, n * 48, hipMemcpyDeviceToHost, st) != hipSuccess) ||
+        (out_affine96 && hipMemcpyAsync(out_affine96, d_aff, n * 96, hipMemcpyDeviceToHost, st) != hipSuccess) ||
+        (out_y32 && hipMemcpyAsync(out_y32, d_y, n * 32, hipMemcpyDeviceToHost, st) != hipSuccess) ||
+        hipMemcpyAsync(status, d_status, n * sizeof(int32_t), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
       rc = fail(KZG_FAIL_HIP, "device-to-host copy failed");
-  }
+  } while (0);
   if (rc) (void)hipDeviceSynchronize();
   return rc;
 }

@@ -25,4 +25,25 @@ KZG_HD void issue_fair_tick(uint32_t shift) {
 #endif
 }
 
+// The fixed-base MSM's variant: levels 2 / 0.  Its waves live for a whole launch (7-29 ms); the short, latency-bound kernels
+// that may run beside them on another stream (hash, quotient, bit-plane transposition, lane-sum trees, encoding -- the chunk
+// pipelines of the host-buffer entry points) raise themselves to 3 with issue_priority_latency() and so never wait behind an
+// MSM wave's instruction stream.
+KZG_HD void issue_fair_tick_low(uint32_t shift) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const uint32_t parity = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1u;
+  if ((((uint32_t)(__builtin_amdgcn_s_memtime() >> shift)) & 1u) == parity)
+    __builtin_amdgcn_s_setprio(2);
+  else
+    __builtin_amdgcn_s_setprio(0);
+#else
+  (void)shift;
+#endif
+}
+KZG_HD void issue_priority_latency() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_s_setprio(3);
+#endif
+}
+
 }  // namespace kzg

@@ -90,6 +90,7 @@ template <bool BE_BYTES>
 static __global__ __launch_bounds__(512) void k_comb_transpose(const uint8_t* __restrict__ scalars, uint64_t n, uint64_t* __restrict__ masks,
                                                                int32_t* __restrict__ status) {
   __shared__ uint64_t tile[256][8];
+  issue_priority_latency();
   const int tid = threadIdx.x;
   const int lane = tid & 63, wv = tid >> 6;
   const uint64_t blob = blockIdx.x >> 3;
@@ -255,7 +256,7 @@ static __global__ __launch_bounds__(64, 2) void k_msm_comb28(const uint64_t* __r
   // late); with 2^20 cycles 27.8 / 28.4 ms and the launch takes 29.2 instead of 30.7 ms (profiles/r02/wave_fairness_sweep.json).
 #pragma unroll 1
   for (uint32_t t = 0; t < total; t++) {
-    if (g.fair) issue_fair_tick(g.fair);
+    if (g.fair) issue_fair_tick_low(g.fair);
     fp28 cx, cy;
     f28_load_entry(cx, cy, nx, ny, nneg);
     const bool cneg = nneg, cdbl = ndbl;

@@ -5,6 +5,7 @@
 // test-only library (tests/window_msm/).
 #pragma once
 #include "g1_decode28.cuh"
+#include "issue_fair.cuh"
 
 namespace kzg {
 
@@ -74,6 +75,7 @@ __device__ __forceinline__ void wave_reduce_xyzz(g1_xyzz& acc, g1_xyzz* lds, int
 static __global__ __launch_bounds__(64) void k_msm_reduce(const g1_xyzz* __restrict__ partials, uint64_t units, uint32_t lpb, g1_xyzz* __restrict__ unit_sums,
                                                           uint64_t n_out) {
   __shared__ g1_xyzz28 lds[32];
+  issue_priority_latency();
   const int lane = threadIdx.x;
   const uint64_t u = blockIdx.x;
   if (u >= units) return;
@@ -137,6 +139,7 @@ static __global__ __launch_bounds__(BS) void k_msm_reduce_splits(const g1_xyzz* 
                                                                  const int32_t* __restrict__ status, uint8_t* __restrict__ out48,
                                                                  uint8_t* __restrict__ out_affine96) {
   __shared__ g1_xyzz28 lds[BS / 2];
+  issue_priority_latency();
   const int t = threadIdx.x;
   const uint64_t b = blockIdx.x;
   if (b >= n) return;
@@ -172,6 +175,7 @@ static __global__ __launch_bounds__(BS) void k_msm_reduce_splits(const g1_xyzz* 
 // One thread per item: g1_finish_item over n sums.
 static __global__ __launch_bounds__(64) void k_g1_compress(const g1_xyzz* __restrict__ sums, uint64_t n, const int32_t* __restrict__ status,
                                                     uint8_t* __restrict__ out48, uint8_t* __restrict__ out_affine96) {
+  issue_priority_latency();
   const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= n) return;
   const g1_xyzz acc = sums[b];
