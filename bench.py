@@ -69,7 +69,7 @@ def parse():
     ap.add_argument("--spawn", action="store_true", help="start the rank processes through this script's launcher even for --gpus 1 (checks the launcher against the direct path)")
     ap.add_argument("--rank-logs", default=os.path.join(ROOT, "gpurun_out", "bench_ranks"), help="launcher: directory for every rank's stdout/stderr (rank<k>.out / rank<k>.err)")
     ap.add_argument("--dry-run", action="store_true", help="print every rank's HBM plan for --workload/--batch/--gpus as one JSON line and exit non-zero if it cannot fit; touches no GPU")
-    ap.add_argument("--assume-hbm-gib", type=float, default=0.0, help="--dry-run: HBM per GPU in GiB (default: 288 GB = 268.2 GiB, MI355X)")
+    ap.add_argument("--assume-hbm-gib", type=float, default=0.0, help="--dry-run: HBM per GPU in GiB (default: 288, what an MI355X reports)")
     return ap.parse_args()
 
 
@@ -77,7 +77,7 @@ def parse():
 # memory plan: what one rank keeps resident, from the engine's own constants (include/kateth_amd.h, engine.hip)
 # ---------------------------------------------------------------------------------------------------------------
 GIB = float(1 << 30)
-MI355X_HBM_BYTES = 288e9
+MI355X_HBM_BYTES = 288.0 * (1 << 30)  # hipMemGetInfo reports 287.4 GiB free on an idle MI355X here
 TABLE_GROUP_BYTES = {22: 64 * (1 << 22) * 96, 16: 64 * (4 << 15) * 96, 8: 64 * (8 << 7) * 96, 4: 64 * (16 << 3) * 96}
 
 

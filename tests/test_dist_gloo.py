@@ -119,7 +119,7 @@ def _bench(*argv):
 
 def test_bench_dry_run_prints_every_ranks_memory_plan():
     """`bench.py --dry-run` (no GPU, no torch): BASELINE configs[4] = 2^20 blobs over 8 GPUs is 131,072 blobs = 16 GiB per
-    rank beside the 192-GiB table and fits a 288-GB part; a batch that cannot fit fails BEFORE any allocation"""
+    rank beside the 192-GiB table and fits an MI355X (288 GiB as the device reports it); a batch that cannot fit fails BEFORE any allocation"""
     import json
 
     out = _bench("--dry-run", "--workload", "commit", "--batch", "131072", "--gpus", "8")
@@ -135,5 +135,5 @@ def test_bench_dry_run_prints_every_ranks_memory_plan():
     # a part with 160 GiB of HBM steps down to 4 plane groups; a batch that cannot fit is refused with exit code 3
     small = json.loads(_bench("--dry-run", "--workload", "commit", "--batch", "4096", "--assume-hbm-gib", "160").stdout.strip().splitlines()[-1])
     assert (small["ranks"][0]["table_class"], small["ranks"][0]["plane_groups"]) == (22, 4)
-    bad = _bench("--dry-run", "--workload", "commit", "--batch", "700000", "--gpus", "8")
+    bad = _bench("--dry-run", "--workload", "commit", "--batch", "800000", "--gpus", "8")
     assert bad.returncode == 3 and "does not fit" in bad.stderr
