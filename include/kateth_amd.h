@@ -140,6 +140,17 @@ int32_t kzg_compute_blob_proof_batch_affine(const kzg_ctx* ctx, const uint8_t* b
 int32_t kzg_compute_proof_batch_affine(const kzg_ctx* ctx, const uint8_t* blobs, const uint8_t* z32, uint64_t n, uint8_t* out_proof_affine96, uint8_t* out_y32, int32_t* status);
 
 /*
+ * Replaces P1::decompress -- the crate's public `Decompress` trait on G1 points, i.e. on `Commitment` / `Proof`
+ * (src/lib.rs:5, src/bls.rs:505-531: ZCash decoding, on-curve check, SUBGROUP check) -- for n compressed points:
+ *   in48         : n * 48 bytes
+ *   out_affine96 : n * 96 bytes, blst_p1_affine images as above (infinity = 96 zero bytes, status 0)
+ *   status       : per point 0 or KZG_ERR_EC_INVALID_ENCODING / KZG_ERR_EC_NOT_ON_CURVE / KZG_ERR_EC_NOT_IN_GROUP
+ *                  (a rejected point's 96 output bytes are zeroed)
+ * The same decoder the verification entry points run on their commitments and proofs.
+ */
+int32_t kzg_g1_decompress_batch(const kzg_ctx* ctx, const uint8_t* in48, uint64_t n, uint8_t* out_affine96, int32_t* status);
+
+/*
  * Replaces Setup::blob_proof + compress for n (blob, commitment) pairs
  * (src/kzg/setup.rs:177-183, src/blob.rs:55-97, src/kzg/poly.rs:10-71).
  *   status : per item 0, KZG_ERR_BLOB_*, or KZG_ERR_EC_* for the commitment

@@ -677,6 +677,64 @@ static int32_t verify_phase1_host(const kzg_ctx* ctx, const uint8_t* blobs, cons
   return 0;
 }
 
+// P1::decompress for n points (src/bls.rs:505-531): the decoder of the verification path with its result in the 2^384-
+// Montgomery domain, as blst_p1_affine images
+__global__ __launch_bounds__(64) void k_g1_decompress_public(const uint8_t* __restrict__ in48, uint64_t n, uint8_t* __restrict__ out_affine96,
+                                                             int32_t* __restrict__ status) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint8_t buf[48];
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(in48 + i * 48);
+#pragma unroll
+  for (int q = 0; q < 12; q++) {
+    const uint32_t w = src[q];
+    buf[4 * q] = (uint8_t)w;
+    buf[4 * q + 1] = (uint8_t)(w >> 8);
+    buf[4 * q + 2] = (uint8_t)(w >> 16);
+    buf[4 * q + 3] = (uint8_t)(w >> 24);
+  }
+  fp_t x, y;
+  bool is_inf = false;
+  const int32_t st = g1_decompress28(x, y, is_inf, buf, false);
+  status[i] = st;
+  if (st != 0 || is_inf) {
+    bn_zero(x);
+    bn_zero(y);
+  }
+  uint32_t* o = reinterpret_cast<uint32_t*>(out_affine96 + i * 96);
+#pragma unroll
+  for (int q = 0; q < 12; q++) {
+    o[q] = x.v[q];
+    o[12 + q] = y.v[q];
+  }
+}
+
+extern "C" int32_t kzg_g1_decompress_batch(const kzg_ctx* ctx, const uint8_t* in48, uint64_t n, uint8_t* out_affine96, int32_t* status) {
+  if (!ctx || (n && (!in48 || !out_affine96 || !status))) return fail(KZG_FAIL_ARGUMENT, "null argument");
+  if (n == 0) return 0;
+  HIP_TRY(hipSetDevice(ctx->device));
+  std::lock_guard<std::mutex> guard(ctx->stage_lock);  // pooled device buffers + an idle stream of the host-buffer pipelines
+  int32_t rc = stage_init(ctx);
+  if (rc) return rc;
+  const size_t o_out = align_up((size_t)n * 48, 256), o_st = o_out + align_up((size_t)n * 96, 256);
+  rc = stage_reserve(ctx, 0, o_st + (size_t)n * sizeof(int32_t));
+  if (rc) return rc;
+  uint8_t* d_in = ctx->hostio;
+  uint8_t* d_out = ctx->hostio + o_out;
+  int32_t* d_st = reinterpret_cast<int32_t*>(ctx->hostio + o_st);
+  hipStream_t st = ctx->stage_streams[0];
+  HIP_TRY(hipMemcpyAsync(d_in, in48, (size_t)n * 48, hipMemcpyHostToDevice, st));
+  {
+    ProfScope ps(ctx, PROF_DECODE, st);
+    hipLaunchKernelGGL(k_g1_decompress_public, dim3(blocks_for(n, 64)), dim3(64), 0, st, d_in, n, d_out, d_st);
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(out_affine96, d_out, (size_t)n * 96, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(status, d_st, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return 0;
+}
+
 extern "C" int32_t kzg_verify_phase2_dev(kzg_verify_session* s, const uint8_t* roots32, uint64_t world, uint64_t first_index, uint64_t n_total,
                                          uint8_t* out192) {
   if (!s || !roots32 || !out192 || world == 0) return fail(KZG_FAIL_ARGUMENT, "null argument");

@@ -9,6 +9,7 @@
 //   blob_proof(blob, commitment)         <- src/kzg/setup.rs:177-183
 //   proof(blob, z)                       <- src/kzg/setup.rs:185-194
 //   verify_proof(proof, commitment, z, y)<- src/kzg/setup.rs:96-113
+//   decompress(bytes48) -> P1            <- P1::decompress, src/bls.rs:505-531
 //   verify_blob_proof(blob, c, p)        <- src/kzg/setup.rs:208-221
 //   verify_blob_proof_batch(blobs,cs,ps) <- src/kzg/setup.rs:247-275
 //   Blob::{from_slice,to_bytes,random}   <- src/blob.rs:26-46,66-76
@@ -289,6 +290,17 @@ class Setup {
     check(kzg_compute_proof_batch_affine(ctx_.get(), blob, point.data(), 1, pi.affine.data(), y.data(), &status), "kzg_compute_proof_batch_affine");
     if (status) throw Error(static_cast<ErrorKind>(status));
     return {pi, y};
+  }
+
+  // `P1::decompress` (the crate's `Decompress` trait on Commitment / Proof, src/bls.rs:505-531): decode + on-curve + subgroup
+  // check of one point on the engine; throws the reference's ECGroupError for a rejected encoding
+  P1 decompress(const Bytes48& in) const {
+    P1 out;
+    int32_t status = 0;
+    int32_t rc = kzg_g1_decompress_batch(ctx_.get(), in.data(), 1, out.affine.data(), &status);
+    if (rc < 0) throw EngineFailure("kzg_g1_decompress_batch", rc);
+    if (status) throw Error(static_cast<ErrorKind>(status));
+    return out;
   }
 
   bool verify_proof(const Bytes48& proof, const Bytes48& commitment, const Bytes32& point, const Bytes32& eval) const {

@@ -20,7 +20,7 @@ from __future__ import annotations
 import ctypes
 import json
 import os
-from typing import Optional, Sequence
+from typing import List, Optional, Sequence, Tuple
 
 BYTES_PER_BLOB = 131072
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -129,6 +129,7 @@ _SIGNATURES = {
     "kzg_verify_blob_proof_batch_dev": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, _i32p, ctypes.c_void_p]),
     "kzg_verify_blob_proof": (ctypes.c_int32, [ctypes.c_void_p, _u8p, _u8p, _u8p, _i32p]),
     "kzg_verify_proof": (ctypes.c_int32, [ctypes.c_void_p, _u8p, _u8p, _u8p, _u8p, _i32p]),
+    "kzg_g1_decompress_batch": (ctypes.c_int32, [ctypes.c_void_p, _u8p, ctypes.c_uint64, _u8p, _i32p]),
     "kzg_verify_phase1_dev": (
         ctypes.c_int32,
         [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, _u8p, _i32p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p],
@@ -524,6 +525,29 @@ class Setup:
         if status[0]:
             raise _kzg_error(status[0])
         return proofs, ys
+
+    def decompress_g1_batch(self, points48) -> Tuple[List["P1"], List[int]]:
+        """`P1::decompress` (the crate's `Decompress` trait on `Commitment` / `Proof`, src/bls.rs:505-531) for a list (or a
+        concatenation) of 48-byte encodings: the points and the per-point status (0 or an ECGroupError code)."""
+        data = b"".join(points48) if isinstance(points48, (list, tuple)) else _buf(points48)
+        if len(data) % 48:
+            raise KzgError(BlsError(ECGroupError("InvalidEncoding")))
+        n = len(data) // 48
+        out = (ctypes.c_uint8 * (96 * max(n, 1)))()
+        status = (ctypes.c_int32 * max(n, 1))()
+        rc = self._lib.kzg_g1_decompress_batch(self._h, data, n, out, status)
+        self._check(rc, "kzg_g1_decompress_batch")
+        raw = bytes(out)
+        return [P1(raw[96 * i:96 * i + 96]) for i in range(n)], list(status)[:n]
+
+    def decompress_g1(self, point48: bytes) -> "P1":
+        """one point; raises the reference's error (`bls::Error::ECGroup(..)`) for a rejected encoding"""
+        if len(point48) != 48:
+            raise BlsError(ECGroupError("InvalidEncoding"))
+        pts, st = self.decompress_g1_batch(point48)
+        if st[0]:
+            raise BlsError(error_from_status(st[0]))
+        return pts[0]
 
     def verify_proof(self, proof: bytes, commitment: bytes, point: bytes, evaluation: bytes) -> bool:
         proof, commitment, point, evaluation = _buf(proof), _buf(commitment), _buf(point), _buf(evaluation)

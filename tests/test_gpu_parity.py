@@ -1194,6 +1194,39 @@ def test_point_returning_methods_match_the_byte_returning_ones(engine, golden):
     assert engine.verify_blob_proof(rb.to_bytes(), c48, p48) is True
 
 
+def test_public_g1_decompress_matches_the_oracle(engine, golden, oracle_setup):
+    """kzg_g1_decompress_batch = `P1::decompress` (src/bls.rs:505-531) for a batch: golden commitments and proofs, the
+    generator, infinity and each rejection class against the oracle's decoder -- the accepted points as blst_p1_affine images
+    (x || y, little-endian limbs of the 2^384-Montgomery residue), the rejected ones with the reference's error code"""
+    import kateth_amd
+    from oracle.pyref import bls
+
+    P = bls.P
+    good = [bytes.fromhex(r["commitment"]) for r in golden["blobs"]] + [bytes.fromhex(r["proof"]) for r in golden["blobs"]] + [GEN48, INF48]
+    x_off_curve = next(x for x in range(1, 200) if pow((x ** 3 + 4) % P, (P - 1) // 2, P) != 1)
+    # an on-curve point outside the subgroup: x = 4 has y^2 = 68, a square; (4, y) has large cofactor order
+    x_on = next(x for x in range(1, 200) if pow((x ** 3 + 4) % P, (P - 1) // 2, P) == 1 and not bls.g1_in_subgroup((x, pow((x ** 3 + 4) % P, (P + 1) // 4, P))))
+    enc = lambda x, flags=0x80: bytes([x.to_bytes(48, "big")[0] | flags]) + x.to_bytes(48, "big")[1:]  # noqa: E731
+    bad = [bytes([GEN48[0] & 0x7F]) + GEN48[1:],  # compression bit clear -> InvalidEncoding
+           enc(P),                                  # x >= p -> InvalidEncoding
+           bytes([0xC0]) + bytes(46) + b"\x01",     # infinity flag with a non-zero tail -> InvalidEncoding
+           enc(x_off_curve),                        # no square root -> NotOnCurve
+           enc(x_on)]                               # on the curve, not in the subgroup -> NotInGroup
+    pts, st = engine.decompress_g1_batch(good + bad)
+    assert st == [0] * len(good) + [3, 3, 3, 4, 5]
+    for b, pt in zip(good, pts):
+        want = bls.g1_decompress(b)
+        if want is None:
+            assert pt.is_inf()
+        else:
+            assert int.from_bytes(pt.affine[:48], "little") == want[0] * (1 << 384) % P and int.from_bytes(pt.affine[48:], "little") == want[1] * (1 << 384) % P
+        assert pt.compress() == b
+    assert all(p.is_inf() for p in pts[len(good):])
+    assert engine.decompress_g1(GEN48).compress() == GEN48
+    with pytest.raises(kateth_amd.BlsError, match="NotInGroup"):
+        engine.decompress_g1(bad[4])
+
+
 def test_load_setup_rejects_bad_points_with_the_reference_error():
     """Setup::load_json maps a rejected point to LoadSetupError::Bls(ECGroup(..)) (src/kzg/setup.rs:59-72): the engine
     reports which class through kzg_last_error_code"""
