@@ -91,7 +91,10 @@ KZG_HD void f29_to_canonical_bn(fr_t& r, const fr29& a) {
   canonicalize<FrParams>(r);
 }
 
-// k_eval_frac's per-pair table entry: { w R, w R^2, w^2 R } = 27 limbs, padded to seven 16-byte loads
-constexpr int EVAL_TAB_DWORDS = 28;
+// k_eval_frac's per-QUAD table entry (elements 4q .. 4q+3 sit at the roots w, -w, iw, -iw): { w R, w R^2, (iw) R, (iw) R^2,
+// w^2 R, w^4 R }: six slots of 9 limbs, each padded to 12 dwords (three 16-byte loads, fetched where it is used)
+constexpr int EVAL_TAB_SLOT = 12;
+constexpr int EVAL_TAB_DWORDS = 6 * EVAL_TAB_SLOT;
+constexpr int EVAL_TAB_QUADS = 1024;
 
 }  // namespace kzg

@@ -108,12 +108,13 @@ static __global__ __launch_bounds__(64) void k_setup_sum_bases(const uint4* __re
   }
 }
 
-// one thread per pair: builds eval_tab from the Montgomery (radix 2^256) roots
+// one thread per quad: builds eval_tab from the Montgomery (radix 2^256) roots.  In bit-reversed order elements 4q .. 4q+3 sit
+// at w, -w, w', -w' with w = roots_brp[4q] and w' = roots_brp[4q+2] = i w (i = the primitive 4th root of unity).
 static __global__ __launch_bounds__(64) void k_setup_eval_tab(const fr_t* __restrict__ roots_brp, uint32_t* __restrict__ eval_tab) {
-  const uint32_t pr = blockIdx.x * blockDim.x + threadIdx.x;
-  if (pr >= 2048) return;
-  const fr_t w = roots_brp[2 * pr];
-  fr_t c261, c522, t;
+  const uint32_t qd = blockIdx.x * blockDim.x + threadIdx.x;
+  if (qd >= (uint32_t)EVAL_TAB_QUADS) return;
+  const fr_t w = roots_brp[4 * qd], w2 = roots_brp[4 * qd + 2];
+  fr_t c261, c522, t, sq;
   {
     const uint32_t a[8] = KZG_FR_R261_PLAIN, b[8] = KZG_FR_R522_PLAIN;
 #pragma unroll
@@ -122,22 +123,29 @@ static __global__ __launch_bounds__(64) void k_setup_eval_tab(const fr_t* __rest
       c522.v[q] = b[q];
     }
   }
-  fr29 o;
-  uint32_t* out = eval_tab + (uint64_t)pr * EVAL_TAB_DWORDS;
+  uint32_t* out = eval_tab + (uint64_t)qd * EVAL_TAB_DWORDS;
+  auto put = [&](int slot, const fr_t& v) {  // canonical value -> 9 strictly normalised limbs
+    fr29 o;
+    f29_from_bn(o, v);
+#pragma unroll
+    for (int q = 0; q < F29_N; q++) out[EVAL_TAB_SLOT * slot + q] = o.l[q];
+#pragma unroll
+    for (int q = F29_N; q < EVAL_TAB_SLOT; q++) out[EVAL_TAB_SLOT * slot + q] = 0;
+  };
   fr_mul(t, w, c261);  // (w 2^256)(2^261) / 2^256 = w 2^261
-  f29_from_bn(o, t);
-#pragma unroll
-  for (int q = 0; q < F29_N; q++) out[q] = o.l[q];
-  fr_mul(t, w, c522);
-  f29_from_bn(o, t);
-#pragma unroll
-  for (int q = 0; q < F29_N; q++) out[9 + q] = o.l[q];
-  fr_sqr(t, w);
-  fr_mul(t, t, c261);
-  f29_from_bn(o, t);
-#pragma unroll
-  for (int q = 0; q < F29_N; q++) out[18 + q] = o.l[q];
-  out[27] = 0;
+  put(0, t);
+  fr_mul(t, w, c522);  // w R^2
+  put(1, t);
+  fr_mul(t, w2, c261);
+  put(2, t);
+  fr_mul(t, w2, c522);
+  put(3, t);
+  fr_sqr(sq, w);       // w^2 (Montgomery 2^256)
+  fr_mul(t, sq, c261);
+  put(4, t);
+  fr_sqr(sq, sq);      // w^4
+  fr_mul(t, sq, c261);
+  put(5, t);
 }
 
 // roots_of_unity_brp (src/math.rs:16-29 + BRP, src/kzg/setup.rs:74-75), Montgomery form.

@@ -21,14 +21,16 @@ namespace kzg {
 // barycentric factor and y = N / 4096: the whole evaluation needs no inversion.
 // ---------------------------------------------------------------------------
 // The arithmetic runs in the carry-free radix-2^29 representation of Fr (fr29.cuh, Montgomery radix R = 2^261).
-// Bit-reversed order puts w and -w next to each other (roots_brp[2k+1] = -roots_brp[2k]), so a PAIR of elements
-// contributes
-//   e0 w/(z - w) - e1 w/(z + w) = w [ (e0 - e1) z + (e0 + e1) w ] / (z^2 - w^2)
-// and per pair the kernel does 6 products with only 4 reductions:
-//   u  = ((e0 - e1) * zR + (e0 + e1) * wR) / R           plain, one reduction for two products
-//   a  = (u * wR^2) / R = (u w) R                         Montgomery
-//   N' = (N * d + a * D) / R,  D' = (D * d) / R           d = z^2 R - w^2 R (a limb-wise subtraction)
-// eval_tab[pr] = { w R, w R^2, w^2 R } as 3 x 9 limbs (28 dwords with padding), w = roots_brp[2 pr].
+// Bit-reversed order puts FOUR related roots next to each other: elements 4q .. 4q+3 sit at w, -w, w', -w' with w' = i w.
+// A pair contributes
+//   e0 w/(z - w) - e1 w/(z + w) = w [ (e0 - e1) z + (e0 + e1) w ] / (z^2 - w^2) = a / d
+// and the quad  a/d + a'/d'  with  d = z^2 - w^2,  d' = z^2 - w'^2 = z^2 + w^2,  d d' = z^4 - w^4  (a limb-wise subtraction
+// from the table's w^4: no product).  Per quad the kernel does 11 products with 7 reductions (per pair it was 6 with 4):
+//   u  = ((e0 - e1) * zR + (e0 + e1) * wR) / R            plain, one reduction for two products
+//   a  = (u * wR^2) / R = (u w) R                          Montgomery              (likewise u', a' with w')
+//   A  = (a * d' + a' * d) / R                             the quad's numerator, one reduction for two products
+//   N' = (N * dd + A * D) / R,  D' = (D * dd) / R          dd = z^4 R - w^4 R
+// eval_tab[q] = { w R, w R^2, w' R, w' R^2, w^2 R, w^4 R }: six 9-limb slots padded to 12 dwords, w = roots_brp[4 q].
 template <int G>
 __device__ __forceinline__ fr29 shfl_down_fr29(const fr29& a, int delta) {
   fr29 r;
@@ -36,27 +38,72 @@ __device__ __forceinline__ fr29 shfl_down_fr29(const fr29& a, int delta) {
   for (int q = 0; q < F29_N; q++) r.l[q] = __shfl_down(a.l[q], delta, G);
   return r;
 }
-// G lanes work on one blob (64 / G blobs per wave).  G = 64 has the shortest latency (32 pairs per lane); G = 16 does
-// 128 pairs per lane and a 4-level merge instead of 32 pairs and a 6-level one -- the merge is 11 % of a wave's work
+__device__ __forceinline__ void eval_load_element(fr_t& e, const uint4& hi, const uint4& lo, bool& bad) {  // 32 big-endian bytes -> 8 little-endian limbs
+  e.v[7] = __builtin_bswap32(hi.x); e.v[6] = __builtin_bswap32(hi.y); e.v[5] = __builtin_bswap32(hi.z); e.v[4] = __builtin_bswap32(hi.w);
+  e.v[3] = __builtin_bswap32(lo.x); e.v[2] = __builtin_bswap32(lo.y); e.v[1] = __builtin_bswap32(lo.z); e.v[0] = __builtin_bswap32(lo.w);
+  if (!fr_is_canonical(e)) {
+    bad = true;
+    bn_zero(e);
+  }
+}
+// one 9-limb slot of a quad's table entry (three 16-byte loads)
+__device__ __forceinline__ void eval_tab_slot(fr29& o, const uint32_t* __restrict__ entry, int slot) {
+  const uint4* t = reinterpret_cast<const uint4*>(entry + slot * EVAL_TAB_SLOT);
+  const uint4 t0 = t[0], t1 = t[1], t2 = t[2];
+  o.l[0] = t0.x; o.l[1] = t0.y; o.l[2] = t0.z; o.l[3] = t0.w;
+  o.l[4] = t1.x; o.l[5] = t1.y; o.l[6] = t1.z; o.l[7] = t1.w;
+  o.l[8] = t2.x;
+}
+// a = w [ (e0 - e1) z + (e0 + e1) w ] R for one pair (Montgomery, N-form)
+__device__ __forceinline__ void eval_pair_numerator(fr29& a, const fr_t& e0, const fr_t& e1, const fr29& z, const fr29& w, const fr29& wr2) {
+  fr29 x0, x1, sm, df, u;
+  f29_from_bn(x0, e0);
+  f29_from_bn(x1, e1);
+  f29_add(sm, x0, x1);        // limbs < 2^30, value < 2r
+  f29_sub_2r(df, x0, x1);     // limbs < 3*2^29, value < 3r
+  f29_mul2(u, df, z, sm, w);  // 9*(3 + 2)*2^58 + 9*2^58 = 54*2^58 < 2^64;  plain (e0-e1) z + (e0+e1) w
+  f29_mul(a, u, wr2);
+}
+// G lanes work on one blob (64 / G blobs per wave).  G = 64 has the shortest latency (16 quads per lane); G = 16 does
+// 64 quads per lane and a 4-level merge instead of 16 quads and a 6-level one -- the merge is 11 % of a wave's work
 // at G = 64, 2 % at G = 16 -- and is used when the batch fills the chip.
 template <int G>
-static __global__ __launch_bounds__(64) void k_eval_frac(const uint8_t* __restrict__ blobs, const fr_t* __restrict__ z_plain,
+static __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_eval_frac(const uint8_t* __restrict__ blobs, const fr_t* __restrict__ z_plain,
                                                          const fr_t* __restrict__ roots_brp, const uint32_t* __restrict__ eval_tab,
                                                          fr_t* __restrict__ y_plain, int32_t* __restrict__ status, uint64_t n) {
-  constexpr int PER_LANE = 2048 / G;  // pairs per lane
+  constexpr int PER_LANE = EVAL_TAB_QUADS / G;  // quads per lane
   const int lane = threadIdx.x % G;   // position inside the blob's group
   const int group = threadIdx.x / G;
   uint64_t b = (uint64_t)blockIdx.x * (64 / G) + group;
   const bool live = b < n;
   if (!live) b = n - 1;  // idle groups shadow the last blob (they take part in the shuffles, never store)
   const uint8_t* blob = blobs + b * 131072ull;
-  fr29 z, z2;
+  // z stays in registers (two products per pair); z^2 and z^4 are read once per quad and live in LDS (one copy per blob
+  // group of the wave) -- with the pair-sized prefetch below that keeps the kernel at three waves per SIMD
+  __shared__ uint32_t zpow[64 / G][2][12];
+  fr29 z;
   {
-    fr29 zp;
+    fr29 zp, z2, z4;
     f29_from_bn(zp, z_plain[b]);
     f29_to_mont(z, zp);  // N-form
     f29_sqr(z2, z);
+    f29_sqr(z4, z2);
+    if (lane == 0) {
+#pragma unroll
+      for (int q = 0; q < F29_N; q++) {
+        zpow[group][0][q] = z2.l[q];
+        zpow[group][1][q] = z4.l[q];
+      }
+    }
   }
+  __syncthreads();
+  auto load_zpow = [&](fr29& o, int which) {
+    const uint4* t = reinterpret_cast<const uint4*>(&zpow[group][which][0]);
+    const uint4 t0 = t[0], t1 = t[1], t2 = t[2];
+    o.l[0] = t0.x; o.l[1] = t0.y; o.l[2] = t0.z; o.l[3] = t0.w;
+    o.l[4] = t1.x; o.l[5] = t1.y; o.l[6] = t1.z; o.l[7] = t1.w;
+    o.l[8] = t2.x;
+  };
   // lane fraction N/D: both N-form between steps
   fr29 N, D = f29_const_one();
   KZG_UNROLL_FULL
@@ -65,78 +112,78 @@ static __global__ __launch_bounds__(64) void k_eval_frac(const uint8_t* __restri
   bn_zero(e_dom);
   bool bad = false;
   int dom = -1;
-  // the blob elements come from HBM (each byte is read exactly once): the next pair is in flight while this one is
-  // processed; the table entry is L2-resident and loaded where it is used
+  // the blob elements come from HBM (each byte is read exactly once): the next PAIR (64 contiguous bytes) is in flight while
+  // this one is processed; the table slots are L2-resident and loaded where they are used (short live ranges)
   uint4 nb0, nb1, nb2, nb3;
   {
-    const uint4* src = reinterpret_cast<const uint4*>(blob + (uint64_t)lane * 64u);  // pair `lane` of the blob
-    nb0 = src[0];
-    nb1 = src[1];
-    nb2 = src[2];
-    nb3 = src[3];
+    const uint4* src = reinterpret_cast<const uint4*>(blob + (uint64_t)lane * 128u);  // first pair of quad `lane`
+    nb0 = src[0]; nb1 = src[1]; nb2 = src[2]; nb3 = src[3];
   }
 #pragma unroll 1
   for (int k = 0; k < PER_LANE; k++) {
-    const int pr = k * G + lane;  // pair index: elements 2*pr, 2*pr + 1 (64 contiguous bytes)
-    const uint4 b0 = nb0, b1 = nb1, b2 = nb2, b3 = nb3;
-    if (k + 1 < PER_LANE) {
-      const uint4* src = reinterpret_cast<const uint4*>(blob + (uint64_t)(pr + G) * 64u);
-      nb0 = src[0];
-      nb1 = src[1];
-      nb2 = src[2];
-      nb3 = src[3];
-    }
-    fr_t e0, e1;  // 32 big-endian bytes -> 8 little-endian limbs
-    e0.v[7] = __builtin_bswap32(b0.x); e0.v[6] = __builtin_bswap32(b0.y); e0.v[5] = __builtin_bswap32(b0.z); e0.v[4] = __builtin_bswap32(b0.w);
-    e0.v[3] = __builtin_bswap32(b1.x); e0.v[2] = __builtin_bswap32(b1.y); e0.v[1] = __builtin_bswap32(b1.z); e0.v[0] = __builtin_bswap32(b1.w);
-    e1.v[7] = __builtin_bswap32(b2.x); e1.v[6] = __builtin_bswap32(b2.y); e1.v[5] = __builtin_bswap32(b2.z); e1.v[4] = __builtin_bswap32(b2.w);
-    e1.v[3] = __builtin_bswap32(b3.x); e1.v[2] = __builtin_bswap32(b3.y); e1.v[1] = __builtin_bswap32(b3.z); e1.v[0] = __builtin_bswap32(b3.w);
-    if (!fr_is_canonical(e0)) {
-      bad = true;
-      bn_zero(e0);
-    }
-    if (!fr_is_canonical(e1)) {
-      bad = true;
-      bn_zero(e1);
-    }
-    fr29 w, wr2, wsq;
+    const int qd = k * G + lane;  // quad index: elements 4 qd .. 4 qd + 3
+    const uint32_t* tab = eval_tab + (uint64_t)qd * EVAL_TAB_DWORDS;
+    fr29 dd;
     {
-      const uint4* t = reinterpret_cast<const uint4*>(eval_tab + (uint64_t)pr * EVAL_TAB_DWORDS);
-      const uint4 t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3], t4 = t[4], t5 = t[5], t6 = t[6];
-      const uint32_t f[28] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w, t2.x, t2.y, t2.z, t2.w, t3.x, t3.y,
-                              t3.z, t3.w, t4.x, t4.y, t4.z, t4.w, t5.x, t5.y, t5.z, t5.w, t6.x, t6.y, t6.z, t6.w};
-#pragma unroll
-      for (int q = 0; q < F29_N; q++) {
-        w.l[q] = f[q];
-        wr2.l[q] = f[9 + q];
-        wsq.l[q] = f[18 + q];
-      }
+      fr29 w4, z4;
+      eval_tab_slot(w4, tab, 5);
+      load_zpow(z4, 1);
+      f29_sub_2r(dd, z4, w4);  // z^4 - w^4: limbs < 3*2^29, value < 4r
     }
-    fr29 d;
-    f29_sub_2r(d, z2, wsq);  // z^2 - w^2: limbs < 3*2^29, value < 4r
-    if (f29_maybe_zero(d)) {
-      if (f29_is_zero_exact(d)) {  // z == w or z == -w: the evaluation is that element (poly.rs:14-18)
-        fr29 t;
-        f29_sub_2r(t, z, w);
-        if (f29_is_zero_exact(t)) {
-          dom = 2 * pr;
-          e_dom = e0;
-        } else {
-          dom = 2 * pr + 1;
-          e_dom = e1;
-        }
-        continue;
-      }
+    bool in_domain = false;
+    if (f29_maybe_zero(dd)) in_domain = f29_is_zero_exact(dd);
+    fr29 a, ap;
+    {  // pair 1 (roots w, -w); the quad's second pair is fetched meanwhile
+      fr_t e0, e1;
+      eval_load_element(e0, nb0, nb1, bad);
+      eval_load_element(e1, nb2, nb3, bad);
+      const uint4* src = reinterpret_cast<const uint4*>(blob + (uint64_t)qd * 128u + 64u);
+      nb0 = src[0]; nb1 = src[1]; nb2 = src[2]; nb3 = src[3];
+      fr29 w, wr2;
+      eval_tab_slot(w, tab, 0);
+      eval_tab_slot(wr2, tab, 1);
+      eval_pair_numerator(a, e0, e1, z, w, wr2);
     }
-    fr29 x0, x1, sm, df, u, a;
-    f29_from_bn(x0, e0);
-    f29_from_bn(x1, e1);
-    f29_add(sm, x0, x1);      // limbs < 2^30, value < 2r
-    f29_sub_2r(df, x0, x1);   // limbs < 3*2^29, value < 3r
-    f29_mul2(u, df, z, sm, w);  // 9*(3 + 2)*2^58 + 9*2^58 = 54*2^58 < 2^64;  plain (e0-e1) z + (e0+e1) w
-    f29_mul(a, u, wr2);
-    f29_mul2(N, N, d, a, D);  // 9*(3 + 1)*2^58 + 9*2^58
-    f29_mul(D, D, d);
+    {  // pair 2 (roots w', -w'); the next quad's first pair is fetched meanwhile
+      fr_t e2, e3;
+      eval_load_element(e2, nb0, nb1, bad);
+      eval_load_element(e3, nb2, nb3, bad);
+      if (k + 1 < PER_LANE) {
+        const uint4* src = reinterpret_cast<const uint4*>(blob + (uint64_t)(qd + G) * 128u);
+        nb0 = src[0]; nb1 = src[1]; nb2 = src[2]; nb3 = src[3];
+      }
+      fr29 wp, wpr2;
+      eval_tab_slot(wp, tab, 2);
+      eval_tab_slot(wpr2, tab, 3);
+      eval_pair_numerator(ap, e2, e3, z, wp, wpr2);
+    }
+    if (in_domain) {  // z is one of w, -w, w', -w': the evaluation is that element (poly.rs:14-18); rare: the element is re-read
+      fr29 w, wp, t;
+      eval_tab_slot(w, tab, 0);
+      eval_tab_slot(wp, tab, 2);
+      f29_sub_2r(t, z, w);
+      const bool is0 = f29_is_zero_exact(t);
+      f29_add(t, z, w);
+      const bool is1 = f29_is_zero_exact(t);
+      f29_sub_2r(t, z, wp);
+      const bool is2 = f29_is_zero_exact(t);
+      dom = 4 * qd + (is0 ? 0 : (is1 ? 1 : (is2 ? 2 : 3)));
+      const uint4* src = reinterpret_cast<const uint4*>(blob + (uint64_t)dom * 32u);
+      bool dummy = false;
+      eval_load_element(e_dom, src[0], src[1], dummy);
+      continue;
+    }
+    fr29 A;
+    {
+      fr29 wsq, z2, d, dp;
+      eval_tab_slot(wsq, tab, 4);
+      load_zpow(z2, 0);
+      f29_sub_2r(d, z2, wsq);  // z^2 - w^2: limbs < 3*2^29, value < 4r
+      f29_add(dp, z2, wsq);    // z^2 + w^2 = z^2 - w'^2: limbs < 2^30, value < 3r
+      f29_mul2(A, a, dp, ap, d);  // 9*(2 + 3)*2^58 + 9*2^58 < 2^64;  value 2*3 + 2*4 = 14 < 2^6
+    }
+    f29_mul2(N, N, dd, A, D);  // 9*(3 + 1)*2^58 + 9*2^58
+    f29_mul(D, D, dd);
   }
   // merge lane fractions: (N1/D1) + (N2/D2) = (N1 D2 + N2 D1) / (D1 D2)
 #pragma unroll 1
@@ -151,11 +198,11 @@ static __global__ __launch_bounds__(64) void k_eval_frac(const uint8_t* __restri
     const int o = __shfl_xor(dom_any, delta, G);
     dom_any = o > dom_any ? o : dom_any;
   }
-  // The merged denominator is prod_k (z^2 - w_k^2) = z^4096 - 1 exactly, so
+  // The merged denominator is prod_q (z^4 - w_q^4) = z^4096 - 1 exactly, so
   //   y = (N / D) * (z^4096 - 1) / 4096 = N / 4096          -- no inversion at all.
   fr_t y;
   if (dom_any >= 0) {
-    const int owner = (dom_any >> 1) % G;  // pair index pr = k*G + lane
+    const int owner = (dom_any >> 2) % G;  // quad index qd = k*G + lane
 #pragma unroll
     for (int q = 0; q < 8; q++) y.v[q] = __shfl(e_dom.v[q], owner, G);  // already plain
   } else {
