@@ -231,6 +231,7 @@ static __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)
 static __global__ __launch_bounds__(256) void k_transcript_leaves(const uint8_t* __restrict__ commitments48, const uint8_t* __restrict__ proofs48,
                                                           const fr_t* __restrict__ z_plain, const fr_t* __restrict__ y_plain, uint64_t n,
                                                           uint32_t* __restrict__ leaves /* n x 8 words, big-endian word values */) {
+  issue_priority_latency();  // short kernels in the shadow of the point decoder (whose waves trade priorities 3 / 1)
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t m[40];  // 160 bytes as big-endian words
@@ -262,6 +263,7 @@ static __global__ __launch_bounds__(256) void k_transcript_leaves(const uint8_t*
 }
 
 static __global__ __launch_bounds__(64) void k_transcript_nodes(const uint32_t* __restrict__ leaves, uint64_t n, uint32_t* __restrict__ nodes) {
+  issue_priority_latency();
   const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t groups = (n + 255) / 256;
   if (g >= groups) return;
