@@ -775,6 +775,45 @@ def test_host_buffer_commitment_chunk_plans(engine, torch_cuda):
         assert got == want[: 48 * m], m
 
 
+def test_host_buffer_proof_passes_match_the_device_path(engine, torch_cuda):
+    """kzg_compute_blob_proof_batch above 5,120 blobs walks the batch in double-buffered passes (1,024, then 4,096s, then the
+    rest; the copy of pass k+1 beside the device path on pass k): 5,300 blobs = passes of 1,024 + 4,096 + 180, an invalid blob
+    and an undecodable commitment in different passes, against the device-pointer entry point; also compute_kzg_proof (z given)
+    through the same passes"""
+    torch = torch_cuda
+    n = 5300
+    d_blobs = torch.empty(n * 131072, dtype=torch.uint8, device="cuda")
+    engine.synth_blobs_dev(0x9A55, 5, n, d_blobs.data_ptr())
+    d_blobs[3000 * 131072 + 32 * 9: 3000 * 131072 + 32 * 9 + 32] = 0xFF  # blob 3000 (second pass), element 9: not canonical
+    d_c = torch.empty(n * 48, dtype=torch.uint8, device="cuda")
+    d_p = torch.empty(n * 48, dtype=torch.uint8, device="cuda")
+    d_st = torch.empty(n, dtype=torch.int32, device="cuda")
+    engine.blob_to_commitment_batch_dev(d_blobs.data_ptr(), n, d_c.data_ptr(), d_st.data_ptr())
+    torch.cuda.synchronize()
+    d_c[3000 * 48: 3001 * 48] = d_c[0:48]          # a decodable commitment for the invalid blob
+    d_c[5250 * 48] = d_c[5250 * 48] & 0x7F         # third pass: compression bit cleared -> InvalidEncoding
+    engine.compute_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), n, d_p.data_ptr(), d_st.data_ptr())
+    torch.cuda.synchronize()
+    want, want_st = d_p.cpu().numpy().tobytes(), d_st.cpu().tolist()
+    assert want_st[3000] == 2 and want_st[5250] == 3 and sum(1 for v in want_st if v) == 2
+    host_blobs, host_c = d_blobs.cpu().numpy().tobytes(), d_c.cpu().numpy().tobytes()
+    got, got_st = engine.compute_blob_proof_batch(host_blobs, host_c)
+    assert got_st == want_st
+    assert got == want
+    # proofs at given points through the same passes: y and proof equal the blob-proof values when z is the blob's challenge
+    sess, _, _ = engine.verify_phase1_dev(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), 64)
+    z64, y64 = engine.verify_session_zy(sess, 0, 64)
+    engine.verify_session_destroy(sess)
+    m = 5200
+    zs = (z64 * (m // 64 + 1))[: 32 * m]
+    proofs, ys, st = engine.compute_proof_batch(host_blobs[: m * 131072], zs)
+    assert [k for k, v in enumerate(st) if v] == [3000] and st[3000] == 2
+    assert proofs[: 48 * 64] == want[: 48 * 64] and ys[: 32 * 64] == y64
+    # a blob in the last pass, checked through the single-item path
+    one_p, one_y, one_st = engine.compute_proof_batch(host_blobs[5199 * 131072: 5200 * 131072], zs[32 * 5199: 32 * 5200])
+    assert one_st == [0] and proofs[48 * 5199: 48 * 5200] == one_p and ys[32 * 5199: 32 * 5200] == one_y
+
+
 def test_mid_size_batches_take_the_unfused_preparation_path(engine, torch_cuda):
     """16,384 < n <= 32,768: the two-wave SHA-256 kernel runs on its own and the points are decoded on the side stream
     (smaller batches fuse the two, larger ones use the one-lane-per-blob hash); commit -> prove -> verify closes, a swapped
