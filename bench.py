@@ -66,6 +66,8 @@ def parse():
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary proof/verify workloads")
     ap.add_argument("--cpu-sample", type=int, default=0, help="blobs in the CPU baseline sample (0 = auto, ~10-30 s)")
     ap.add_argument("--no-live-traffic", action="store_true", help="do not run the two rocprofv3 --pmc child passes (FETCH_SIZE, WRITE_SIZE) that measure roofline.traffic in this run")
+    ap.add_argument("--dist-single", action="store_true", help="with --gpus 1: still create the process group (world size 1) and route the result gathers / the sharded "
+                    "verification through it -- exercises the RCCL calls of the N-rank path on a one-GPU box")
     ap.add_argument("--spawn", action="store_true", help="start the rank processes through this script's launcher even for --gpus 1 (checks the launcher against the direct path)")
     ap.add_argument("--rank-logs", default=os.path.join(ROOT, "gpurun_out", "bench_ranks"), help="launcher: directory for every rank's stdout/stderr (rank<k>.out / rank<k>.err)")
     ap.add_argument("--dry-run", action="store_true", help="print every rank's HBM plan for --workload/--batch/--gpus as one JSON line and exit non-zero if it cannot fit; touches no GPU")
@@ -352,8 +354,15 @@ class Rank:
 
         self.torch, self.dist, self.args = torch, dist, args
         self.rank, self.world = rank, world
-        if world > 1:
+        self.use_dist = world > 1 or args.dist_single  # --dist-single: a one-rank process group, same code path as N ranks
+        if self.use_dist:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if "MASTER_PORT" not in os.environ:  # --dist-single without a launcher: any free port
+                import socket
+
+                with socket.socket() as sk:
+                    sk.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             dist.init_process_group(args.backend, rank=rank, world_size=world)
         assert torch.cuda.is_available(), "bench.py needs an MI355X; the engine has no CPU fallback"
@@ -363,7 +372,7 @@ class Rank:
         self.local_dev = local_rank % max(1, ndev)  # ranks share a card only in the gloo rehearsal
         torch.cuda.set_device(self.local_dev)
         self.dev = torch.device("cuda", self.local_dev)
-        if world > 1:  # RCCL needs one GPU per rank: every rank of a host must sit on a card of its own
+        if self.use_dist:  # RCCL needs one GPU per rank: every rank of a host must sit on a card of its own
             import socket
 
             mine = (socket.gethostname(), torch.cuda.current_device(), getattr(torch.cuda.get_device_properties(self.local_dev), "pci_bus_id", -1))
@@ -416,7 +425,7 @@ class Rank:
         return d_out, d_status
 
     def verify(self, d_blobs, d_com, d_prf, n, first_index, n_total):
-        if self.world == 1:
+        if not self.use_dist:
             return self.setup.verify_blob_proof_batch_dev(d_blobs.data_ptr(), d_com.data_ptr(), d_prf.data_ptr(), n, self.stream)
         from kateth_amd import dist as kdist
 
@@ -425,7 +434,7 @@ class Rank:
                                                      self.rank, self.world, gather_dev, self.stream)
 
     def gather48(self, d_local, gathered):
-        if self.world == 1:
+        if not self.use_dist:
             return
         if self.args.backend == "nccl":
             self.dist.all_gather_into_tensor(gathered, d_local)  # RCCL over xGMI: 48 B per blob
@@ -435,7 +444,7 @@ class Rank:
             gathered.copy_(self.torch.cat(host))
 
     def fence(self):
-        if self.world > 1:
+        if self.use_dist:
             self.dist.barrier()
         self.torch.cuda.synchronize()
 
@@ -453,7 +462,7 @@ class Rank:
         elapsed = time.perf_counter() - t0
         prof = self.setup.profile_end()
         prof["calls"] = a.steps
-        if self.world > 1:
+        if self.use_dist:
             t = self.torch.tensor([elapsed], dtype=self.torch.float64, device=self.dev if a.backend == "nccl" else "cpu")
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
             elapsed = float(t.item())
@@ -554,7 +563,7 @@ def run_rank(args, rank, local_rank, world):
     d_blobs = R.make_blobs(n, first)
     d_out = torch.empty(n * 48, dtype=torch.uint8, device=R.dev)
     d_status = torch.empty(n, dtype=torch.int32, device=R.dev)
-    gathered = torch.empty(world * n * 48, dtype=torch.uint8, device=R.dev) if world > 1 else None
+    gathered = torch.empty(world * n * 48, dtype=torch.uint8, device=R.dev) if R.use_dist else None
     verdicts = []
 
     if wl == "commit":
@@ -586,7 +595,7 @@ def run_rank(args, rank, local_rank, world):
     gpu_out = d_out.cpu().numpy().tobytes() if rank == 0 else b""
     if rank == 0 and wl != "verify":
         check_golden(gpu_out, n, first, "commitment" if wl == "commit" else "proof")
-    if world > 1 and wl != "verify":  # rank-ordered gather = global blob order
+    if R.use_dist and wl != "verify":  # rank-ordered gather = global blob order
         assert bytes(gathered[rank * n * 48:(rank + 1) * n * 48].cpu().numpy().tobytes()) == d_out.cpu().numpy().tobytes()
 
     result = {
@@ -611,7 +620,7 @@ def run_rank(args, rank, local_rank, world):
             "window_bits": setup.window_bits,
             "table_gib": setup.table_bytes / 2**30,
             "parallelism": "blob-sharded x%d, %s" % (world, "RCCL all-gather of 48-B results" if wl != "verify" else "all-gather of 32-B transcript roots + 192-B partial sums, one pairing"),
-            "backend": args.backend if world > 1 else None,
+            "backend": args.backend if R.use_dist else None,
             "setup_s": R.t_setup,
             "plane_groups": setup.plane_groups,
             "hbm_plan_gib": {k: round(v / GIB, 2) for k, v in R.plan.items() if k in ("table", "blobs", "workspace", "resident_total", "peak_total", "hbm_total")},
@@ -678,7 +687,7 @@ def run_rank(args, rank, local_rank, world):
                 roof["traffic_live_error"] = live.get("error")
         print(json.dumps(result), flush=True)
     setup.close()
-    if world > 1:
+    if R.use_dist:
         R.dist.barrier()
         R.dist.destroy_process_group()
 

@@ -1339,6 +1339,25 @@ def test_bench_rank_launcher_two_real_engine_ranks_on_one_card(workload):
         assert "GPUs visible" in errs or "share a GPU" in errs
 
 
+@pytest.mark.parametrize("workload", ["commit", "verify"])
+def test_bench_rccl_calls_with_a_one_rank_group(workload):
+    """`bench.py --gpus 1 --dist-single --backend nccl`: a ONE-rank process group over RCCL on the real GPU, so that the calls
+    the N-rank path makes -- init_process_group("nccl"), all_gather_object of the device seats, all_gather_into_tensor of the
+    48-byte results on the device, the all-gathers of dist.verify_blob_proof_batch_sharded, the MAX all-reduce of the elapsed
+    time, barrier -- execute against RCCL itself (every multi-rank run so far went through gloo: a one-GPU box)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--dist-single", "--backend", "nccl", "--workload", workload, "--batch", "256",
+           "--window-bits", "8", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extra", "--no-live-traffic"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    rec = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rec["n_gpus"] == 1 and rec["config"]["backend"] == "nccl" and rec["value"] > 0
+
+
 def test_bench_launcher_single_rank_matches_the_direct_run():
     """`bench.py --gpus 1 --spawn` goes through the launcher (child process, per-rank logs, relayed JSON line); its number must
     be the direct run's within noise -- the launcher adds nothing to the timed region"""
