@@ -47,6 +47,12 @@ __device__ __forceinline__ void eval_load_element(fr_t& e, const uint4& hi, cons
   }
 }
 // one 9-limb slot of a quad's table entry (three 16-byte loads)
+// keeps a value computed HERE: without it the compiler sinks the arithmetic (and with it the wait for the loads that feed it)
+// to the first use, behind the prefetch that must stay outstanding
+__device__ __forceinline__ void eval_pin(fr29& a) {
+  static_assert(F29_N == 9, "nine limbs");
+  asm volatile("" : "+v"(a.l[0]), "+v"(a.l[1]), "+v"(a.l[2]), "+v"(a.l[3]), "+v"(a.l[4]), "+v"(a.l[5]), "+v"(a.l[6]), "+v"(a.l[7]), "+v"(a.l[8]));
+}
 __device__ __forceinline__ void eval_tab_slot(fr29& o, const uint32_t* __restrict__ entry, int slot) {
   const uint4* t = reinterpret_cast<const uint4*>(entry + slot * EVAL_TAB_SLOT);
   const uint4 t0 = t[0], t1 = t[1], t2 = t[2];
@@ -111,7 +117,7 @@ static __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)
   fr_t e_dom;
   bn_zero(e_dom);
   bool bad = false;
-  int dom = -1;
+  int dom = -1, dom_q = -1;
   // the blob elements come from HBM (each byte is read exactly once): the next PAIR (64 contiguous bytes) is in flight while
   // this one is processed; the table slots are L2-resident and loaded where they are used (short live ranges)
   uint4 nb0, nb1, nb2, nb3;
@@ -132,58 +138,74 @@ static __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)
     }
     bool in_domain = false;
     if (f29_maybe_zero(dd)) in_domain = f29_is_zero_exact(dd);
+    // Loads return in issue order, so the wait for a table slot also waits for every load issued before it: the table slots
+    // of a step are therefore issued FIRST and the blob prefetch LAST (pinned with sched_barrier) -- the prefetch then stays
+    // in flight for a whole pair step instead of being drained by the next table access a few dozen instructions later.
     fr29 a, ap;
     {  // pair 1 (roots w, -w); the quad's second pair is fetched meanwhile
+      fr29 w, wr2;
+      eval_tab_slot(w, tab, 0);
+      eval_tab_slot(wr2, tab, 1);
+      __builtin_amdgcn_sched_barrier(0);
       fr_t e0, e1;
       eval_load_element(e0, nb0, nb1, bad);
       eval_load_element(e1, nb2, nb3, bad);
       const uint4* src = reinterpret_cast<const uint4*>(blob + (uint64_t)qd * 128u + 64u);
       nb0 = src[0]; nb1 = src[1]; nb2 = src[2]; nb3 = src[3];
-      fr29 w, wr2;
-      eval_tab_slot(w, tab, 0);
-      eval_tab_slot(wr2, tab, 1);
+      __builtin_amdgcn_sched_barrier(0);
       eval_pair_numerator(a, e0, e1, z, w, wr2);
     }
+    fr29 d, dp;
     {  // pair 2 (roots w', -w'); the next quad's first pair is fetched meanwhile
+      fr29 wp, wpr2;
+      {
+        fr29 wsq, z2;
+        eval_tab_slot(wp, tab, 2);
+        eval_tab_slot(wpr2, tab, 3);
+        eval_tab_slot(wsq, tab, 4);
+        load_zpow(z2, 0);
+        f29_sub_2r(d, z2, wsq);  // z^2 - w^2: limbs < 3*2^29, value < 4r   (every table value is consumed before the prefetch
+        f29_add(dp, z2, wsq);    // z^2 + w^2 = z^2 - w'^2: limbs < 2^30, value < 3r    is issued: nothing later waits on it)
+        eval_pin(d);
+        eval_pin(dp);
+      }
+      __builtin_amdgcn_sched_barrier(0);
       fr_t e2, e3;
       eval_load_element(e2, nb0, nb1, bad);
       eval_load_element(e3, nb2, nb3, bad);
-      if (k + 1 < PER_LANE) {
-        const uint4* src = reinterpret_cast<const uint4*>(blob + (uint64_t)(qd + G) * 128u);
+      {  // unconditional (a conditional load makes the compiler's wait counts pessimistic at the join): the last step re-reads
+         // the lane's first quad, which is in bounds and in L2
+        const int qn = (k + 1 < PER_LANE) ? qd + G : lane;
+        const uint4* src = reinterpret_cast<const uint4*>(blob + (uint64_t)qn * 128u);
         nb0 = src[0]; nb1 = src[1]; nb2 = src[2]; nb3 = src[3];
       }
-      fr29 wp, wpr2;
-      eval_tab_slot(wp, tab, 2);
-      eval_tab_slot(wpr2, tab, 3);
+      __builtin_amdgcn_sched_barrier(0);
       eval_pair_numerator(ap, e2, e3, z, wp, wpr2);
     }
-    if (in_domain) {  // z is one of w, -w, w', -w': the evaluation is that element (poly.rs:14-18); rare: the element is re-read
-      fr29 w, wp, t;
-      eval_tab_slot(w, tab, 0);
-      eval_tab_slot(wp, tab, 2);
-      f29_sub_2r(t, z, w);
-      const bool is0 = f29_is_zero_exact(t);
-      f29_add(t, z, w);
-      const bool is1 = f29_is_zero_exact(t);
-      f29_sub_2r(t, z, wp);
-      const bool is2 = f29_is_zero_exact(t);
-      dom = 4 * qd + (is0 ? 0 : (is1 ? 1 : (is2 ? 2 : 3)));
-      const uint4* src = reinterpret_cast<const uint4*>(blob + (uint64_t)dom * 32u);
-      bool dummy = false;
-      eval_load_element(e_dom, src[0], src[1], dummy);
+    if (in_domain) {  // z is one of this quad's four roots: resolved after the loop (no loads in here: a branch with loads makes
+      dom_q = qd;     // the compiler drain the prefetch at the join)
       continue;
     }
     fr29 A;
-    {
-      fr29 wsq, z2, d, dp;
-      eval_tab_slot(wsq, tab, 4);
-      load_zpow(z2, 0);
-      f29_sub_2r(d, z2, wsq);  // z^2 - w^2: limbs < 3*2^29, value < 4r
-      f29_add(dp, z2, wsq);    // z^2 + w^2 = z^2 - w'^2: limbs < 2^30, value < 3r
-      f29_mul2(A, a, dp, ap, d);  // 9*(2 + 3)*2^58 + 9*2^58 < 2^64;  value 2*3 + 2*4 = 14 < 2^6
-    }
+    f29_mul2(A, a, dp, ap, d);  // 9*(2 + 3)*2^58 + 9*2^58 < 2^64;  value 2*3 + 2*4 = 14 < 2^6
     f29_mul2(N, N, dd, A, D);  // 9*(3 + 1)*2^58 + 9*2^58
     f29_mul(D, D, dd);
+  }
+  if (dom_q >= 0) {  // rare (poly.rs:14-18): which of the quad's roots w, -w, w', -w' is z?  The evaluation is that element (re-read).
+    const uint32_t* tab = eval_tab + (uint64_t)dom_q * EVAL_TAB_DWORDS;
+    fr29 w, wp, t;
+    eval_tab_slot(w, tab, 0);
+    eval_tab_slot(wp, tab, 2);
+    f29_sub_2r(t, z, w);
+    const bool is0 = f29_is_zero_exact(t);
+    f29_add(t, z, w);
+    const bool is1 = f29_is_zero_exact(t);
+    f29_sub_2r(t, z, wp);
+    const bool is2 = f29_is_zero_exact(t);
+    dom = 4 * dom_q + (is0 ? 0 : (is1 ? 1 : (is2 ? 2 : 3)));
+    const uint4* src = reinterpret_cast<const uint4*>(blob + (uint64_t)dom * 32u);
+    bool dummy = false;
+    eval_load_element(e_dom, src[0], src[1], dummy);
   }
   // merge lane fractions: (N1/D1) + (N2/D2) = (N1 D2 + N2 D1) / (D1 D2)
 #pragma unroll 1
