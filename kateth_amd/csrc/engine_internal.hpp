@@ -261,12 +261,12 @@ static inline int32_t msm_finish(const kzg_ctx* ctx, uint64_t n, uint8_t* d_out4
   const uint64_t units = msm_units(n, splits, lpb);
   hipLaunchKernelGGL(k_msm_reduce, dim3((unsigned)units), dim3(64), 0, st, partials, units, lpb, unit_sums, lpb == 64 ? units : n);
   if (splits > 64) {  // latency shape (a few blobs over up to 256 units each): tree + constant term + encoding in one launch
-    hipLaunchKernelGGL((k_msm_reduce_splits<256, true>), dim3((unsigned)n), dim3(256), 0, st, unit_sums, splits, n, sums, d_status, d_out48, d_out_affine96);
+    hipLaunchKernelGGL((k_msm_reduce_splits<true>), dim3((unsigned)n), dim3(64), 0, st, unit_sums, splits, n, sums, d_status, d_out48, d_out_affine96);
     HIP_TRY(hipGetLastError());
     return 0;
   }
   if (splits > 1)
-    hipLaunchKernelGGL((k_msm_reduce_splits<64, false>), dim3((unsigned)n), dim3(64), 0, st, unit_sums, splits, n, sums, (const int32_t*)nullptr,
+    hipLaunchKernelGGL((k_msm_reduce_splits<false>), dim3((unsigned)n), dim3(64), 0, st, unit_sums, splits, n, sums, (const int32_t*)nullptr,
                        (uint8_t*)nullptr, (uint8_t*)nullptr);
   hipLaunchKernelGGL(k_g1_compress, dim3(blocks_for(n, 64)), dim3(64), 0, st, sums, n, d_status, d_out48, d_out_affine96);
   HIP_TRY(hipGetLastError());

@@ -326,8 +326,9 @@ KZG_HD void xyzz28_dbl_inl(g1_xyzz28& p) {
 }
 KZG_HD_NOINLINE void xyzz28_dbl(g1_xyzz28& p) { xyzz28_dbl_inl(p); }
 
-// p += q, both XYZZ accumulators under the invariant; complete   (add-2008-s)
-KZG_HD_NOINLINE void xyzz28_add_complete(g1_xyzz28& p, const g1_xyzz28& q) {
+// p += q, both XYZZ accumulators under the invariant; complete   (add-2008-s).  _inl: for the lane-sum trees, whose lone waves
+// would otherwise pass both operands through scratch memory on every level.
+KZG_HD void xyzz28_add_complete_inl(g1_xyzz28& p, const g1_xyzz28& q) {
   if (q.inf) return;
   if (p.inf) {
     p = q;
@@ -367,6 +368,7 @@ KZG_HD_NOINLINE void xyzz28_add_complete(g1_xyzz28& p, const g1_xyzz28& q) {
   f28_neg_4p(ns1, s1);
   f28_mul2(p.y, s2, pp, ns1, ppp);  // Y3 = R (Q - X3) - S1 PPP
 }
+KZG_HD_NOINLINE void xyzz28_add_complete(g1_xyzz28& p, const g1_xyzz28& q) { xyzz28_add_complete_inl(p, q); }
 
 // accumulator -> the 12 x 32-limb XYZZ format of g1.cuh (2^384 Montgomery, canonical)
 KZG_HD void xyzz28_to_xyzz(g1_xyzz& r, const g1_xyzz28& p) {

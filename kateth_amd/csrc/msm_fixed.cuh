@@ -91,10 +91,8 @@ static __global__ __launch_bounds__(64) void k_msm_reduce(const g1_xyzz* __restr
     if ((lane & m) == step) lds[lane >> 1] = acc;
     __syncthreads();
     if ((lane & m) == 0) {
-      g1_xyzz28 other = lds[(lane + step) >> 1];
-      g1_xyzz28 mine = acc;  // copies: the out-of-line adder takes addresses
-      xyzz28_add_complete(mine, other);
-      acc = mine;
+      const g1_xyzz28 other = lds[(lane + step) >> 1];
+      xyzz28_add_complete_inl(acc, other);
     }
     __syncthreads();
   }
@@ -130,15 +128,18 @@ __device__ __noinline__ void g1_finish_item(const g1_xyzz& sum, uint64_t b, cons
   }
 }
 
-// One workgroup of BS threads per blob: sums the blob's `splits` (<= BS) unit sums by a tree through LDS in the radix-2^28
-// field.  FINISH: thread 0 then encodes the point itself (the latency shape: a single blob
-// is spread over up to 256 units, and a separate one-thread k_g1_compress launch would cost a launch and a cold start);
-// otherwise sums[b] is written for k_g1_compress.
-template <int BS, bool FINISH>
-static __global__ __launch_bounds__(BS) void k_msm_reduce_splits(const g1_xyzz* __restrict__ unit_sums, uint32_t splits, uint64_t n, g1_xyzz* __restrict__ sums,
+// One WAVE per blob: sums the blob's `splits` (<= 256) unit sums in the radix-2^28 field.  Each lane first adds up its own
+// units t, t + 64, ... one after the other, then the 64 lane sums fold by a tree through LDS.  (A 256-thread workgroup with
+// an 8-level tree was slower: the dispatcher packs the four waves of a workgroup onto shared SIMDs, so its first two levels
+// cost 4 and 2 additions' time; three sequential additions on one wave cost 3 and leave the SIMD to a single wave.)
+// FINISH: lane 0 then encodes the point itself (the latency shape: a single blob is spread over up to 256 units, and a
+// separate one-thread k_g1_compress launch would cost a launch and a cold start); otherwise sums[b] is written for
+// k_g1_compress.
+template <bool FINISH>
+static __global__ __launch_bounds__(64) void k_msm_reduce_splits(const g1_xyzz* __restrict__ unit_sums, uint32_t splits, uint64_t n, g1_xyzz* __restrict__ sums,
                                                                  const int32_t* __restrict__ status, uint8_t* __restrict__ out48,
                                                                  uint8_t* __restrict__ out_affine96) {
-  __shared__ g1_xyzz28 lds[BS / 2];
+  __shared__ g1_xyzz28 lds[32];
   issue_priority_latency();
   const int t = threadIdx.x;
   const uint64_t b = blockIdx.x;
@@ -150,15 +151,20 @@ static __global__ __launch_bounds__(BS) void k_msm_reduce_splits(const g1_xyzz* 
     xyzz28_from_xyzz(acc, in);
   }
 #pragma unroll 1
-  for (int step = 1; step < BS && (uint32_t)step < splits; step <<= 1) {
+  for (uint32_t u = 64u + (uint32_t)t; u < splits; u += 64u) {
+    const g1_xyzz in = unit_sums[b * splits + u];
+    g1_xyzz28 other;
+    xyzz28_from_xyzz(other, in);
+    xyzz28_add_complete_inl(acc, other);
+  }
+#pragma unroll 1
+  for (int step = 1; step < 64 && (uint32_t)step < splits; step <<= 1) {
     const int m = 2 * step - 1;
     if ((t & m) == step) lds[t >> 1] = acc;
     __syncthreads();
     if ((t & m) == 0) {
-      g1_xyzz28 other = lds[(t + step) >> 1];
-      g1_xyzz28 mine = acc;  // copies: the out-of-line adder takes addresses
-      xyzz28_add_complete(mine, other);
-      acc = mine;
+      const g1_xyzz28 other = lds[(t + step) >> 1];
+      xyzz28_add_complete_inl(acc, other);
     }
     __syncthreads();
   }
