@@ -732,18 +732,16 @@ static __global__ __launch_bounds__(256) void k_var_bitsums(const g1_xyzz28* __r
     const uint32_t di = i / per, k = i % per;
     const uint32_t d = ((di >> b) << (b + 1u)) | (1u << b) | (di & low_mask);  // the di-th number with bit b set
     if (d > limit) break;  // d grows with i
-    g1_xyzz28 t = B[(uint64_t)(d - 1u) * per + k];
-    xyzz28_add_complete(acc, t);
+    const g1_xyzz28 t = B[(uint64_t)(d - 1u) * per + k];
+    xyzz28_add_complete_inl(acc, t);  // inlined: the out-of-line adder passes both operands through scratch on every step
   }
 #pragma unroll 1
   for (uint32_t step = 128; step >= 1; step >>= 1) {
     if (threadIdx.x >= step && threadIdx.x < 2 * step) lds[threadIdx.x - step] = acc;
     __syncthreads();
     if (threadIdx.x < step) {
-      g1_xyzz28 other = lds[threadIdx.x];
-      g1_xyzz28 mine = acc;
-      xyzz28_add_complete(mine, other);
-      acc = mine;
+      const g1_xyzz28 other = lds[threadIdx.x];
+      xyzz28_add_complete_inl(acc, other);
     }
     __syncthreads();
   }
