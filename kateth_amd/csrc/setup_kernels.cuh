@@ -138,7 +138,8 @@ static __global__ __launch_bounds__(64) void k_setup_eval_tab(const fr_t* __rest
   put(1, t);
   fr_mul(t, w2, c261);
   put(2, t);
-  fr_mul(t, w2, c522);
+  fr_mul(t, w, w2);    // w w' = i w^2 (Montgomery 2^256)
+  fr_mul(t, t, c261);
   put(3, t);
   fr_sqr(sq, w);       // w^2 (Montgomery 2^256)
   fr_mul(t, sq, c261);

@@ -25,12 +25,16 @@ namespace kzg {
 // A pair contributes
 //   e0 w/(z - w) - e1 w/(z + w) = w [ (e0 - e1) z + (e0 + e1) w ] / (z^2 - w^2) = a / d
 // and the quad  a/d + a'/d'  with  d = z^2 - w^2,  d' = z^2 - w'^2 = z^2 + w^2,  d d' = z^4 - w^4  (a limb-wise subtraction
-// from the table's w^4: no product).  Per quad the kernel does 11 products with 7 reductions (per pair it was 6 with 4):
-//   u  = ((e0 - e1) * zR + (e0 + e1) * wR) / R            plain, one reduction for two products
-//   a  = (u * wR^2) / R = (u w) R                          Montgomery              (likewise u', a' with w')
-//   A  = (a * d' + a' * d) / R                             the quad's numerator, one reduction for two products
+// from the table's w^4: no product).  With a = w u, a' = w' u' = i w u'  (u = (e0 - e1) z + (e0 + e1) w, likewise u' with w')
+// the root is factored out of the quad,   a/d + a'/d' = w [ u d' + u' (i d) ] / (d d'),   i d = i z^2 - i w^2 again a limb-wise
+// subtraction (i z^2 once per blob, i w^2 = w w' from the table).  Per quad the kernel does 10 products with 6 reductions
+// (with the root applied per pair it was 11 with 7, per pair without the quad structure 12 with 8):
+//   u  = ((e0 - e1) * zR + (e0 + e1) * wR) / R            plain, one reduction for two products   (likewise u' with w')
+//   A~ = (u * d' + u' * (i d)) / R                        plain, one reduction for two products
+//   A  = (A~ * wR^2) / R = (A~ w) R                        Montgomery: the quad's numerator
 //   N' = (N * dd + A * D) / R,  D' = (D * dd) / R          dd = z^4 R - w^4 R
-// eval_tab[q] = { w R, w R^2, w' R, w' R^2, w^2 R, w^4 R }: six 9-limb slots padded to 12 dwords, w = roots_brp[4 q].
+// eval_tab[q] = { w R, w R^2, w' R, w w' R, w^2 R, w^4 R }: six 9-limb slots padded to 12 dwords, w = roots_brp[4 q]; slot 3 of
+// quad 0 (w = 1, w' = i) is i R itself.
 template <int G>
 __device__ __forceinline__ fr29 shfl_down_fr29(const fr29& a, int delta) {
   fr29 r;
@@ -60,15 +64,14 @@ __device__ __forceinline__ void eval_tab_slot(fr29& o, const uint32_t* __restric
   o.l[4] = t1.x; o.l[5] = t1.y; o.l[6] = t1.z; o.l[7] = t1.w;
   o.l[8] = t2.x;
 }
-// a = w [ (e0 - e1) z + (e0 + e1) w ] R for one pair (Montgomery, N-form)
-__device__ __forceinline__ void eval_pair_numerator(fr29& a, const fr_t& e0, const fr_t& e1, const fr29& z, const fr29& w, const fr29& wr2) {
-  fr29 x0, x1, sm, df, u;
+// u = (e0 - e1) z + (e0 + e1) w for one pair (plain, N-form)
+__device__ __forceinline__ void eval_pair_numerator(fr29& u, const fr_t& e0, const fr_t& e1, const fr29& z, const fr29& w) {
+  fr29 x0, x1, sm, df;
   f29_from_bn(x0, e0);
   f29_from_bn(x1, e1);
   f29_add(sm, x0, x1);        // limbs < 2^30, value < 2r
   f29_sub_2r(df, x0, x1);     // limbs < 3*2^29, value < 3r
-  f29_mul2(u, df, z, sm, w);  // 9*(3 + 2)*2^58 + 9*2^58 = 54*2^58 < 2^64;  plain (e0-e1) z + (e0+e1) w
-  f29_mul(a, u, wr2);
+  f29_mul2(u, df, z, sm, w);  // 9*(3 + 2)*2^58 + 9*2^58 = 54*2^58 < 2^64
 }
 // G lanes work on one blob (64 / G blobs per wave).  G = 64 has the shortest latency (16 quads per lane); G = 16 does
 // 64 quads per lane and a 4-level merge instead of 16 quads and a 6-level one -- the merge is 11 % of a wave's work
@@ -84,9 +87,9 @@ static __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)
   const bool live = b < n;
   if (!live) b = n - 1;  // idle groups shadow the last blob (they take part in the shuffles, never store)
   const uint8_t* blob = blobs + b * 131072ull;
-  // z stays in registers (two products per pair); z^2 and z^4 are read once per quad and live in LDS (one copy per blob
-  // group of the wave) -- with the pair-sized prefetch below that keeps the kernel at three waves per SIMD
-  __shared__ uint32_t zpow[64 / G][2][12];
+  // z stays in registers (two products per pair); z^2, z^4 and i z^2 are read once per quad and live in LDS (one copy per
+  // blob group of the wave) -- with the pair-sized prefetch below that keeps the kernel at three waves per SIMD
+  __shared__ uint32_t zpow[64 / G][3][12];
   fr29 z;
   {
     fr29 zp, z2, z4;
@@ -94,11 +97,15 @@ static __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)
     f29_to_mont(z, zp);  // N-form
     f29_sqr(z2, z);
     f29_sqr(z4, z2);
+    fr29 iR, iz2;
+    eval_tab_slot(iR, eval_tab, 3);  // quad 0: w w' = i
+    f29_mul(iz2, z2, iR);
     if (lane == 0) {
 #pragma unroll
       for (int q = 0; q < F29_N; q++) {
         zpow[group][0][q] = z2.l[q];
         zpow[group][1][q] = z4.l[q];
+        zpow[group][2][q] = iz2.l[q];
       }
     }
   }
@@ -141,11 +148,10 @@ static __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)
     // Loads return in issue order, so the wait for a table slot also waits for every load issued before it: the table slots
     // of a step are therefore issued FIRST and the blob prefetch LAST (pinned with sched_barrier) -- the prefetch then stays
     // in flight for a whole pair step instead of being drained by the next table access a few dozen instructions later.
-    fr29 a, ap;
+    fr29 u, up;
     {  // pair 1 (roots w, -w); the quad's second pair is fetched meanwhile
-      fr29 w, wr2;
+      fr29 w;
       eval_tab_slot(w, tab, 0);
-      eval_tab_slot(wr2, tab, 1);
       __builtin_amdgcn_sched_barrier(0);
       fr_t e0, e1;
       eval_load_element(e0, nb0, nb1, bad);
@@ -153,21 +159,24 @@ static __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)
       const uint4* src = reinterpret_cast<const uint4*>(blob + (uint64_t)qd * 128u + 64u);
       nb0 = src[0]; nb1 = src[1]; nb2 = src[2]; nb3 = src[3];
       __builtin_amdgcn_sched_barrier(0);
-      eval_pair_numerator(a, e0, e1, z, w, wr2);
+      eval_pair_numerator(u, e0, e1, z, w);
     }
-    fr29 d, dp;
+    fr29 dp, id, wr2;
     {  // pair 2 (roots w', -w'); the next quad's first pair is fetched meanwhile
-      fr29 wp, wpr2;
+      fr29 wp;
       {
-        fr29 wsq, z2;
+        fr29 wsq, iwsq, z2, iz2;
         eval_tab_slot(wp, tab, 2);
-        eval_tab_slot(wpr2, tab, 3);
         eval_tab_slot(wsq, tab, 4);
+        eval_tab_slot(iwsq, tab, 3);
+        eval_tab_slot(wr2, tab, 1);
         load_zpow(z2, 0);
-        f29_sub_2r(d, z2, wsq);  // z^2 - w^2: limbs < 3*2^29, value < 4r   (every table value is consumed before the prefetch
-        f29_add(dp, z2, wsq);    // z^2 + w^2 = z^2 - w'^2: limbs < 2^30, value < 3r    is issued: nothing later waits on it)
-        eval_pin(d);
-        eval_pin(dp);
+        load_zpow(iz2, 2);
+        f29_add(dp, z2, wsq);        // d' = z^2 + w^2 = z^2 - w'^2: limbs < 2^30, value < 3r
+        f29_sub_2r(id, iz2, iwsq);   // i d = i z^2 - i w^2: limbs < 3*2^29, value < 4r
+        eval_pin(dp);                // every table value is consumed (or at least waited for) before the prefetch is issued:
+        eval_pin(id);                // nothing later waits on it
+        eval_pin(wr2);
       }
       __builtin_amdgcn_sched_barrier(0);
       fr_t e2, e3;
@@ -180,15 +189,16 @@ static __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)
         nb0 = src[0]; nb1 = src[1]; nb2 = src[2]; nb3 = src[3];
       }
       __builtin_amdgcn_sched_barrier(0);
-      eval_pair_numerator(ap, e2, e3, z, wp, wpr2);
+      eval_pair_numerator(up, e2, e3, z, wp);
     }
     if (in_domain) {  // z is one of this quad's four roots: resolved after the loop (no loads in here: a branch with loads makes
       dom_q = qd;     // the compiler drain the prefetch at the join)
       continue;
     }
     fr29 A;
-    f29_mul2(A, a, dp, ap, d);  // 9*(2 + 3)*2^58 + 9*2^58 < 2^64;  value 2*3 + 2*4 = 14 < 2^6
-    f29_mul2(N, N, dd, A, D);  // 9*(3 + 1)*2^58 + 9*2^58
+    f29_mul2(A, u, dp, up, id);  // 9*(2 + 3)*2^58 + 9*2^58 < 2^64;  value 2*3 + 2*4 = 14 < 2^6;  plain u d' + u' i d
+    f29_mul(A, A, wr2);          // (A w) R
+    f29_mul2(N, N, dd, A, D);    // 9*(3 + 1)*2^58 + 9*2^58
     f29_mul(D, D, dd);
   }
   if (dom_q >= 0) {  // rare (poly.rs:14-18): which of the quad's roots w, -w, w', -w' is z?  The evaluation is that element (re-read).
