@@ -91,10 +91,12 @@ KZG_HD void f29_to_canonical_bn(fr_t& r, const fr29& a) {
   canonicalize<FrParams>(r);
 }
 
-// k_eval_frac's per-QUAD table entry (elements 4q .. 4q+3 sit at the roots w, -w, iw, -iw): { w R, w R^2, (iw) R, (iw) R^2,
-// w^2 R, w^4 R }: six slots of 9 limbs, each padded to 12 dwords (three 16-byte loads, fetched where it is used)
+// k_eval_frac's per-OCT table entry (elements 8o .. 8o+7 sit at the roots w, -w, iw, -iw, cw, -cw, icw, -icw with i, c the
+// primitive 4th and 8th roots of unity): { w R, (iw) R, (cw) R, (icw) R, w^2 R, (i w^2) R, w^4 R, (c w^4) R, w^8 R, w R^2 }: ten
+// slots of 9 limbs, each padded to 12 dwords (three 16-byte loads, fetched where it is used)
 constexpr int EVAL_TAB_SLOT = 12;
-constexpr int EVAL_TAB_DWORDS = 6 * EVAL_TAB_SLOT;
-constexpr int EVAL_TAB_QUADS = 1024;
+constexpr int EVAL_TAB_SLOTS = 10;
+constexpr int EVAL_TAB_DWORDS = EVAL_TAB_SLOTS * EVAL_TAB_SLOT;
+constexpr int EVAL_TAB_OCTS = 512;
 
 }  // namespace kzg

@@ -108,12 +108,13 @@ static __global__ __launch_bounds__(64) void k_setup_sum_bases(const uint4* __re
   }
 }
 
-// one thread per quad: builds eval_tab from the Montgomery (radix 2^256) roots.  In bit-reversed order elements 4q .. 4q+3 sit
-// at w, -w, w', -w' with w = roots_brp[4q] and w' = roots_brp[4q+2] = i w (i = the primitive 4th root of unity).
+// one thread per oct: builds eval_tab from the Montgomery (radix 2^256) roots.  In bit-reversed order elements 8o .. 8o+7 sit
+// at w, -w, iw, -iw, cw, -cw, icw, -icw with w = roots_brp[8o], i = roots_brp[2], c = roots_brp[4] (the primitive 4th and 8th
+// roots of unity).  Slots as listed in fr29.cuh.
 static __global__ __launch_bounds__(64) void k_setup_eval_tab(const fr_t* __restrict__ roots_brp, uint32_t* __restrict__ eval_tab) {
-  const uint32_t qd = blockIdx.x * blockDim.x + threadIdx.x;
-  if (qd >= (uint32_t)EVAL_TAB_QUADS) return;
-  const fr_t w = roots_brp[4 * qd], w2 = roots_brp[4 * qd + 2];
+  const uint32_t od = blockIdx.x * blockDim.x + threadIdx.x;
+  if (od >= (uint32_t)EVAL_TAB_OCTS) return;
+  const fr_t w = roots_brp[8 * od], wi = roots_brp[8 * od + 2], wc = roots_brp[8 * od + 4], wic = roots_brp[8 * od + 6], c = roots_brp[4];
   fr_t c261, c522, t, sq;
   {
     const uint32_t a[8] = KZG_FR_R261_PLAIN, b[8] = KZG_FR_R522_PLAIN;
@@ -123,7 +124,7 @@ static __global__ __launch_bounds__(64) void k_setup_eval_tab(const fr_t* __rest
       c522.v[q] = b[q];
     }
   }
-  uint32_t* out = eval_tab + (uint64_t)qd * EVAL_TAB_DWORDS;
+  uint32_t* out = eval_tab + (uint64_t)od * EVAL_TAB_DWORDS;
   auto put = [&](int slot, const fr_t& v) {  // canonical value -> 9 strictly normalised limbs
     fr29 o;
     f29_from_bn(o, v);
@@ -134,19 +135,29 @@ static __global__ __launch_bounds__(64) void k_setup_eval_tab(const fr_t* __rest
   };
   fr_mul(t, w, c261);  // (w 2^256)(2^261) / 2^256 = w 2^261
   put(0, t);
-  fr_mul(t, w, c522);  // w R^2
+  fr_mul(t, wi, c261);
   put(1, t);
-  fr_mul(t, w2, c261);
+  fr_mul(t, wc, c261);
   put(2, t);
-  fr_mul(t, w, w2);    // w w' = i w^2 (Montgomery 2^256)
-  fr_mul(t, t, c261);
+  fr_mul(t, wic, c261);
   put(3, t);
   fr_sqr(sq, w);       // w^2 (Montgomery 2^256)
   fr_mul(t, sq, c261);
   put(4, t);
+  fr_mul(t, w, wi);    // w (iw) = i w^2
+  fr_mul(t, t, c261);
+  put(5, t);
   fr_sqr(sq, sq);      // w^4
   fr_mul(t, sq, c261);
-  put(5, t);
+  put(6, t);
+  fr_mul(t, sq, c);    // c w^4
+  fr_mul(t, t, c261);
+  put(7, t);
+  fr_sqr(sq, sq);      // w^8
+  fr_mul(t, sq, c261);
+  put(8, t);
+  fr_mul(t, w, c522);  // w R^2
+  put(9, t);
 }
 
 // roots_of_unity_brp (src/math.rs:16-29 + BRP, src/kzg/setup.rs:74-75), Montgomery form.

@@ -21,20 +21,24 @@ namespace kzg {
 // barycentric factor and y = N / 4096: the whole evaluation needs no inversion.
 // ---------------------------------------------------------------------------
 // The arithmetic runs in the carry-free radix-2^29 representation of Fr (fr29.cuh, Montgomery radix R = 2^261).
-// Bit-reversed order puts FOUR related roots next to each other: elements 4q .. 4q+3 sit at w, -w, w', -w' with w' = i w.
-// A pair contributes
-//   e0 w/(z - w) - e1 w/(z + w) = w [ (e0 - e1) z + (e0 + e1) w ] / (z^2 - w^2) = a / d
-// and the quad  a/d + a'/d'  with  d = z^2 - w^2,  d' = z^2 - w'^2 = z^2 + w^2,  d d' = z^4 - w^4  (a limb-wise subtraction
-// from the table's w^4: no product).  With a = w u, a' = w' u' = i w u'  (u = (e0 - e1) z + (e0 + e1) w, likewise u' with w')
-// the root is factored out of the quad,   a/d + a'/d' = w [ u d' + u' (i d) ] / (d d'),   i d = i z^2 - i w^2 again a limb-wise
-// subtraction (i z^2 once per blob, i w^2 = w w' from the table).  Per quad the kernel does 10 products with 6 reductions
-// (with the root applied per pair it was 11 with 7, per pair without the quad structure 12 with 8):
-//   u  = ((e0 - e1) * zR + (e0 + e1) * wR) / R            plain, one reduction for two products   (likewise u' with w')
-//   A~ = (u * d' + u' * (i d)) / R                        plain, one reduction for two products
-//   A  = (A~ * wR^2) / R = (A~ w) R                        Montgomery: the quad's numerator
-//   N' = (N * dd + A * D) / R,  D' = (D * dd) / R          dd = z^4 R - w^4 R
-// eval_tab[q] = { w R, w R^2, w' R, w w' R, w^2 R, w^4 R }: six 9-limb slots padded to 12 dwords, w = roots_brp[4 q]; slot 3 of
-// quad 0 (w = 1, w' = i) is i R itself.
+// Bit-reversed order puts EIGHT related roots next to each other: elements 8o .. 8o+7 sit at w, -w, iw, -iw, cw, -cw, icw, -icw
+// (i, c: the primitive 4th and 8th roots of unity).  A pair at roots (x, -x) contributes
+//   e0 x/(z - x) - e1 x/(z + x) = x [ (e0 - e1) z + (e0 + e1) x ] / (z^2 - x^2) = x u / d ,
+// two pairs at (x, ix) make a quad, with d' = z^2 - (ix)^2 = z^2 + x^2 and d d' = z^4 - x^4:
+//   x u/d + i x u'/d' = x [ u d' + u' (i d) ] / (z^4 - x^4) = x A~ / dd ,          i d = i z^2 - i x^2 ,
+// and the quads at x = w and x = cw make the oct, with dd' = z^4 - (cw)^4 = z^4 + w^4 and dd dd' = z^8 - w^8:
+//   w A~/dd + c w A~'/dd' = w [ A~ dd' + A~' (c dd) ] / (z^8 - w^8) = w B~ / ddd ,   c dd = c z^4 - c w^4 .
+// Every denominator and every "i d" / "c dd" is a limb-wise sum or difference of a per-blob power of z (LDS) and a table
+// slot -- no product -- and the second quad needs no slots of its own: (cw)^2 = i w^2, so d = z^2 - i w^2, d' = z^2 + i w^2,
+// i d = i z^2 + w^2.  The root w is applied once per oct.  Per oct the kernel does 18 products with 10 reductions (2.25 + 1.25
+// per element; per quad it was 2.5 + 1.5, per pair without this structure 3 + 2):
+//   u   = ((e0 - e1) * zR + (e0 + e1) * xR) / R           plain, one reduction for two products        (four pairs)
+//   A~  = (u * d' + u' * (i d)) / R                       plain, one reduction for two products        (two quads)
+//   B~  = (A~ * dd' + A~' * (c dd)) / R                   plain
+//   B   = (B~ * wR^2) / R = (B~ w) R                       Montgomery: the oct's numerator
+//   N'  = (N * ddd + B * D) / R,  D' = (D * ddd) / R       ddd = z^8 R - w^8 R
+// eval_tab[o] = { w R, iw R, cw R, icw R, w^2 R, i w^2 R, w^4 R, c w^4 R, w^8 R, w R^2 } (fr29.cuh), w = roots_brp[8 o]; slots 1
+// and 2 of oct 0 (w = 1) are i R and c R themselves.
 template <int G>
 __device__ __forceinline__ fr29 shfl_down_fr29(const fr29& a, int delta) {
   fr29 r;
@@ -73,39 +77,44 @@ __device__ __forceinline__ void eval_pair_numerator(fr29& u, const fr_t& e0, con
   f29_sub_2r(df, x0, x1);     // limbs < 3*2^29, value < 3r
   f29_mul2(u, df, z, sm, w);  // 9*(3 + 2)*2^58 + 9*2^58 = 54*2^58 < 2^64
 }
-// G lanes work on one blob (64 / G blobs per wave).  G = 64 has the shortest latency (16 quads per lane); G = 16 does
-// 64 quads per lane and a 4-level merge instead of 16 quads and a 6-level one -- the merge is 11 % of a wave's work
+// G lanes work on one blob (64 / G blobs per wave).  G = 64 has the shortest latency (8 octs per lane); G = 16 does
+// 32 octs per lane and a 4-level merge instead of 8 octs and a 6-level one -- the merge is 11 % of a wave's work
 // at G = 64, 2 % at G = 16 -- and is used when the batch fills the chip.
 template <int G>
 static __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_eval_frac(const uint8_t* __restrict__ blobs, const fr_t* __restrict__ z_plain,
                                                          const fr_t* __restrict__ roots_brp, const uint32_t* __restrict__ eval_tab,
                                                          fr_t* __restrict__ y_plain, int32_t* __restrict__ status, uint64_t n) {
-  constexpr int PER_LANE = EVAL_TAB_QUADS / G;  // quads per lane
+  constexpr int PER_LANE = EVAL_TAB_OCTS / G;  // octs per lane
   const int lane = threadIdx.x % G;   // position inside the blob's group
   const int group = threadIdx.x / G;
   uint64_t b = (uint64_t)blockIdx.x * (64 / G) + group;
   const bool live = b < n;
   if (!live) b = n - 1;  // idle groups shadow the last blob (they take part in the shuffles, never store)
   const uint8_t* blob = blobs + b * 131072ull;
-  // z stays in registers (two products per pair); z^2, z^4 and i z^2 are read once per quad and live in LDS (one copy per
-  // blob group of the wave) -- with the pair-sized prefetch below that keeps the kernel at three waves per SIMD
-  __shared__ uint32_t zpow[64 / G][3][12];
+  // z stays in registers (two products per pair); z^2, i z^2, z^4, c z^4 and z^8 are read once or twice per oct and live in
+  // LDS (one copy per blob group of the wave) -- with the pair-sized prefetch below that keeps the kernel at three waves per SIMD
+  enum { Z2 = 0, IZ2 = 1, Z4 = 2, CZ4 = 3, Z8 = 4 };
+  __shared__ uint32_t zpow[64 / G][5][12];
   fr29 z;
   {
-    fr29 zp, z2, z4;
+    fr29 zp, z2, z4, z8, iR, cR, iz2, cz4;
     f29_from_bn(zp, z_plain[b]);
     f29_to_mont(z, zp);  // N-form
     f29_sqr(z2, z);
     f29_sqr(z4, z2);
-    fr29 iR, iz2;
-    eval_tab_slot(iR, eval_tab, 3);  // quad 0: w w' = i
+    f29_sqr(z8, z4);
+    eval_tab_slot(iR, eval_tab, 1);  // oct 0: w = 1
+    eval_tab_slot(cR, eval_tab, 2);
     f29_mul(iz2, z2, iR);
+    f29_mul(cz4, z4, cR);
     if (lane == 0) {
 #pragma unroll
       for (int q = 0; q < F29_N; q++) {
-        zpow[group][0][q] = z2.l[q];
-        zpow[group][1][q] = z4.l[q];
-        zpow[group][2][q] = iz2.l[q];
+        zpow[group][Z2][q] = z2.l[q];
+        zpow[group][IZ2][q] = iz2.l[q];
+        zpow[group][Z4][q] = z4.l[q];
+        zpow[group][CZ4][q] = cz4.l[q];
+        zpow[group][Z8][q] = z8.l[q];
       }
     }
   }
@@ -124,95 +133,125 @@ static __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)
   fr_t e_dom;
   bn_zero(e_dom);
   bool bad = false;
-  int dom = -1, dom_q = -1;
-  // the blob elements come from HBM (each byte is read exactly once): the next PAIR (64 contiguous bytes) is in flight while
-  // this one is processed; the table slots are L2-resident and loaded where they are used (short live ranges)
+  int dom = -1, dom_o = -1;
+  // The blob elements come from HBM (each byte is read exactly once): the next PAIR (64 contiguous bytes) is in flight while
+  // this one is processed; the table slots are L2-resident and loaded where they are used (short live ranges).
+  // Loads return in issue order, so the wait for a table slot also waits for every load issued before it: the table slots
+  // of a step are therefore issued FIRST and the blob prefetch LAST (pinned with sched_barrier) -- the prefetch then stays
+  // in flight for a whole pair step instead of being drained by the next table access a few dozen instructions later.  For
+  // the same reason no load sits behind a branch (the compiler's wait counts turn pessimistic at a join).
   uint4 nb0, nb1, nb2, nb3;
   {
-    const uint4* src = reinterpret_cast<const uint4*>(blob + (uint64_t)lane * 128u);  // first pair of quad `lane`
+    const uint4* src = reinterpret_cast<const uint4*>(blob + (uint64_t)lane * 256u);  // first pair of oct `lane`
     nb0 = src[0]; nb1 = src[1]; nb2 = src[2]; nb3 = src[3];
   }
+  // one pair step: u = (e0 - e1) z + (e0 + e1) x with x = table slot `slot`; the pair at byte offset `next` is fetched meanwhile
+  auto pair_step = [&](fr29& u, const uint32_t* tab, int slot, uint64_t next) {
+    fr29 x;
+    eval_tab_slot(x, tab, slot);
+    __builtin_amdgcn_sched_barrier(0);
+    fr_t e0, e1;
+    eval_load_element(e0, nb0, nb1, bad);
+    eval_load_element(e1, nb2, nb3, bad);
+    const uint4* src = reinterpret_cast<const uint4*>(blob + next);
+    nb0 = src[0]; nb1 = src[1]; nb2 = src[2]; nb3 = src[3];
+    __builtin_amdgcn_sched_barrier(0);
+    eval_pair_numerator(u, e0, e1, z, x);
+  };
 #pragma unroll 1
   for (int k = 0; k < PER_LANE; k++) {
-    const int qd = k * G + lane;  // quad index: elements 4 qd .. 4 qd + 3
-    const uint32_t* tab = eval_tab + (uint64_t)qd * EVAL_TAB_DWORDS;
-    fr29 dd;
-    {
-      fr29 w4, z4;
-      eval_tab_slot(w4, tab, 5);
-      load_zpow(z4, 1);
-      f29_sub_2r(dd, z4, w4);  // z^4 - w^4: limbs < 3*2^29, value < 4r
-    }
+    const int od = k * G + lane;  // oct index: elements 8 od .. 8 od + 7
+    const uint32_t* tab = eval_tab + (uint64_t)od * EVAL_TAB_DWORDS;
+    const uint64_t base = (uint64_t)od * 256u;
+    // is z one of this oct's roots (z^8 == w^8)?  Tested up here, where the pending prefetch is needed at once anyway.
     bool in_domain = false;
-    if (f29_maybe_zero(dd)) in_domain = f29_is_zero_exact(dd);
-    // Loads return in issue order, so the wait for a table slot also waits for every load issued before it: the table slots
-    // of a step are therefore issued FIRST and the blob prefetch LAST (pinned with sched_barrier) -- the prefetch then stays
-    // in flight for a whole pair step instead of being drained by the next table access a few dozen instructions later.
-    fr29 u, up;
-    {  // pair 1 (roots w, -w); the quad's second pair is fetched meanwhile
-      fr29 w;
-      eval_tab_slot(w, tab, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      fr_t e0, e1;
-      eval_load_element(e0, nb0, nb1, bad);
-      eval_load_element(e1, nb2, nb3, bad);
-      const uint4* src = reinterpret_cast<const uint4*>(blob + (uint64_t)qd * 128u + 64u);
-      nb0 = src[0]; nb1 = src[1]; nb2 = src[2]; nb3 = src[3];
-      __builtin_amdgcn_sched_barrier(0);
-      eval_pair_numerator(u, e0, e1, z, w);
+    {
+      fr29 w8, z8, ddd;
+      eval_tab_slot(w8, tab, 8);
+      load_zpow(z8, Z8);
+      f29_sub_2r(ddd, z8, w8);
+      if (f29_maybe_zero(ddd)) in_domain = f29_is_zero_exact(ddd);
     }
-    fr29 dp, id, wr2;
-    {  // pair 2 (roots w', -w'); the next quad's first pair is fetched meanwhile
-      fr29 wp;
+    fr29 At1;
+    {  // quad 1: pairs at w and iw
+      fr29 u0, u1, dp, id;
+      pair_step(u0, tab, 0, base + 64u);
       {
         fr29 wsq, iwsq, z2, iz2;
-        eval_tab_slot(wp, tab, 2);
         eval_tab_slot(wsq, tab, 4);
-        eval_tab_slot(iwsq, tab, 3);
-        eval_tab_slot(wr2, tab, 1);
-        load_zpow(z2, 0);
-        load_zpow(iz2, 2);
-        f29_add(dp, z2, wsq);        // d' = z^2 + w^2 = z^2 - w'^2: limbs < 2^30, value < 3r
-        f29_sub_2r(id, iz2, iwsq);   // i d = i z^2 - i w^2: limbs < 3*2^29, value < 4r
-        eval_pin(dp);                // every table value is consumed (or at least waited for) before the prefetch is issued:
-        eval_pin(id);                // nothing later waits on it
-        eval_pin(wr2);
+        eval_tab_slot(iwsq, tab, 5);
+        load_zpow(z2, Z2);
+        load_zpow(iz2, IZ2);
+        f29_add(dp, z2, wsq);       // d' = z^2 + w^2: limbs < 2^30, value < 3r
+        f29_sub_2r(id, iz2, iwsq);  // i d = i z^2 - i w^2: limbs < 3*2^29, value < 4r
       }
-      __builtin_amdgcn_sched_barrier(0);
-      fr_t e2, e3;
-      eval_load_element(e2, nb0, nb1, bad);
-      eval_load_element(e3, nb2, nb3, bad);
-      {  // unconditional (a conditional load makes the compiler's wait counts pessimistic at the join): the last step re-reads
-         // the lane's first quad, which is in bounds and in L2
-        const int qn = (k + 1 < PER_LANE) ? qd + G : lane;
-        const uint4* src = reinterpret_cast<const uint4*>(blob + (uint64_t)qn * 128u);
-        nb0 = src[0]; nb1 = src[1]; nb2 = src[2]; nb3 = src[3];
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      eval_pair_numerator(up, e2, e3, z, wp);
+      pair_step(u1, tab, 1, base + 128u);
+      f29_mul2(At1, u0, dp, u1, id);  // 9*(2 + 3)*2^58 + 9*2^58 < 2^64;  value 2*3 + 2*4 = 14 < 2^6;  plain
     }
-    if (in_domain) {  // z is one of this quad's four roots: resolved after the loop (no loads in here: a branch with loads makes
-      dom_q = qd;     // the compiler drain the prefetch at the join)
+    fr29 At2;
+    {  // quad 2: pairs at cw and icw; (cw)^2 = i w^2
+      fr29 u2, u3, dp, id;
+      pair_step(u2, tab, 2, base + 192u);
+      {
+        fr29 wsq, iwsq, z2, iz2;
+        eval_tab_slot(wsq, tab, 4);
+        eval_tab_slot(iwsq, tab, 5);
+        load_zpow(z2, Z2);
+        load_zpow(iz2, IZ2);
+        f29_add(dp, z2, iwsq);   // d' = z^2 + i w^2: limbs < 2^30, value < 3r
+        f29_add(id, iz2, wsq);   // i d = i z^2 + w^2: limbs < 2^30, value < 3r
+      }
+      // unconditional prefetch (a conditional load makes the wait counts pessimistic): the last step re-reads the lane's first
+      // oct, which is in bounds and in L2
+      pair_step(u3, tab, 3, (uint64_t)((k + 1 < PER_LANE) ? od + G : lane) * 256u);
+      f29_mul2(At2, u2, dp, u3, id);
+    }
+    if (in_domain) {  // resolved after the loop (no loads in here)
+      dom_o = od;
       continue;
     }
-    fr29 A;
-    f29_mul2(A, u, dp, up, id);  // 9*(2 + 3)*2^58 + 9*2^58 < 2^64;  value 2*3 + 2*4 = 14 < 2^6;  plain u d' + u' i d
-    f29_mul(A, A, wr2);          // (A w) R
-    f29_mul2(N, N, dd, A, D);    // 9*(3 + 1)*2^58 + 9*2^58
-    f29_mul(D, D, dd);
+    fr29 B;
+    {
+      fr29 ddp, cdd;
+      {
+        fr29 w4, cw4, z4, cz4;
+        eval_tab_slot(w4, tab, 6);
+        eval_tab_slot(cw4, tab, 7);
+        load_zpow(z4, Z4);
+        load_zpow(cz4, CZ4);
+        f29_add(ddp, z4, w4);        // dd' = z^4 + w^4: limbs < 2^30, value < 3r
+        f29_sub_2r(cdd, cz4, cw4);   // c dd = c z^4 - c w^4: limbs < 3*2^29, value < 4r
+      }
+      f29_mul2(B, At1, ddp, At2, cdd);  // same bounds as A~
+    }
+    {
+      fr29 wr2;
+      eval_tab_slot(wr2, tab, 9);
+      f29_mul(B, B, wr2);  // (B~ w) R
+    }
+    fr29 ddd;
+    {
+      fr29 w8, z8;
+      eval_tab_slot(w8, tab, 8);
+      load_zpow(z8, Z8);
+      f29_sub_2r(ddd, z8, w8);  // z^8 - w^8: limbs < 3*2^29, value < 4r
+    }
+    f29_mul2(N, N, ddd, B, D);  // 9*(3 + 1)*2^58 + 9*2^58;  value 2*4 + 2*2 = 12
+    f29_mul(D, D, ddd);
   }
-  if (dom_q >= 0) {  // rare (poly.rs:14-18): which of the quad's roots w, -w, w', -w' is z?  The evaluation is that element (re-read).
-    const uint32_t* tab = eval_tab + (uint64_t)dom_q * EVAL_TAB_DWORDS;
-    fr29 w, wp, t;
-    eval_tab_slot(w, tab, 0);
-    eval_tab_slot(wp, tab, 2);
-    f29_sub_2r(t, z, w);
-    const bool is0 = f29_is_zero_exact(t);
-    f29_add(t, z, w);
-    const bool is1 = f29_is_zero_exact(t);
-    f29_sub_2r(t, z, wp);
-    const bool is2 = f29_is_zero_exact(t);
-    dom = 4 * dom_q + (is0 ? 0 : (is1 ? 1 : (is2 ? 2 : 3)));
+  if (dom_o >= 0) {  // rare (poly.rs:14-18): which of the oct's eight roots is z?  The evaluation is that element (re-read).
+    const uint32_t* tab = eval_tab + (uint64_t)dom_o * EVAL_TAB_DWORDS;
+    int which = 7;
+#pragma unroll 1
+    for (int pr = 3; pr >= 0; pr--) {
+      fr29 x, t;
+      eval_tab_slot(x, tab, pr);
+      f29_sub_2r(t, z, x);
+      if (f29_is_zero_exact(t)) which = 2 * pr;
+      f29_add(t, z, x);
+      if (f29_is_zero_exact(t)) which = 2 * pr + 1;
+    }
+    dom = 8 * dom_o + which;
     const uint4* src = reinterpret_cast<const uint4*>(blob + (uint64_t)dom * 32u);
     bool dummy = false;
     eval_load_element(e_dom, src[0], src[1], dummy);
@@ -234,7 +273,7 @@ static __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)
   //   y = (N / D) * (z^4096 - 1) / 4096 = N / 4096          -- no inversion at all.
   fr_t y;
   if (dom_any >= 0) {
-    const int owner = (dom_any >> 2) % G;  // quad index qd = k*G + lane
+    const int owner = (dom_any >> 3) % G;  // oct index od = k*G + lane
 #pragma unroll
     for (int q = 0; q < 8; q++) y.v[q] = __shfl(e_dom.v[q], owner, G);  // already plain
   } else {
