@@ -151,6 +151,16 @@ int32_t kzg_compute_proof_batch_affine(const kzg_ctx* ctx, const uint8_t* blobs,
 int32_t kzg_g1_decompress_batch(const kzg_ctx* ctx, const uint8_t* in48, uint64_t n, uint8_t* out_affine96, int32_t* status);
 
 /*
+ * Replaces Polynomial::evaluate (src/kzg/poly.rs:10-33; with Blob::from_slice, src/blob.rs:26-37) for n (blob, z) pairs --
+ * the evaluation step of the verification path on its own (there z is a hash output; an evaluation point on the domain,
+ * poly.rs:14-18, reaches that kernel only through this call).  At most 16384 pairs per call.
+ *   blobs   : n * 131072 bytes          z32 : n * 32 bytes, big-endian canonical
+ *   out_y32 : n * 32 bytes, big-endian (zero bytes for a rejected item)
+ *   status  : per item 0, KZG_ERR_BLOB_INVALID_FIELD_ELEMENT, or KZG_ERR_FF_NOT_IN_FIELD for z
+ */
+int32_t kzg_evaluate_blobs(const kzg_ctx* ctx, const uint8_t* blobs, const uint8_t* z32, uint64_t n, uint8_t* out_y32, int32_t* status);
+
+/*
  * Replaces Setup::blob_proof + compress for n (blob, commitment) pairs
  * (src/kzg/setup.rs:177-183, src/blob.rs:55-97, src/kzg/poly.rs:10-71).
  *   status : per item 0, KZG_ERR_BLOB_*, or KZG_ERR_EC_* for the commitment

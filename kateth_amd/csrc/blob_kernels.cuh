@@ -392,6 +392,17 @@ static __global__ __launch_bounds__(64) void k_fr_parse(const uint8_t* __restric
   out_plain[i] = v;
 }
 
+// plain field elements -> 32 big-endian bytes each (an item whose status is non-zero gets zero bytes)
+static __global__ __launch_bounds__(256) void k_fr_store_be(const fr_t* __restrict__ plain, uint64_t n, const int32_t* __restrict__ status, uint8_t* __restrict__ out32) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  fr_t v = plain[i];
+  if (status != nullptr && status[i] != 0) bn_zero(v);
+  uint4* o = reinterpret_cast<uint4*>(out32 + i * 32);
+  o[0] = make_uint4(__builtin_bswap32(v.v[7]), __builtin_bswap32(v.v[6]), __builtin_bswap32(v.v[5]), __builtin_bswap32(v.v[4]));
+  o[1] = make_uint4(__builtin_bswap32(v.v[3]), __builtin_bswap32(v.v[2]), __builtin_bswap32(v.v[1]), __builtin_bswap32(v.v[0]));
+}
+
 // ---------------------------------------------------------------------------
 // K1 + K5 + K6: Blob::from_slice validation (src/blob.rs:26-37),
 // Polynomial::evaluate (src/kzg/poly.rs:10-33) and the quotient of

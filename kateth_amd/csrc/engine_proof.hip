@@ -6,16 +6,6 @@ __global__ __launch_bounds__(256) void k_merge_status(int32_t* __restrict__ prim
   if (i < n && primary[i] == 0) primary[i] = secondary[i];
 }
 
-__global__ __launch_bounds__(256) void k_fr_store_be(const fr_t* __restrict__ plain, uint64_t n, const int32_t* __restrict__ status, uint8_t* __restrict__ out32) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  fr_t v = plain[i];
-  if (status != nullptr && status[i] != 0) bn_zero(v);
-  uint4* o = reinterpret_cast<uint4*>(out32 + i * 32);
-  o[0] = make_uint4(__builtin_bswap32(v.v[7]), __builtin_bswap32(v.v[6]), __builtin_bswap32(v.v[5]), __builtin_bswap32(v.v[4]));
-  o[1] = make_uint4(__builtin_bswap32(v.v[3]), __builtin_bswap32(v.v[2]), __builtin_bswap32(v.v[1]), __builtin_bswap32(v.v[0]));
-}
-
 // proofs for n (blob, commitment) or (blob, z) items resident on the device.
 //   d_commitments48 != null : blob proofs (z from the Fiat-Shamir challenge)
 //   d_z32 != null           : proofs at caller-supplied points; y written to d_y32

@@ -737,6 +737,50 @@ extern "C" int32_t kzg_g1_decompress_batch(const kzg_ctx* ctx, const uint8_t* in
   return 0;
 }
 
+// Polynomial::evaluate (src/kzg/poly.rs:10-33) for n (blob, z) pairs from host buffers, through the evaluation kernel of the
+// verification path.  (In verify_blob_kzg_proof_batch z is a hash output; an evaluation point ON the domain -- poly.rs:14-18 --
+// reaches k_eval_frac only through this entry point.)
+extern "C" int32_t kzg_evaluate_blobs(const kzg_ctx* ctx, const uint8_t* blobs, const uint8_t* z32, uint64_t n, uint8_t* out_y32, int32_t* status) {
+  if (!ctx || (n && (!blobs || !z32 || !out_y32 || !status))) return fail(KZG_FAIL_ARGUMENT, "null argument");
+  if (n == 0) return 0;
+  if (n > 16384) return fail(KZG_FAIL_ARGUMENT, "kzg_evaluate_blobs: at most 16384 pairs per call");
+  HIP_TRY(hipSetDevice(ctx->device));
+  std::lock_guard<std::mutex> guard(ctx->stage_lock);  // pooled device buffers + an idle stream of the host-buffer pipelines
+  int32_t rc = stage_init(ctx);
+  if (rc) return rc;
+  const size_t o_z32 = align_up((size_t)n * KZG_BYTES_PER_BLOB, 256), o_y32 = o_z32 + align_up((size_t)n * 32, 256);
+  const size_t o_z = o_y32 + align_up((size_t)n * 32, 256), o_y = o_z + align_up((size_t)n * sizeof(fr_t), 256);
+  const size_t o_st = o_y + align_up((size_t)n * sizeof(fr_t), 256);
+  rc = stage_reserve(ctx, 0, o_st + (size_t)n * sizeof(int32_t));
+  if (rc) return rc;
+  uint8_t* d_blobs = ctx->hostio;
+  uint8_t* d_z32 = ctx->hostio + o_z32;
+  uint8_t* d_y32 = ctx->hostio + o_y32;
+  fr_t* d_z = reinterpret_cast<fr_t*>(ctx->hostio + o_z);
+  fr_t* d_y = reinterpret_cast<fr_t*>(ctx->hostio + o_y);
+  int32_t* d_st = reinterpret_cast<int32_t*>(ctx->hostio + o_st);
+  hipStream_t st = ctx->stage_streams[0];
+  HIP_TRY(hipMemcpyAsync(d_blobs, blobs, (size_t)n * KZG_BYTES_PER_BLOB, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(d_z32, z32, (size_t)n * 32, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemsetAsync(d_st, 0, (size_t)n * sizeof(int32_t), st));
+  hipLaunchKernelGGL(k_fr_parse, dim3(blocks_for(n, 64)), dim3(64), 0, st, d_z32, n, d_z, d_st);
+  bool wide_groups = n < 4096;
+  if (ctx->knobs.eval_group) wide_groups = ctx->knobs.eval_group != 16;
+  {
+    ProfScope ps(ctx, PROF_EVAL, st);
+    if (!wide_groups)
+      hipLaunchKernelGGL(k_eval_frac<16>, dim3(blocks_for(n, 4)), dim3(64), 0, st, d_blobs, d_z, ctx->d_roots_brp, ctx->d_eval_tab, d_y, d_st, n);
+    else
+      hipLaunchKernelGGL(k_eval_frac<64>, dim3((unsigned)n), dim3(64), 0, st, d_blobs, d_z, ctx->d_roots_brp, ctx->d_eval_tab, d_y, d_st, n);
+  }
+  hipLaunchKernelGGL(k_fr_store_be, dim3(blocks_for(n, 256)), dim3(256), 0, st, d_y, n, d_st, d_y32);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(out_y32, d_y32, (size_t)n * 32, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(status, d_st, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return 0;
+}
+
 extern "C" int32_t kzg_verify_phase2_dev(kzg_verify_session* s, const uint8_t* roots32, uint64_t world, uint64_t first_index, uint64_t n_total,
                                          uint8_t* out192) {
   if (!s || !roots32 || !out192 || world == 0) return fail(KZG_FAIL_ARGUMENT, "null argument");

@@ -303,6 +303,16 @@ class Setup {
     return out;
   }
 
+  // `Polynomial::evaluate` (src/kzg/poly.rs:10-33) of one blob at one point, through the verification path's evaluation kernel
+  Bytes32 evaluate(const uint8_t* blob, size_t len, const Bytes32& point) const {
+    if (len != BLOB_BYTES) throw Error(ErrorKind::BlobInvalidLen);
+    Bytes32 y{};
+    int32_t status = 0;
+    check(kzg_evaluate_blobs(ctx_.get(), blob, point.data(), 1, y.data(), &status), "kzg_evaluate_blobs");
+    if (status) throw Error(static_cast<ErrorKind>(status));
+    return y;
+  }
+
   bool verify_proof(const Bytes48& proof, const Bytes48& commitment, const Bytes32& point, const Bytes32& eval) const {
     int32_t ok = 0;
     int32_t rc = kzg_verify_proof(ctx_.get(), proof.data(), commitment.data(), point.data(), eval.data(), &ok);

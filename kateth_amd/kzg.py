@@ -130,6 +130,7 @@ _SIGNATURES = {
     "kzg_verify_blob_proof": (ctypes.c_int32, [ctypes.c_void_p, _u8p, _u8p, _u8p, _i32p]),
     "kzg_verify_proof": (ctypes.c_int32, [ctypes.c_void_p, _u8p, _u8p, _u8p, _u8p, _i32p]),
     "kzg_g1_decompress_batch": (ctypes.c_int32, [ctypes.c_void_p, _u8p, ctypes.c_uint64, _u8p, _i32p]),
+    "kzg_evaluate_blobs": (ctypes.c_int32, [ctypes.c_void_p, _u8p, _u8p, ctypes.c_uint64, _u8p, _i32p]),
     "kzg_verify_phase1_dev": (
         ctypes.c_int32,
         [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, _u8p, _i32p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p],
@@ -525,6 +526,20 @@ class Setup:
         if status[0]:
             raise _kzg_error(status[0])
         return proofs, ys
+
+    def evaluate_blobs(self, blobs: bytes, points32: bytes) -> Tuple[bytes, List[int]]:
+        """`Polynomial::evaluate` (src/kzg/poly.rs:10-33) for n (blob, z) pairs through the verification path's evaluation
+        kernel: n * 32 big-endian bytes of evaluations and the per-item status (0, BlobError InvalidFieldElement, or
+        FiniteFieldError NotInFiniteField for z)."""
+        blobs, points32 = _buf(blobs), _buf(points32)
+        if len(points32) % 32 or len(blobs) != (len(points32) // 32) * BYTES_PER_BLOB:
+            raise KzgError(BlobError("InvalidLen"))
+        n = len(points32) // 32
+        out = (ctypes.c_uint8 * (32 * max(n, 1)))()
+        status = (ctypes.c_int32 * max(n, 1))()
+        rc = self._lib.kzg_evaluate_blobs(self._h, blobs, points32, n, out, status)
+        self._check(rc, "kzg_evaluate_blobs")
+        return bytes(out)[:32 * n], list(status)[:n]
 
     def decompress_g1_batch(self, points48) -> Tuple[List["P1"], List[int]]:
         """`P1::decompress` (the crate's `Decompress` trait on `Commitment` / `Proof`, src/bls.rs:505-531) for a list (or a

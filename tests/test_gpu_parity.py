@@ -430,6 +430,52 @@ def test_kzg_proof_special_points_vs_live_oracle(engine, oracle_setup):
         assert engine.verify_proof(proof, c, be32(z), yy) is True
 
 
+def test_evaluation_kernel_on_and_off_the_domain(engine, oracle_setup, monkeypatch):
+    """Polynomial::evaluate (src/kzg/poly.rs:10-33) through the VERIFICATION path's kernel (k_eval_frac, 16 and 64 lanes per
+    blob): random points, 0, 1, r - 1, and -- poly.rs:14-18 -- every one of the eight positions of a bit-reversed group of
+    roots, in the first, the last and interior groups (all lanes of both shapes are hit).  In verify_blob_kzg_proof_batch z
+    is a hash output, so only this entry point reaches the kernel's on-domain case."""
+    import random
+
+    from oracle.pyref import blob as oblob
+    from oracle.pyref import poly
+
+    rng = random.Random(0xE7A1)
+    blob = synth_blob(23, 0x3C)
+    elements = oblob.from_slice(blob)
+    roots = oracle_setup.roots_of_unity_brp
+    zs, want = [], []
+    for z in [0, 1, R - 1] + [rng.randrange(R) for _ in range(5)]:
+        zs.append(z)
+        want.append(poly.evaluate(elements, z, oracle_setup))
+    on_domain = []
+    for octet in (0, 1, 15, 16, 17, 63, 64, 255, 300, 511):
+        on_domain += [8 * octet + j for j in range(8)]
+    on_domain += [rng.randrange(4096) for _ in range(16)]
+    for i in on_domain:
+        zs.append(roots[i])
+        want.append(elements[i])  # poly.rs:14-18: the evaluation at a root is that element
+    assert poly.evaluate(elements, roots[on_domain[13]], oracle_setup) == elements[on_domain[13]]  # the oracle agrees with the shortcut
+    n = len(zs)
+    blobs = blob * n
+    points = b"".join(be32(z) for z in zs)
+    for group in ("16", "64"):
+        e2 = _engine_with_env(monkeypatch, {"KATETH_AMD_EVAL_GROUP": group})
+        try:
+            ys, status = e2.evaluate_blobs(blobs, points)
+            assert status == [0] * n
+            for k in range(n):
+                assert ys[32 * k:32 * k + 32] == be32(want[k]), (group, k, hex(zs[k]))
+            # a non-canonical z and a non-canonical blob element are reported per item
+            bad_blob = bytearray(blob)
+            bad_blob[32 * 77:32 * 77 + 32] = b"\xff" * 32
+            ys2, st2 = e2.evaluate_blobs(blob + bytes(bad_blob) + blob, be32(5) + be32(5) + b"\xff" * 32)
+            assert st2[0] == 0 and st2[1] == 2 and st2[2] == 7
+            assert ys2[:32] == be32(poly.evaluate(elements, 5, oracle_setup)) and ys2[32:] == bytes(64)
+        finally:
+            e2.close()
+
+
 def test_verify_proof_infinity_and_constant_polynomial(engine):
     from oracle.pyref import bls
 
