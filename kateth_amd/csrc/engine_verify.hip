@@ -27,7 +27,8 @@ struct kzg_verify_session {
   fr_t* y = nullptr;       // [n] plain
   fr_t* scal = nullptr;    // [2n+1] plain: r_i*z_i (n), r_i (n), -sum r_i*y_i
   int32_t* stat = nullptr;   // [3n] blob / commitment / proof status
-  uint32_t* leaves = nullptr;  // transcript
+  uint32_t* leaves = nullptr;  // transcript: n leaves, ceil(n / 16) mid digests, ceil(n / 256) nodes
+  uint32_t* mids = nullptr;
   uint32_t* nodes = nullptr;
   uint8_t* pts48 = nullptr;  // [2n * 48] device copy of proofs || commitments (host-buffer entry points)
   uint8_t* msm_a = nullptr;  // scratch of the two lincomb MSMs (carved from buf: no allocation in phase 2)
@@ -287,7 +288,7 @@ static void scan_first_error(const int32_t* st, uint64_t n, int32_t* idx, int32_
 
 // ---- session set-up -----------------------------------------------------------------------------------------------
 struct SessionLayout {
-  size_t o_aff, o_inf, o_z, o_y, o_scal, o_stat, o_leaves, o_nodes, o_pts, o_msm_a, o_msm_b, o_rpow, o_ysum, total;
+  size_t o_aff, o_inf, o_z, o_y, o_scal, o_stat, o_leaves, o_mids, o_nodes, o_pts, o_msm_a, o_msm_b, o_rpow, o_ysum, total;
 };
 static SessionLayout session_layout(const kzg_ctx* ctx, uint64_t n) {
   SessionLayout L{};
@@ -305,6 +306,7 @@ static SessionLayout session_layout(const kzg_ctx* ctx, uint64_t n) {
   L.o_scal = take((2 * n + 1) * 32);
   L.o_stat = take(3 * n * 4 + 4);
   L.o_leaves = take(n * 32 + 32);
+  L.o_mids = take((n / 16 + 1) * 32 + 32);
   L.o_nodes = take(groups * 32 + 32);
   L.o_pts = take(2 * n * 48 + 48);
   L.o_msm_a = take(msm_var_layout(ctx, n).total + 256);
@@ -374,6 +376,7 @@ static int32_t session_acquire(const kzg_ctx* ctx, uint64_t n, hipStream_t st, k
   s->scal = (fr_t*)(s->buf + L.o_scal);
   s->stat = (int32_t*)(s->buf + L.o_stat);
   s->leaves = (uint32_t*)(s->buf + L.o_leaves);
+  s->mids = (uint32_t*)(s->buf + L.o_mids);
   s->nodes = (uint32_t*)(s->buf + L.o_nodes);
   s->pts48 = s->buf + L.o_pts;
   s->msm_a = s->buf + L.o_msm_a;
@@ -469,7 +472,9 @@ static int32_t phase1_finish(kzg_verify_session* s, const uint8_t* com, const ui
   s->h_stat.resize(3 * n);
   s->h_nodes.resize(groups * 8);
   hipLaunchKernelGGL(k_transcript_leaves, dim3(blocks_for(n, 256)), dim3(256), 0, st, com, prf, s->z, s->y, n, s->leaves);
-  hipLaunchKernelGGL(k_transcript_nodes, dim3(blocks_for(groups, 64)), dim3(64), 0, st, s->leaves, n, s->nodes);
+  const uint64_t nmid = (n + 15) / 16;  // groups == ceil(nmid / 16)
+  hipLaunchKernelGGL(k_transcript_nodes, dim3(blocks_for(nmid, 64)), dim3(64), 0, st, s->leaves, n, 16u, s->mids);
+  hipLaunchKernelGGL(k_transcript_nodes, dim3(blocks_for(groups, 64)), dim3(64), 0, st, s->mids, nmid, 16u, s->nodes);
   (void)hipStreamWaitEvent(st, s->ev_join, 0);
   if (hipGetLastError() != hipSuccess) return fail(KZG_FAIL_HIP, "verify phase 1 launch failed");
   if (hipMemcpyAsync(s->h_stat.data(), s->stat, 3 * n * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||

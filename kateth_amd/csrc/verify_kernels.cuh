@@ -294,10 +294,13 @@ static __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)
 // ---------------------------------------------------------------------------
 // Batch challenge transcript.  kateth derives r from the batch SIZE only
 // (src/kzg/setup.rs:127-136); the Deneb spec binds every
-// input.  The engine binds every input through a two-level SHA-256 tree so the
-// hashing is parallel:  leaf_i = H(C_i || z_i || y_i || pi_i)  (160 B),
-// node_g = H(leaf_{256g} .. leaf_{256g+255}), and the host hashes
+// input.  The engine binds every input through a SHA-256 tree so the hashing is
+// parallel AND short:  leaf_i = H(C_i || z_i || y_i || pi_i)  (160 B),
+// mid_j = H(leaf_{16j} .. leaf_{16j+15}), node_g = H(mid_{16g} .. mid_{16g+15})
+// (ragged at the end), and the host hashes
 // "RCKZGBATCH___V1_" || u128(4096) || u128(n) || node_0 || ... into the seed.
+// (Fan-out 16 twice instead of 256 once: a thread hashes 9 blocks, not 129 -- the
+// 256-ary level was a 0.6 ms serial chain at the end of phase 1.)
 // ---------------------------------------------------------------------------
 static __global__ __launch_bounds__(256) void k_transcript_leaves(const uint8_t* __restrict__ commitments48, const uint8_t* __restrict__ proofs48,
                                                           const fr_t* __restrict__ z_plain, const fr_t* __restrict__ y_plain, uint64_t n,
@@ -333,13 +336,15 @@ static __global__ __launch_bounds__(256) void k_transcript_leaves(const uint8_t*
   for (int q = 0; q < 8; q++) leaves[i * 8 + q] = s.h[q];
 }
 
-static __global__ __launch_bounds__(64) void k_transcript_nodes(const uint32_t* __restrict__ leaves, uint64_t n, uint32_t* __restrict__ nodes) {
+// out[g] = H(in[g * fan] .. in[min(n_in, (g + 1) * fan) - 1]) over 32-byte digests (8 big-endian word values each)
+static __global__ __launch_bounds__(64) void k_transcript_nodes(const uint32_t* __restrict__ in, uint64_t n_in, uint32_t fan, uint32_t* __restrict__ nodes) {
   issue_priority_latency();
   const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const uint64_t groups = (n + 255) / 256;
+  const uint64_t groups = (n_in + fan - 1) / fan;
   if (g >= groups) return;
-  const uint64_t first = g * 256;
-  const uint64_t cnt = (n - first < 256) ? (n - first) : 256;
+  const uint32_t* leaves = in;
+  const uint64_t first = g * fan;
+  const uint64_t cnt = (n_in - first < fan) ? (n_in - first) : fan;
   sha256_state s;
   sha256_init(s);
   uint32_t w[16];
