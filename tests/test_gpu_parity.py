@@ -476,6 +476,32 @@ def test_evaluation_kernel_on_and_off_the_domain(engine, oracle_setup, monkeypat
             e2.close()
 
 
+def test_two_evaluation_kernels_agree_at_scale(engine, torch_cuda):
+    """Polynomial::evaluate lives twice on the device: in the proof path (k_poly: batch inversion, 8 x 32-bit limbs, one
+    workgroup per blob) and in the verification path (k_eval_frac: inversion-free fraction sums over octs of roots, radix
+    2^29, 16 lanes per blob at this size).  Independent code, same answers on 4,100 (blob, z) pairs -- random points plus a
+    sprinkling of points on the domain."""
+    import random
+
+    from oracle.pyref import domain
+
+    torch = torch_cuda
+    n = 4100  # >= 4,096: the 16-lane shape of k_eval_frac, ragged last wave
+    d_blobs = torch.empty(n * 131072, dtype=torch.uint8, device="cuda")
+    engine.synth_blobs_dev(0xE7A2, 5, n, d_blobs.data_ptr())
+    blobs = d_blobs.cpu().numpy().tobytes()
+    rng = random.Random(0xE7A2)
+    roots = domain.bit_reversal_permutation(domain.roots_of_unity(4096))
+    zs = [rng.randrange(R) for _ in range(n)]
+    for k in range(0, n, 97):
+        zs[k] = roots[rng.randrange(4096)]
+    points = b"".join(be32(z) for z in zs)
+    _, ys_proof, st_proof = engine.compute_proof_batch(blobs, points)
+    ys_eval, st_eval = engine.evaluate_blobs(blobs, points)
+    assert st_proof == [0] * n and st_eval == [0] * n
+    assert ys_eval == ys_proof
+
+
 def test_verify_proof_infinity_and_constant_polynomial(engine):
     from oracle.pyref import bls
 
