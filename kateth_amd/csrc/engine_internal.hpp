@@ -259,7 +259,10 @@ static inline int32_t msm_finish(const kzg_ctx* ctx, uint64_t n, uint8_t* d_out4
   ProfScope ps(ctx, PROF_REDUCE_COMPRESS, st);
   g1_xyzz* unit_sums = (splits == 1) ? sums : partials + (size_t)n * splits * 64;
   const uint64_t units = msm_units(n, splits, lpb);
-  hipLaunchKernelGGL(k_msm_reduce, dim3((unsigned)units), dim3(64), 0, st, partials, units, lpb, unit_sums, lpb == 64 ? units : n);
+  if (lpb == 32)  // half-wave mode: four blobs per reducing wave
+    hipLaunchKernelGGL(k_msm_reduce_half4, dim3((unsigned)((units + 1) / 2)), dim3(64), 0, st, partials, units, unit_sums, n);
+  else
+    hipLaunchKernelGGL(k_msm_reduce, dim3((unsigned)units), dim3(64), 0, st, partials, units, lpb, unit_sums, units);
   if (splits > 64) {  // latency shape (a few blobs over up to 256 units each): tree + constant term + encoding in one launch
     hipLaunchKernelGGL((k_msm_reduce_splits<true>), dim3((unsigned)n), dim3(64), 0, st, unit_sums, splits, n, sums, d_status, d_out48, d_out_affine96);
     HIP_TRY(hipGetLastError());

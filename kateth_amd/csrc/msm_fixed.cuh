@@ -103,6 +103,46 @@ static __global__ __launch_bounds__(64) void k_msm_reduce(const g1_xyzz* __restr
     unit_sums[slot] = out;
   }
 }
+// The comb's half-wave mode (two blobs per unit, 32 lane sums each) with FOUR blobs per wave: lane l adds the lane sums j and
+// j + 16 (j = l % 16) of blob l / 16 as it loads them, then a 4-level tree over 16 lanes.  The same five dependent additions per
+// blob as k_msm_reduce, but n / 4 waves instead of n / 2: at 4,096 blobs one wave per SIMD instead of two, whose interleaved
+// issue made every level 1.5 times as long (0.25 -> 0.13 ms per 4,096 blobs).
+static __global__ __launch_bounds__(64) void k_msm_reduce_half4(const g1_xyzz* __restrict__ partials, uint64_t units, g1_xyzz* __restrict__ unit_sums,
+                                                                uint64_t n_out) {
+  __shared__ g1_xyzz28 lds[32];
+  issue_priority_latency();
+  const int lane = threadIdx.x;
+  const int q = lane >> 4, j = lane & 15;
+  const uint64_t u = (uint64_t)blockIdx.x * 2 + (uint32_t)(q >> 1);  // unit of this lane's blob
+  const uint64_t slot = u * 2 + (uint32_t)(q & 1);                   // = blob index
+  const bool live = u < units && slot < n_out;
+  g1_xyzz28 acc;
+  xyzz28_set_inf(acc);
+  if (live) {
+    const g1_xyzz* row = partials + u * 64 + (uint32_t)(q & 1) * 32u;
+    const g1_xyzz a = row[j], b = row[j + 16];
+    g1_xyzz28 other;
+    xyzz28_from_xyzz(acc, a);
+    xyzz28_from_xyzz(other, b);
+    xyzz28_add_complete_inl(acc, other);
+  }
+#pragma unroll 1
+  for (int step = 1; step < 16; step <<= 1) {
+    const int m = 2 * step - 1;
+    if ((lane & m) == step) lds[lane >> 1] = acc;
+    __syncthreads();
+    if ((lane & m) == 0) {
+      const g1_xyzz28 other = lds[(lane + step) >> 1];
+      xyzz28_add_complete_inl(acc, other);
+    }
+    __syncthreads();
+  }
+  if (j == 0 && live) {
+    g1_xyzz out;
+    xyzz28_to_xyzz(out, acc);
+    unit_sums[slot] = out;
+  }
+}
 // XYZZ sum of one blob -> affine -> 48-byte compressed encoding (K3: blst_p1_compress, src/bls.rs:499) and/or the 96-byte
 // blst_p1_affine image (so that a caller that wants the reference's `P1` back -- Commitment = Proof = P1,
 // src/kzg/mod.rs:9-10 -- needs no square root).  An item whose status is non-zero gets zero bytes.  Either output pointer may
