@@ -54,13 +54,7 @@ __device__ __forceinline__ void eval_load_element(fr_t& e, const uint4& hi, cons
     bn_zero(e);
   }
 }
-// one 9-limb slot of a quad's table entry (three 16-byte loads)
-// keeps a value computed HERE: without it the compiler sinks the arithmetic (and with it the wait for the loads that feed it)
-// to the first use, behind the prefetch that must stay outstanding
-__device__ __forceinline__ void eval_pin(fr29& a) {
-  static_assert(F29_N == 9, "nine limbs");
-  asm volatile("" : "+v"(a.l[0]), "+v"(a.l[1]), "+v"(a.l[2]), "+v"(a.l[3]), "+v"(a.l[4]), "+v"(a.l[5]), "+v"(a.l[6]), "+v"(a.l[7]), "+v"(a.l[8]));
-}
+// one 9-limb slot of an oct's table entry (three 16-byte loads)
 __device__ __forceinline__ void eval_tab_slot(fr29& o, const uint32_t* __restrict__ entry, int slot) {
   const uint4* t = reinterpret_cast<const uint4*>(entry + slot * EVAL_TAB_SLOT);
   const uint4 t0 = t[0], t1 = t[1], t2 = t[2];
