@@ -403,6 +403,58 @@ def test_verify_roundtrip_at_batch_size(engine, torch_cuda):
     assert engine.verify_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n) is False
 
 
+def test_batch_transcript_and_lincombs_against_a_python_restatement(engine, torch_cuda):
+    """verify_blob_kzg_proof_batch up to the pairing, restated with hashlib and the oracle's group law: the SHA-256 transcript
+    tree (leaves H(C || z || y || pi), two levels of fan-out 16, ragged at the end), the challenge r, the powers r^i
+    (src/kzg/setup.rs:138-150 with the spec's exponents) and both random linear combinations
+        A = sum r^i pi_i        B = sum r^i C_i - (sum r^i y_i) G + sum r^i z_i pi_i      (setup.rs:151-160)
+    for 37 triples (mid digests over 16 + 16 + 5 leaves) and for 300 (two node digests, the second over three mids)."""
+    import hashlib
+
+    from oracle.pyref import bls
+
+    torch = torch_cuda
+    sha = lambda b: hashlib.sha256(b).digest()  # noqa: E731
+    for n, full in ((37, True), (300, False)):
+        d_blobs = torch.empty(n * 131072, dtype=torch.uint8, device="cuda")
+        d_c = torch.empty(n * 48, dtype=torch.uint8, device="cuda")
+        d_p = torch.empty(n * 48, dtype=torch.uint8, device="cuda")
+        d_st = torch.empty(n, dtype=torch.int32, device="cuda")
+        engine.synth_blobs_dev(0x7A5C, 9, n, d_blobs.data_ptr())
+        engine.blob_to_commitment_batch_dev(d_blobs.data_ptr(), n, d_c.data_ptr(), d_st.data_ptr())
+        engine.compute_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), n, d_p.data_ptr(), d_st.data_ptr())
+        torch.cuda.synchronize()
+        assert int(d_st.abs().sum()) == 0
+        com, prf = d_c.cpu().numpy().tobytes(), d_p.cpu().numpy().tobytes()
+        sess, root, err = engine.verify_phase1_dev(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n)
+        assert err[0] == err[2] == err[4] == -1
+        zs, ys = engine.verify_session_zy(sess, 0, n)
+        out = engine.verify_phase2_dev(sess, root, 0, n)
+        engine.verify_session_destroy(sess)
+        # the transcript
+        level = [sha(com[48 * i:48 * i + 48] + zs[32 * i:32 * i + 32] + ys[32 * i:32 * i + 32] + prf[48 * i:48 * i + 48]) for i in range(n)]
+        for _ in range(2):
+            level = [sha(b"".join(level[k:k + 16])) for k in range(0, len(level), 16)]
+        assert len(level) == (n + 255) // 256
+        assert sha(b"".join(level)) == root
+        if not full:
+            continue
+        # the challenge and the two linear combinations
+        r = bls.fr_hash_to(b"RCKZGBATCH___V1_" + (4096).to_bytes(16, "big") + n.to_bytes(16, "big") + root)
+        A = B = None
+        ysum, ri = 0, 1
+        for i in range(n):
+            C, pi = bls.g1_decompress(com[48 * i:48 * i + 48]), bls.g1_decompress(prf[48 * i:48 * i + 48])
+            z, y = int.from_bytes(zs[32 * i:32 * i + 32], "big"), int.from_bytes(ys[32 * i:32 * i + 32], "big")
+            A = bls.g1_add(A, bls.g1_mul(pi, ri))
+            B = bls.g1_add(B, bls.g1_add(bls.g1_mul(C, ri), bls.g1_mul(pi, ri * z % R)))
+            ysum = (ysum + ri * y) % R
+            ri = ri * r % R
+        B = bls.g1_add(B, bls.g1_neg(bls.g1_mul(bls.G1_GEN, ysum)))
+        want = b"".join(v.to_bytes(48, "big") for v in (A[0], A[1], B[0], B[1]))
+        assert out == want
+
+
 def test_asm_multiply_matches_compiler_scheduled_multiply(engine):
     """hardware self-test of the inline-asm v_mad_u64_u32 / v_addc_co_u32 chains (no manual wait
     states between the carry producer and consumer) against a plain-C multiply for which hipcc
