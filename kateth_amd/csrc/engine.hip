@@ -435,8 +435,8 @@ static int32_t ctx_build(kzg_ctx* ctx, const uint8_t* g1_lagrange, const uint8_t
   // ---- roots of unity -------------------------------------------------------
   HIP_TRY(hipMalloc(&ctx->d_roots_brp, 4096 * sizeof(fr_t)));
   hipLaunchKernelGGL(k_setup_roots, dim3(64), dim3(64), 0, st, ctx->d_roots_brp);
-  HIP_TRY(hipMalloc(&ctx->d_eval_tab, (size_t)EVAL_TAB_OCTS * EVAL_TAB_DWORDS * sizeof(uint32_t)));
-  hipLaunchKernelGGL(k_setup_eval_tab, dim3(EVAL_TAB_OCTS / 64), dim3(64), 0, st, ctx->d_roots_brp, ctx->d_eval_tab);
+  HIP_TRY(hipMalloc(&ctx->d_eval_tab, (size_t)EVAL_TAB_HEXES * EVAL_TAB_DWORDS * sizeof(uint32_t)));
+  hipLaunchKernelGGL(k_setup_eval_tab, dim3(EVAL_TAB_HEXES / 64), dim3(64), 0, st, ctx->d_roots_brp, ctx->d_eval_tab);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
   if (ctx->msm_override && ctx->msm_override->build) {  // test-only library (tests/window_msm)

@@ -108,7 +108,7 @@ struct kzg_ctx {
   uint32_t window_class = 0;     // what kzg_ctx_window_bits reports
   uint4* d_bases_brp = nullptr;  // 4096 affine Lagrange points, BRP order
   fr_t* d_roots_brp = nullptr;   // 4096 roots of unity, Montgomery, BRP order
-  uint32_t* d_eval_tab = nullptr;  // 512 octs x ten 9-limb slots in radix-2^29 limbs (layout: fr29.cuh; k_eval_frac, verify_kernels.cuh)
+  uint32_t* d_eval_tab = nullptr;  // 256 hexes x twenty 9-limb slots in radix-2^29 limbs (layout: fr29.cuh; k_eval_frac, verify_kernels.cuh)
   uint4* d_gen_affine = nullptr; // G1 generator, affine, 2^392-Montgomery (96 B): a term of batch verification's second lincomb
   host::pairing_ctx* pairing = nullptr;  // host: Frobenius constants + Miller lines of G2 and [tau]_2
   uint64_t table_bytes = 0;

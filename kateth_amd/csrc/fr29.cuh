@@ -91,12 +91,14 @@ KZG_HD void f29_to_canonical_bn(fr_t& r, const fr29& a) {
   canonicalize<FrParams>(r);
 }
 
-// k_eval_frac's per-OCT table entry (elements 8o .. 8o+7 sit at the roots w, -w, iw, -iw, cw, -cw, icw, -icw with i, c the
-// primitive 4th and 8th roots of unity): { w R, (iw) R, (cw) R, (icw) R, w^2 R, (i w^2) R, w^4 R, (c w^4) R, w^8 R, w R^2 }: ten
-// slots of 9 limbs, each padded to 12 dwords (three 16-byte loads, fetched where it is used)
+// k_eval_frac's per-HEX table entry (16 elements 16h .. 16h+15 at the roots +-w rho_k, rho = 1, i, c, ic, s, is, cs, ics with i, c, s
+// the primitive 4th, 8th and 16th roots of unity): twenty slots of 9 limbs, each padded to 12 dwords (three 16-byte loads,
+// fetched where it is used):
+//   0..7   (w rho_k) R                       8..11  w^2 R, i w^2 R, c w^2 R, i c w^2 R
+//   12..15 w^4 R, c w^4 R, i w^4 R, c i w^4 R   16, 17 w^8 R, s w^8 R        18  w^16 R        19  w R^2
 constexpr int EVAL_TAB_SLOT = 12;
-constexpr int EVAL_TAB_SLOTS = 10;
+constexpr int EVAL_TAB_SLOTS = 20;
 constexpr int EVAL_TAB_DWORDS = EVAL_TAB_SLOTS * EVAL_TAB_SLOT;
-constexpr int EVAL_TAB_OCTS = 512;
+constexpr int EVAL_TAB_HEXES = 256;
 
 }  // namespace kzg

@@ -108,14 +108,14 @@ static __global__ __launch_bounds__(64) void k_setup_sum_bases(const uint4* __re
   }
 }
 
-// one thread per oct: builds eval_tab from the Montgomery (radix 2^256) roots.  In bit-reversed order elements 8o .. 8o+7 sit
-// at w, -w, iw, -iw, cw, -cw, icw, -icw with w = roots_brp[8o], i = roots_brp[2], c = roots_brp[4] (the primitive 4th and 8th
-// roots of unity).  Slots as listed in fr29.cuh.
+// one thread per hex: builds eval_tab from the Montgomery (radix 2^256) roots.  In bit-reversed order elements 16h + 2k, 2k + 1
+// sit at +-w rho_k with w = roots_brp[16h] and rho = 1, i, c, ic, s, is, cs, ics (i = roots_brp[2], c = roots_brp[4],
+// s = roots_brp[8]: the primitive 4th, 8th and 16th roots of unity).  Slots as listed in fr29.cuh.
 static __global__ __launch_bounds__(64) void k_setup_eval_tab(const fr_t* __restrict__ roots_brp, uint32_t* __restrict__ eval_tab) {
-  const uint32_t od = blockIdx.x * blockDim.x + threadIdx.x;
-  if (od >= (uint32_t)EVAL_TAB_OCTS) return;
-  const fr_t w = roots_brp[8 * od], wi = roots_brp[8 * od + 2], wc = roots_brp[8 * od + 4], wic = roots_brp[8 * od + 6], c = roots_brp[4];
-  fr_t c261, c522, t, sq;
+  const uint32_t hd = blockIdx.x * blockDim.x + threadIdx.x;
+  if (hd >= (uint32_t)EVAL_TAB_HEXES) return;
+  const fr_t w = roots_brp[16 * hd], ri = roots_brp[2], rc = roots_brp[4], rs = roots_brp[8];
+  fr_t c261, c522, t, u, sq;
   {
     const uint32_t a[8] = KZG_FR_R261_PLAIN, b[8] = KZG_FR_R522_PLAIN;
 #pragma unroll
@@ -124,40 +124,50 @@ static __global__ __launch_bounds__(64) void k_setup_eval_tab(const fr_t* __rest
       c522.v[q] = b[q];
     }
   }
-  uint32_t* out = eval_tab + (uint64_t)od * EVAL_TAB_DWORDS;
-  auto put = [&](int slot, const fr_t& v) {  // canonical value -> 9 strictly normalised limbs
+  uint32_t* out = eval_tab + (uint64_t)hd * EVAL_TAB_DWORDS;
+  auto put = [&](int slot, const fr_t& v) {  // Montgomery (2^256) value -> (value 2^261) canonical -> 9 strictly normalised limbs
+    fr_t m;
+    fr_mul(m, v, c261);  // (v 2^256)(2^261) / 2^256 = v 2^261
     fr29 o;
-    f29_from_bn(o, v);
+    f29_from_bn(o, m);
 #pragma unroll
     for (int q = 0; q < F29_N; q++) out[EVAL_TAB_SLOT * slot + q] = o.l[q];
 #pragma unroll
     for (int q = F29_N; q < EVAL_TAB_SLOT; q++) out[EVAL_TAB_SLOT * slot + q] = 0;
   };
-  fr_mul(t, w, c261);  // (w 2^256)(2^261) / 2^256 = w 2^261
-  put(0, t);
-  fr_mul(t, wi, c261);
-  put(1, t);
-  fr_mul(t, wc, c261);
-  put(2, t);
-  fr_mul(t, wic, c261);
-  put(3, t);
-  fr_sqr(sq, w);       // w^2 (Montgomery 2^256)
-  fr_mul(t, sq, c261);
-  put(4, t);
-  fr_mul(t, w, wi);    // w (iw) = i w^2
-  fr_mul(t, t, c261);
-  put(5, t);
-  fr_sqr(sq, sq);      // w^4
-  fr_mul(t, sq, c261);
-  put(6, t);
-  fr_mul(t, sq, c);    // c w^4
-  fr_mul(t, t, c261);
-  put(7, t);
-  fr_sqr(sq, sq);      // w^8
-  fr_mul(t, sq, c261);
-  put(8, t);
-  fr_mul(t, w, c522);  // w R^2
+  for (int k = 0; k < 8; k++) put(k, roots_brp[16 * hd + 2 * k]);
+  fr_sqr(sq, w);       // w^2
+  put(8, sq);
+  fr_mul(t, sq, ri);   // i w^2
   put(9, t);
+  fr_mul(u, sq, rc);   // c w^2
+  put(10, u);
+  fr_mul(u, t, rc);    // i c w^2
+  put(11, u);
+  fr_sqr(sq, sq);      // w^4
+  put(12, sq);
+  fr_mul(t, sq, rc);   // c w^4
+  put(13, t);
+  fr_mul(u, sq, ri);   // i w^4
+  put(14, u);
+  fr_mul(u, t, ri);    // c i w^4
+  put(15, u);
+  fr_sqr(sq, sq);      // w^8
+  put(16, sq);
+  fr_mul(t, sq, rs);   // s w^8
+  put(17, t);
+  fr_sqr(sq, sq);      // w^16
+  put(18, sq);
+  {  // w R^2
+    fr_t m;
+    fr_mul(m, w, c522);
+    fr29 o;
+    f29_from_bn(o, m);
+#pragma unroll
+    for (int q = 0; q < F29_N; q++) out[EVAL_TAB_SLOT * 19 + q] = o.l[q];
+#pragma unroll
+    for (int q = F29_N; q < EVAL_TAB_SLOT; q++) out[EVAL_TAB_SLOT * 19 + q] = 0;
+  }
 }
 
 // roots_of_unity_brp (src/math.rs:16-29 + BRP, src/kzg/setup.rs:74-75), Montgomery form.

@@ -21,24 +21,27 @@ namespace kzg {
 // barycentric factor and y = N / 4096: the whole evaluation needs no inversion.
 // ---------------------------------------------------------------------------
 // The arithmetic runs in the carry-free radix-2^29 representation of Fr (fr29.cuh, Montgomery radix R = 2^261).
-// Bit-reversed order puts EIGHT related roots next to each other: elements 8o .. 8o+7 sit at w, -w, iw, -iw, cw, -cw, icw, -icw
-// (i, c: the primitive 4th and 8th roots of unity).  A pair at roots (x, -x) contributes
+// Bit-reversed order puts SIXTEEN related roots next to each other: elements 16h + 2k, 2k + 1 sit at +-w rho_k with
+// rho = 1, i, c, ic, s, is, cs, ics (i, c, s: the primitive 4th, 8th and 16th roots of unity).  A pair at roots (x, -x) contributes
 //   e0 x/(z - x) - e1 x/(z + x) = x [ (e0 - e1) z + (e0 + e1) x ] / (z^2 - x^2) = x u / d ,
 // two pairs at (x, ix) make a quad, with d' = z^2 - (ix)^2 = z^2 + x^2 and d d' = z^4 - x^4:
-//   x u/d + i x u'/d' = x [ u d' + u' (i d) ] / (z^4 - x^4) = x A~ / dd ,          i d = i z^2 - i x^2 ,
-// and the quads at x = w and x = cw make the oct, with dd' = z^4 - (cw)^4 = z^4 + w^4 and dd dd' = z^8 - w^8:
-//   w A~/dd + c w A~'/dd' = w [ A~ dd' + A~' (c dd) ] / (z^8 - w^8) = w B~ / ddd ,   c dd = c z^4 - c w^4 .
-// Every denominator and every "i d" / "c dd" is a limb-wise sum or difference of a per-blob power of z (LDS) and a table
-// slot -- no product -- and the second quad needs no slots of its own: (cw)^2 = i w^2, so d = z^2 - i w^2, d' = z^2 + i w^2,
-// i d = i z^2 + w^2.  The root w is applied once per oct.  Per oct the kernel does 18 products with 10 reductions (2.25 + 1.25
-// per element; per quad it was 2.5 + 1.5, per pair without this structure 3 + 2):
-//   u   = ((e0 - e1) * zR + (e0 + e1) * xR) / R           plain, one reduction for two products        (four pairs)
-//   A~  = (u * d' + u' * (i d)) / R                       plain, one reduction for two products        (two quads)
-//   B~  = (A~ * dd' + A~' * (c dd)) / R                   plain
-//   B   = (B~ * wR^2) / R = (B~ w) R                       Montgomery: the oct's numerator
-//   N'  = (N * ddd + B * D) / R,  D' = (D * ddd) / R       ddd = z^8 R - w^8 R
-// eval_tab[o] = { w R, iw R, cw R, icw R, w^2 R, i w^2 R, w^4 R, c w^4 R, w^8 R, w R^2 } (fr29.cuh), w = roots_brp[8 o]; slots 1
-// and 2 of oct 0 (w = 1) are i R and c R themselves.
+//   x u/d + i x u'/d' = x [ u d' + u' (i d) ] / (z^4 - x^4) = x A~ / dd ,            i d = i z^2 - i x^2 ,
+// two quads at (x, cx) make an oct, with dd' = z^4 - (cx)^4 = z^4 + x^4 and dd dd' = z^8 - x^8:
+//   x A~/dd + c x A~'/dd' = x [ A~ dd' + A~' (c dd) ] / (z^8 - x^8) = x B~ / ddd ,     c dd = c z^4 - c x^4 ,
+// and the octs at x = w and x = sw make the hex, with ddd' = z^8 - (sw)^8 = z^8 + w^8 and ddd ddd' = z^16 - w^16:
+//   w B~/ddd + s w B~'/ddd' = w [ B~ ddd' + B~' (s ddd) ] / (z^16 - w^16) = w H~ / dddd ,   s ddd = s z^8 - s w^8 .
+// Every denominator and every "i d" / "c dd" / "s ddd" is a limb-wise sum or difference of a per-blob power of z (LDS) and a
+// table slot -- no product.  The quads of one oct share two slots ((cx)^2 = i x^2: d = z^2 - i x^2, d' = z^2 + i x^2,
+// i d = i z^2 + x^2), the two octs have the same shape with (x^2, i x^2, x^4, c x^4) = (w^2, i w^2, w^4, c w^4) and
+// (c w^2, i c w^2, i w^4, c i w^4): one loop body, run twice.  The root w is applied once per hex.  Per hex the kernel does 34
+// products with 18 reductions (2.125 + 1.125 per element; per oct it was 2.25 + 1.25, per quad 2.5 + 1.5, per pair 3 + 2):
+//   u   = ((e0 - e1) * zR + (e0 + e1) * xR) / R           plain, one reduction for two products        (eight pairs)
+//   A~  = (u * d' + u' * (i d)) / R                       plain                                        (four quads)
+//   B~  = (A~ * dd' + A~' * (c dd)) / R                   plain                                        (two octs)
+//   H~  = (B~ * ddd' + B~' * (s ddd)) / R                 plain
+//   H   = (H~ * wR^2) / R = (H~ w) R                       Montgomery: the hex's numerator
+//   N'  = (N * dddd + H * D) / R,  D' = (D * dddd) / R     dddd = z^16 R - w^16 R
+// eval_tab[h]: twenty slots (fr29.cuh), w = roots_brp[16 h]; slots 1, 2 and 4 of hex 0 (w = 1) are i R, c R and s R themselves.
 template <int G>
 __device__ __forceinline__ fr29 shfl_down_fr29(const fr29& a, int delta) {
   fr29 r;
@@ -54,7 +57,7 @@ __device__ __forceinline__ void eval_load_element(fr_t& e, const uint4& hi, cons
     bn_zero(e);
   }
 }
-// one 9-limb slot of an oct's table entry (three 16-byte loads)
+// one 9-limb slot of a hex's table entry (three 16-byte loads)
 __device__ __forceinline__ void eval_tab_slot(fr29& o, const uint32_t* __restrict__ entry, int slot) {
   const uint4* t = reinterpret_cast<const uint4*>(entry + slot * EVAL_TAB_SLOT);
   const uint4 t0 = t[0], t1 = t[1], t2 = t[2];
@@ -71,46 +74,52 @@ __device__ __forceinline__ void eval_pair_numerator(fr29& u, const fr_t& e0, con
   f29_sub_2r(df, x0, x1);     // limbs < 3*2^29, value < 3r
   f29_mul2(u, df, z, sm, w);  // 9*(3 + 2)*2^58 + 9*2^58 = 54*2^58 < 2^64
 }
-// G lanes work on one blob (64 / G blobs per wave).  G = 64 has the shortest latency (8 octs per lane); G = 16 does
-// 32 octs per lane and a 4-level merge instead of 8 octs and a 6-level one -- the merge is 11 % of a wave's work
+// G lanes work on one blob (64 / G blobs per wave).  G = 64 has the shortest latency (4 hexes per lane); G = 16 does
+// 16 hexes per lane and a 4-level merge instead of 4 hexes and a 6-level one -- the merge is 11 % of a wave's work
 // at G = 64, 2 % at G = 16 -- and is used when the batch fills the chip.
 template <int G>
 static __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_eval_frac(const uint8_t* __restrict__ blobs, const fr_t* __restrict__ z_plain,
                                                          const fr_t* __restrict__ roots_brp, const uint32_t* __restrict__ eval_tab,
                                                          fr_t* __restrict__ y_plain, int32_t* __restrict__ status, uint64_t n) {
-  constexpr int PER_LANE = EVAL_TAB_OCTS / G;  // octs per lane
+  constexpr int PER_LANE = EVAL_TAB_HEXES / G;  // hexes per lane
   const int lane = threadIdx.x % G;   // position inside the blob's group
   const int group = threadIdx.x / G;
   uint64_t b = (uint64_t)blockIdx.x * (64 / G) + group;
   const bool live = b < n;
   if (!live) b = n - 1;  // idle groups shadow the last blob (they take part in the shuffles, never store)
   const uint8_t* blob = blobs + b * 131072ull;
-  // z stays in registers (two products per pair); z^2, i z^2, z^4, c z^4 and z^8 are read once or twice per oct and live in
+  // z stays in registers (two products per pair); seven multiples of powers of z are read once or twice per hex and live in
   // LDS (one copy per blob group of the wave) -- with the pair-sized prefetch below that keeps the kernel at three waves per SIMD
-  enum { Z2 = 0, IZ2 = 1, Z4 = 2, CZ4 = 3, Z8 = 4 };
-  __shared__ uint32_t zpow[64 / G][5][12];
+  enum { Z2 = 0, IZ2 = 1, Z4 = 2, CZ4 = 3, Z8 = 4, SZ8 = 5, Z16 = 6, NZP = 7 };
+  __shared__ uint32_t zpow[64 / G][NZP][12];
   fr29 z;
   {
-    fr29 zp, z2, z4, z8, iR, cR, iz2, cz4;
+    fr29 zp, z2, z4, z8, z16, kR, t;
     f29_from_bn(zp, z_plain[b]);
     f29_to_mont(z, zp);  // N-form
     f29_sqr(z2, z);
     f29_sqr(z4, z2);
     f29_sqr(z8, z4);
-    eval_tab_slot(iR, eval_tab, 1);  // oct 0: w = 1
-    eval_tab_slot(cR, eval_tab, 2);
-    f29_mul(iz2, z2, iR);
-    f29_mul(cz4, z4, cR);
-    if (lane == 0) {
+    f29_sqr(z16, z8);
+    auto put = [&](int which, const fr29& v) {
+      if (lane == 0) {
 #pragma unroll
-      for (int q = 0; q < F29_N; q++) {
-        zpow[group][Z2][q] = z2.l[q];
-        zpow[group][IZ2][q] = iz2.l[q];
-        zpow[group][Z4][q] = z4.l[q];
-        zpow[group][CZ4][q] = cz4.l[q];
-        zpow[group][Z8][q] = z8.l[q];
+        for (int q = 0; q < F29_N; q++) zpow[group][which][q] = v.l[q];
       }
-    }
+    };
+    put(Z2, z2);
+    put(Z4, z4);
+    put(Z8, z8);
+    put(Z16, z16);
+    eval_tab_slot(kR, eval_tab, 1);  // hex 0 (w = 1): slot 1 = i R, slot 2 = c R, slot 4 = s R
+    f29_mul(t, z2, kR);
+    put(IZ2, t);
+    eval_tab_slot(kR, eval_tab, 2);
+    f29_mul(t, z4, kR);
+    put(CZ4, t);
+    eval_tab_slot(kR, eval_tab, 4);
+    f29_mul(t, z8, kR);
+    put(SZ8, t);
   }
   __syncthreads();
   auto load_zpow = [&](fr29& o, int which) {
@@ -127,7 +136,7 @@ static __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)
   fr_t e_dom;
   bn_zero(e_dom);
   bool bad = false;
-  int dom = -1, dom_o = -1;
+  int dom = -1, dom_h = -1;
   // The blob elements come from HBM (each byte is read exactly once): the next PAIR (64 contiguous bytes) is in flight while
   // this one is processed; the table slots are L2-resident and loaded where they are used (short live ranges).
   // Loads return in issue order, so the wait for a table slot also waits for every load issued before it: the table slots
@@ -136,7 +145,7 @@ static __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)
   // the same reason no load sits behind a branch (the compiler's wait counts turn pessimistic at a join).
   uint4 nb0, nb1, nb2, nb3;
   {
-    const uint4* src = reinterpret_cast<const uint4*>(blob + (uint64_t)lane * 256u);  // first pair of oct `lane`
+    const uint4* src = reinterpret_cast<const uint4*>(blob + (uint64_t)lane * 512u);  // first pair of hex `lane`
     nb0 = src[0]; nb1 = src[1]; nb2 = src[2]; nb3 = src[3];
   }
   // one pair step: u = (e0 - e1) z + (e0 + e1) x with x = table slot `slot`; the pair at byte offset `next` is fetched meanwhile
@@ -154,90 +163,112 @@ static __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)
   };
 #pragma unroll 1
   for (int k = 0; k < PER_LANE; k++) {
-    const int od = k * G + lane;  // oct index: elements 8 od .. 8 od + 7
-    const uint32_t* tab = eval_tab + (uint64_t)od * EVAL_TAB_DWORDS;
-    const uint64_t base = (uint64_t)od * 256u;
-    // is z one of this oct's roots (z^8 == w^8)?  Tested up here, where the pending prefetch is needed at once anyway.
+    const int hd = k * G + lane;  // hex index: elements 16 hd .. 16 hd + 15
+    const uint32_t* tab = eval_tab + (uint64_t)hd * EVAL_TAB_DWORDS;
+    // is z one of this hex's roots (z^16 == w^16)?  Tested up here, where the pending prefetch is needed at once anyway.
     bool in_domain = false;
     {
-      fr29 w8, z8, ddd;
-      eval_tab_slot(w8, tab, 8);
-      load_zpow(z8, Z8);
-      f29_sub_2r(ddd, z8, w8);
-      if (f29_maybe_zero(ddd)) in_domain = f29_is_zero_exact(ddd);
+      fr29 w16, z16, d16;
+      eval_tab_slot(w16, tab, 18);
+      load_zpow(z16, Z16);
+      f29_sub_2r(d16, z16, w16);
+      if (f29_maybe_zero(d16)) in_domain = f29_is_zero_exact(d16);
     }
-    fr29 At1;
-    {  // quad 1: pairs at w and iw
-      fr29 u0, u1, dp, id;
-      pair_step(u0, tab, 0, base + 64u);
-      {
-        fr29 wsq, iwsq, z2, iz2;
-        eval_tab_slot(wsq, tab, 4);
-        eval_tab_slot(iwsq, tab, 5);
-        load_zpow(z2, Z2);
-        load_zpow(iz2, IZ2);
-        f29_add(dp, z2, wsq);       // d' = z^2 + w^2: limbs < 2^30, value < 3r
-        f29_sub_2r(id, iz2, iwsq);  // i d = i z^2 - i w^2: limbs < 3*2^29, value < 4r
+    fr29 Bt1, Bt;
+#pragma unroll 1
+    for (int oc = 0; oc < 2; oc++) {  // the octs at w and at s w: the same shape on different slots
+      const uint64_t base = (uint64_t)hd * 512u + (uint32_t)oc * 256u;
+      const int ps = 4 * oc;        // pair roots x, ix, cx, icx
+      const int sq = 8 + 2 * oc;    // x^2, i x^2
+      const int q4 = 12 + 2 * oc;   // x^4, c x^4
+      fr29 At1;
+      {  // quad 1: pairs at x and ix
+        fr29 u0, u1, dp, id;
+        pair_step(u0, tab, ps, base + 64u);
+        {
+          fr29 xsq, ixsq, z2, iz2;
+          eval_tab_slot(xsq, tab, sq);
+          eval_tab_slot(ixsq, tab, sq + 1);
+          load_zpow(z2, Z2);
+          load_zpow(iz2, IZ2);
+          f29_add(dp, z2, xsq);       // d' = z^2 + x^2: limbs < 2^30, value < 3r
+          f29_sub_2r(id, iz2, ixsq);  // i d = i z^2 - i x^2: limbs < 3*2^29, value < 4r
+        }
+        pair_step(u1, tab, ps + 1, base + 128u);
+        f29_mul2(At1, u0, dp, u1, id);  // 9*(2 + 3)*2^58 + 9*2^58 < 2^64;  value 2*3 + 2*4 = 14 < 2^6;  plain
       }
-      pair_step(u1, tab, 1, base + 128u);
-      f29_mul2(At1, u0, dp, u1, id);  // 9*(2 + 3)*2^58 + 9*2^58 < 2^64;  value 2*3 + 2*4 = 14 < 2^6;  plain
-    }
-    fr29 At2;
-    {  // quad 2: pairs at cw and icw; (cw)^2 = i w^2
-      fr29 u2, u3, dp, id;
-      pair_step(u2, tab, 2, base + 192u);
-      {
-        fr29 wsq, iwsq, z2, iz2;
-        eval_tab_slot(wsq, tab, 4);
-        eval_tab_slot(iwsq, tab, 5);
-        load_zpow(z2, Z2);
-        load_zpow(iz2, IZ2);
-        f29_add(dp, z2, iwsq);   // d' = z^2 + i w^2: limbs < 2^30, value < 3r
-        f29_add(id, iz2, wsq);   // i d = i z^2 + w^2: limbs < 2^30, value < 3r
+      fr29 At2;
+      {  // quad 2: pairs at cx and icx; (cx)^2 = i x^2
+        fr29 u2, u3, dp, id;
+        pair_step(u2, tab, ps + 2, base + 192u);
+        {
+          fr29 xsq, ixsq, z2, iz2;
+          eval_tab_slot(xsq, tab, sq);
+          eval_tab_slot(ixsq, tab, sq + 1);
+          load_zpow(z2, Z2);
+          load_zpow(iz2, IZ2);
+          f29_add(dp, z2, ixsq);  // d' = z^2 + i x^2: limbs < 2^30, value < 3r
+          f29_add(id, iz2, xsq);  // i d = i z^2 + x^2: limbs < 2^30, value < 3r
+        }
+        // unconditional prefetch (a conditional load makes the wait counts pessimistic): the very last step re-reads the lane's
+        // first hex, which is in bounds and in L2
+        const uint64_t next = (oc == 0) ? base + 256u : (uint64_t)((k + 1 < PER_LANE) ? hd + G : lane) * 512u;
+        pair_step(u3, tab, ps + 3, next);
+        f29_mul2(At2, u2, dp, u3, id);
       }
-      // unconditional prefetch (a conditional load makes the wait counts pessimistic): the last step re-reads the lane's first
-      // oct, which is in bounds and in L2
-      pair_step(u3, tab, 3, (uint64_t)((k + 1 < PER_LANE) ? od + G : lane) * 256u);
-      f29_mul2(At2, u2, dp, u3, id);
+      {
+        fr29 ddp, cdd;
+        {
+          fr29 x4, cx4, z4, cz4;
+          eval_tab_slot(x4, tab, q4);
+          eval_tab_slot(cx4, tab, q4 + 1);
+          load_zpow(z4, Z4);
+          load_zpow(cz4, CZ4);
+          f29_add(ddp, z4, x4);        // dd' = z^4 + x^4: limbs < 2^30, value < 3r
+          f29_sub_2r(cdd, cz4, cx4);   // c dd = c z^4 - c x^4: limbs < 3*2^29, value < 4r
+        }
+        f29_mul2(Bt, At1, ddp, At2, cdd);  // same bounds as A~
+      }
+      if (oc == 0) Bt1 = Bt;
     }
     if (in_domain) {  // resolved after the loop (no loads in here)
-      dom_o = od;
+      dom_h = hd;
       continue;
     }
-    fr29 B;
+    fr29 H;
     {
-      fr29 ddp, cdd;
+      fr29 e8p, sd8;
       {
-        fr29 w4, cw4, z4, cz4;
-        eval_tab_slot(w4, tab, 6);
-        eval_tab_slot(cw4, tab, 7);
-        load_zpow(z4, Z4);
-        load_zpow(cz4, CZ4);
-        f29_add(ddp, z4, w4);        // dd' = z^4 + w^4: limbs < 2^30, value < 3r
-        f29_sub_2r(cdd, cz4, cw4);   // c dd = c z^4 - c w^4: limbs < 3*2^29, value < 4r
+        fr29 w8, sw8, z8, sz8;
+        eval_tab_slot(w8, tab, 16);
+        eval_tab_slot(sw8, tab, 17);
+        load_zpow(z8, Z8);
+        load_zpow(sz8, SZ8);
+        f29_add(e8p, z8, w8);        // ddd' = z^8 + w^8
+        f29_sub_2r(sd8, sz8, sw8);   // s ddd = s z^8 - s w^8
       }
-      f29_mul2(B, At1, ddp, At2, cdd);  // same bounds as A~
+      f29_mul2(H, Bt1, e8p, Bt, sd8);
     }
     {
       fr29 wr2;
-      eval_tab_slot(wr2, tab, 9);
-      f29_mul(B, B, wr2);  // (B~ w) R
+      eval_tab_slot(wr2, tab, 19);
+      f29_mul(H, H, wr2);  // (H~ w) R
     }
-    fr29 ddd;
+    fr29 d16;
     {
-      fr29 w8, z8;
-      eval_tab_slot(w8, tab, 8);
-      load_zpow(z8, Z8);
-      f29_sub_2r(ddd, z8, w8);  // z^8 - w^8: limbs < 3*2^29, value < 4r
+      fr29 w16, z16;
+      eval_tab_slot(w16, tab, 18);
+      load_zpow(z16, Z16);
+      f29_sub_2r(d16, z16, w16);  // z^16 - w^16: limbs < 3*2^29, value < 4r
     }
-    f29_mul2(N, N, ddd, B, D);  // 9*(3 + 1)*2^58 + 9*2^58;  value 2*4 + 2*2 = 12
-    f29_mul(D, D, ddd);
+    f29_mul2(N, N, d16, H, D);  // 9*(3 + 1)*2^58 + 9*2^58;  value 2*4 + 2*2 = 12
+    f29_mul(D, D, d16);
   }
-  if (dom_o >= 0) {  // rare (poly.rs:14-18): which of the oct's eight roots is z?  The evaluation is that element (re-read).
-    const uint32_t* tab = eval_tab + (uint64_t)dom_o * EVAL_TAB_DWORDS;
-    int which = 7;
+  if (dom_h >= 0) {  // rare (poly.rs:14-18): which of the hex's sixteen roots is z?  The evaluation is that element (re-read).
+    const uint32_t* tab = eval_tab + (uint64_t)dom_h * EVAL_TAB_DWORDS;
+    int which = 15;
 #pragma unroll 1
-    for (int pr = 3; pr >= 0; pr--) {
+    for (int pr = 7; pr >= 0; pr--) {
       fr29 x, t;
       eval_tab_slot(x, tab, pr);
       f29_sub_2r(t, z, x);
@@ -245,7 +276,7 @@ static __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)
       f29_add(t, z, x);
       if (f29_is_zero_exact(t)) which = 2 * pr + 1;
     }
-    dom = 8 * dom_o + which;
+    dom = 16 * dom_h + which;
     const uint4* src = reinterpret_cast<const uint4*>(blob + (uint64_t)dom * 32u);
     bool dummy = false;
     eval_load_element(e_dom, src[0], src[1], dummy);
@@ -267,7 +298,7 @@ static __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)
   //   y = (N / D) * (z^4096 - 1) / 4096 = N / 4096          -- no inversion at all.
   fr_t y;
   if (dom_any >= 0) {
-    const int owner = (dom_any >> 3) % G;  // oct index od = k*G + lane
+    const int owner = (dom_any >> 4) % G;  // hex index hd = k*G + lane
 #pragma unroll
     for (int q = 0; q < 8; q++) y.v[q] = __shfl(e_dom.v[q], owner, G);  // already plain
   } else {

@@ -484,7 +484,7 @@ def test_kzg_proof_special_points_vs_live_oracle(engine, oracle_setup):
 
 def test_evaluation_kernel_on_and_off_the_domain(engine, oracle_setup, monkeypatch):
     """Polynomial::evaluate (src/kzg/poly.rs:10-33) through the VERIFICATION path's kernel (k_eval_frac, 16 and 64 lanes per
-    blob): random points, 0, 1, r - 1, and -- poly.rs:14-18 -- every one of the eight positions of a bit-reversed group of
+    blob): random points, 0, 1, r - 1, and -- poly.rs:14-18 -- every one of the sixteen positions of a bit-reversed group of
     roots, in the first, the last and interior groups (all lanes of both shapes are hit).  In verify_blob_kzg_proof_batch z
     is a hash output, so only this entry point reaches the kernel's on-domain case."""
     import random
@@ -501,7 +501,7 @@ def test_evaluation_kernel_on_and_off_the_domain(engine, oracle_setup, monkeypat
         zs.append(z)
         want.append(poly.evaluate(elements, z, oracle_setup))
     on_domain = []
-    for octet in (0, 1, 15, 16, 17, 63, 64, 255, 300, 511):
+    for octet in (0, 1, 15, 16, 17, 63, 64, 255, 300, 510, 511):
         on_domain += [8 * octet + j for j in range(8)]
     on_domain += [rng.randrange(4096) for _ in range(16)]
     for i in on_domain:
@@ -530,7 +530,7 @@ def test_evaluation_kernel_on_and_off_the_domain(engine, oracle_setup, monkeypat
 
 def test_two_evaluation_kernels_agree_at_scale(engine, torch_cuda):
     """Polynomial::evaluate lives twice on the device: in the proof path (k_poly: batch inversion, 8 x 32-bit limbs, one
-    workgroup per blob) and in the verification path (k_eval_frac: inversion-free fraction sums over octs of roots, radix
+    workgroup per blob) and in the verification path (k_eval_frac: inversion-free fraction sums over hexes of roots, radix
     2^29, 16 lanes per blob at this size).  Independent code, same answers on 4,100 (blob, z) pairs -- random points plus a
     sprinkling of points on the domain."""
     import random
