@@ -78,15 +78,43 @@ typedef struct kzg_ctx kzg_ctx;
  *
  * Class 22 also keeps a 403-MB latency comb (blocks of 8 points, 64 plane groups) for calls of at most 16 blobs.  Building
  * a table needs up to 13 GB of transient device scratch (XYZZ staging for the batch normalisation) on top of it.
+ *
+ * AUTOMATIC choice (window_bits = 0, what the Rust shim's Setup::load_json passes): the fastest class whose table is within
+ * the caller's BUDGET and fits the HBM that is free when the context is created, with room left for the build scratch, the
+ * call workspace and the caller's blobs:
+ *     class 22, G = 8 (192 GiB)  if the budget allows it and >= 232 GiB are free
+ *     class 22, G = 4 ( 96 GiB)  if the budget allows it and >= 136 GiB are free
+ *     class 16        (12.9 GB)  if the budget allows it and >=  21 GiB are free
+ *     class 8         (100 MB)   otherwise
+ * The budget is table_budget_bytes; 0 means the DEFAULT budget of 100 GiB -- so an unconfigured context never takes more
+ * than the 96-GiB table (2.4 % slower than the 192-GiB one), whatever the device has free -- unless flags carries
+ * KZG_CFG_TABLE_MAX, which lifts the cap (bench.py opts in; 192 GiB on an idle MI355X).  An explicit window_bits /
+ * plane_groups is honoured as given and fails if it cannot be built.  PRECEDENCE, one rule: a non-zero field of kzg_config
+ * beats the environment (KATETH_AMD_WINDOW_BITS, KATETH_AMD_COMB_GROUPS), which beats the automatic choice.
+ * kzg_ctx_window_bits / kzg_ctx_plane_groups / kzg_ctx_table_bytes report what was built.
  */
+#define KZG_CFG_TABLE_MAX 0x1   /* flags: the automatic choice may take the largest table the device has room for (192 GiB) */
+#define KZG_CFG_BUILD_ASYNC 0x2 /* flags: kzg_ctx_create returns as soon as a small first-use table (class 8, 100 MB) stands and
+                                 * builds the chosen table on a background thread, swapping it in between calls; results are
+                                 * identical before and after the swap (kzg_ctx_ready / kzg_ctx_wait_ready) */
+#define KZG_ALL_DEVICES 0xffffffffu /* ndev: every HIP device visible to the process */
 typedef struct kzg_config {
-  int32_t device;       /* HIP device ordinal this context lives on */
-  int32_t window_bits;  /* table class: 22, 16..21 (-> 16), 8..15 (-> 8), 4..7 (-> 4); 0 = AUTOMATIC: the fastest class the device
-                         * has room for when the context is created -- class 22 with G = 8 if >= 232 GiB are free, class 22 with
-                         * G = 4 if >= 136 GiB, class 16 if >= 21 GiB, else class 8.  kzg_ctx_window_bits / kzg_ctx_plane_groups /
-                         * kzg_ctx_table_bytes report what was built */
-  int32_t flags;        /* reserved, must be 0 */
-  int32_t plane_groups; /* G: 1, 2, 4, 8 or 16; 0 = automatic (see the table; class 22: 8 if >= 232 GiB are free, else 4) */
+  int32_t device;       /* HIP device ordinal this context lives on (ignored when ndev != 0) */
+  int32_t window_bits;  /* table class: 22, 16..21 (-> 16), 8..15 (-> 8), 4..7 (-> 4); 0 = automatic (above) */
+  int32_t flags;        /* KZG_CFG_* bits */
+  int32_t plane_groups; /* G: 1, 2, 4, 8 or 16; 0 = automatic (class 22: 8 or 4 as above; the other classes: 16) */
+  uint64_t table_budget_bytes; /* cap on the table the AUTOMATIC choice may build; 0 = default (100 GiB, or none with KZG_CFG_TABLE_MAX) */
+  /* Multi-GPU (`kzg_ctx_create(g1, g2, devices[], ndev, &ctx)`): ndev != 0 makes the context a GROUP
+   * with one member per listed ordinal (an ordinal may be listed more than once: two members on one card).  Every member
+   * holds the full tables; the HOST-BUFFER entry points split a batch into contiguous ranges, one per member, run them on
+   * one host thread per member and write the results straight into the caller's buffers (blobs are independent, src/kzg/
+   * setup.rs:235-242: no collective); batch verification runs phase 1 / phase 2 per member with global indices, merges the
+   * first-error records in the reference's order (src/kzg/setup.rs:259-271) and does ONE pairing check.  The *_dev entry
+   * points, sessions, profiling and introspection act on member 0 (device pointers belong to one device);
+   * kzg_ctx_member(ctx, k) lends member k's single-device context to callers that keep data resident on that GPU. */
+  const int32_t* devices; /* ndev ordinals, or NULL with ndev = KZG_ALL_DEVICES */
+  uint32_t ndev;          /* 0 = a single-device context on `device` */
+  uint32_t reserved;      /* must be 0 */
 } kzg_config;
 
 /* Thread-local text for the last negative return on this thread ("" if none). */
@@ -104,7 +132,23 @@ int32_t kzg_last_error_code(void);
  *   g1_lagrange : 4096 * 48 bytes      g2_monomial : 65 * 96 bytes
  */
 int32_t kzg_ctx_create(const uint8_t* g1_lagrange, const uint8_t* g2_monomial, const kzg_config* cfg, kzg_ctx** out);
+/* The same with the device list as arguments, the shape SURVEY.md section 8(b) wrote down: cfg's devices / ndev are replaced
+ * by the arguments (cfg may be NULL); devices = NULL with ndev = KZG_ALL_DEVICES takes every visible device. */
+int32_t kzg_ctx_create_multi(const uint8_t* g1_lagrange, const uint8_t* g2_monomial, const int32_t* devices, uint32_t ndev, const kzg_config* cfg,
+                             kzg_ctx** out);
 void kzg_ctx_destroy(kzg_ctx* ctx);
+/* HIP devices visible to the process (what KZG_ALL_DEVICES expands to); negative = KZG_FAIL_* */
+int32_t kzg_device_count(void);
+/* members of a group context (1 for a single-device context), member k's device ordinal, and member k as a single-device
+ * context (borrowed: owned and destroyed by `ctx`; member 0 of a single-device context is the context itself) */
+uint32_t kzg_ctx_members(const kzg_ctx* ctx);
+int32_t kzg_ctx_member_device(const kzg_ctx* ctx, uint32_t k);
+const kzg_ctx* kzg_ctx_member(const kzg_ctx* ctx, uint32_t k);
+/* KZG_CFG_BUILD_ASYNC: 1 once the chosen table is in use (always 1 without the flag), 0 while the first-use table serves;
+ * kzg_ctx_wait_ready blocks until then and returns 0, or the KZG_FAIL_* code the background build ended with (the context
+ * then stays on the first-use table).  On a group: all members. */
+int32_t kzg_ctx_ready(const kzg_ctx* ctx);
+int32_t kzg_ctx_wait_ready(const kzg_ctx* ctx);
 
 /* introspection for benches / tests */
 int32_t kzg_ctx_window_bits(const kzg_ctx* ctx);
@@ -153,7 +197,7 @@ int32_t kzg_g1_decompress_batch(const kzg_ctx* ctx, const uint8_t* in48, uint64_
 /*
  * Replaces Polynomial::evaluate (src/kzg/poly.rs:10-33; with Blob::from_slice, src/blob.rs:26-37) for n (blob, z) pairs --
  * the evaluation step of the verification path on its own (there z is a hash output; an evaluation point on the domain,
- * poly.rs:14-18, reaches that kernel only through this call).  At most 16384 pairs per call.
+ * poly.rs:14-18, reaches that kernel only through this call).  Any n: the blobs stream through the staging arena in chunks.
  *   blobs   : n * 131072 bytes          z32 : n * 32 bytes, big-endian canonical
  *   out_y32 : n * 32 bytes, big-endian (zero bytes for a rejected item)
  *   status  : per item 0, KZG_ERR_BLOB_INVALID_FIELD_ELEMENT, or KZG_ERR_FF_NOT_IN_FIELD for z
@@ -238,6 +282,14 @@ int32_t kzg_synth_blobs_dev(const kzg_ctx* ctx, uint64_t seed, uint64_t first_in
  * measured with HIP events.
  */
 int32_t kzg_microbench_fp_mul(const kzg_ctx* ctx, uint64_t lanes, uint64_t iters, float* ms);
+/*
+ * The VALU issue interval the roofline is priced with: SIMD cycles per wave-instruction of v_mad_u64_u32 (the
+ * instruction 76-80 % of the MSM / evaluation / decoding streams consist of) with `waves_per_simd` (1..4) co-resident
+ * waves on every SIMD of the chip, 8 independent chains per wave, `iters` x 32 instructions per lane (median over the
+ * waves, by the shader-clock counter), and the shader clock in GHz the chip sustains under that load (shader-clock
+ * ticks per 100-MHz real-time tick).  floor of a kernel = SQ_INSTS_VALU / SIMDs x cycles_per_inst / clock.
+ */
+int32_t kzg_microbench_valu_issue(const kzg_ctx* ctx, uint32_t waves_per_simd, uint32_t iters, double* cycles_per_inst, double* clock_ghz);
 
 /*
  * On-device self-test of the hand-scheduled multiply: every lane multiplies

@@ -6,6 +6,8 @@
 // fails with KZG_FAIL_NO_DEVICE / KZG_FAIL_HIP.
 #include "engine_internal.hpp"
 #include "setup_kernels.cuh"
+
+#include <algorithm>
 // ---------------------------------------------------------------------------
 // error plumbing
 // ---------------------------------------------------------------------------
@@ -26,6 +28,11 @@ static int32_t fail_detail(int32_t code, int32_t detail, const std::string& msg)
   return code;
 }
 const std::string& last_error_text() { return g_last_error; }
+ErrorSnapshot error_snapshot() { return ErrorSnapshot{g_last_error, g_last_detail}; }
+void error_publish(const ErrorSnapshot& e) {
+  g_last_error = e.text;
+  g_last_detail = e.detail;
+}
 
 
 // ---------------------------------------------------------------------------
@@ -59,6 +66,7 @@ int32_t ws_release(const kzg_ctx* ctx, hipStream_t st) {
 }
 
 
+static void tables_free(CombTables& t);
 const MsmOverride* (*g_msm_override_hook)(kzg_ctx* ctx, uint32_t window_bits) = nullptr;  // set only by the test-only library (tests/window_msm)
 
 // Shape of a fixed-base MSM launch over n blobs: (blob, split) units of 64 lanes, or -- splits = 1, lpb = 32 -- two blobs per
@@ -117,6 +125,7 @@ uint32_t msm_lanes_per_blob(const kzg_ctx* ctx, uint64_t n, uint32_t splits) {
 
 extern "C" uint64_t kzg_ctx_adds_per_blob(const kzg_ctx* ctx) {
   if (!ctx) return 0;
+  std::lock_guard<std::mutex> guard(ctx->lock);
   return ctx->use_comb ? (uint64_t)256u * 64u * ctx->comb.nb : ctx->msm_override->adds_per_blob;
 }
 
@@ -132,7 +141,11 @@ static const char* const PROF_NAMES[PROF_KINDS] = {"k_msm_comb28", "k_challenge*
                                                     "k_var_* (two lincombs)", "k_msm_reduce* + k_g1_compress", "k_comb_transpose"};
 
 extern "C" const char* kzg_ctx_msm_kernel_name(const kzg_ctx* ctx) { return (ctx && ctx->msm_override) ? ctx->msm_override->kernel_name : "k_msm_comb28"; }
-extern "C" int32_t kzg_ctx_plane_groups(const kzg_ctx* ctx) { return (ctx && ctx->use_comb) ? (int32_t)ctx->comb.G : 0; }
+extern "C" int32_t kzg_ctx_plane_groups(const kzg_ctx* ctx) {
+  if (!ctx || !ctx->use_comb) return 0;
+  std::lock_guard<std::mutex> guard(ctx->lock);
+  return (int32_t)ctx->comb.G;
+}
 extern "C" const char* kzg_profile_kind_name(int32_t kind) { return (kind >= 0 && kind < PROF_KINDS) ? PROF_NAMES[kind] : ""; }
 
 extern "C" int32_t kzg_profile_end_kinds(const kzg_ctx* ctx, double* ms_out, uint64_t* launches) {
@@ -211,13 +224,36 @@ EnvKnobs read_env_knobs() {
   }
 }
 
-extern "C" int32_t kzg_ctx_window_bits(const kzg_ctx* ctx) { return ctx ? (int32_t)ctx->window_class : 0; }
-extern "C" uint64_t kzg_ctx_table_bytes(const kzg_ctx* ctx) { return ctx ? ctx->table_bytes : 0; }
+// the table fields may be swapped by the background build (KZG_CFG_BUILD_ASYNC): read under the lock
+extern "C" int32_t kzg_ctx_window_bits(const kzg_ctx* ctx) {
+  if (!ctx) return 0;
+  std::lock_guard<std::mutex> guard(ctx->lock);
+  return (int32_t)ctx->window_class;
+}
+extern "C" uint64_t kzg_ctx_table_bytes(const kzg_ctx* ctx) {
+  if (!ctx) return 0;
+  std::lock_guard<std::mutex> guard(ctx->lock);
+  return ctx->table_bytes;
+}
+extern "C" uint32_t kzg_ctx_members(const kzg_ctx* ctx) { return ctx ? 1u + (uint32_t)ctx->peers.size() : 0u; }
+extern "C" const kzg_ctx* kzg_ctx_member(const kzg_ctx* ctx, uint32_t k) {
+  if (!ctx || k > ctx->peers.size()) return nullptr;
+  return k == 0 ? ctx : ctx->peers[k - 1];
+}
+extern "C" int32_t kzg_ctx_member_device(const kzg_ctx* ctx, uint32_t k) {
+  const kzg_ctx* m = kzg_ctx_member(ctx, k);
+  return m ? m->device : -1;
+}
 
 extern "C" void kzg_ctx_destroy(kzg_ctx* ctx) {
   if (!ctx) return;
+  for (kzg_ctx* p : ctx->peers) kzg_ctx_destroy(p);
+  ctx->peers.clear();
+  ctx->build_cancel.store(true);
+  if (ctx->build_thread.joinable()) ctx->build_thread.join();
   (void)hipSetDevice(ctx->device);
   (void)hipDeviceSynchronize();
+  for (CombTables& t : ctx->retired) tables_free(t);
   if (ctx->d_table) (void)hipFree(ctx->d_table);
   if (ctx->d_table_lat) (void)hipFree(ctx->d_table_lat);
   if (ctx->d_bases_brp) (void)hipFree(ctx->d_bases_brp);
@@ -243,7 +279,7 @@ extern "C" void kzg_ctx_destroy(kzg_ctx* ctx) {
 }
 
 
-// temporary device allocations of ctx_build: freed on every exit path
+// temporary device allocations of a build: freed on every exit path
 struct ScratchAllocs {
   std::vector<void*> ptrs;
   template <class T>
@@ -257,13 +293,43 @@ struct ScratchAllocs {
   }
 };
 
+static void tables_free(CombTables& t) {
+  if (t.d_table) (void)hipFree(t.d_table);
+  if (t.d_table_lat) (void)hipFree(t.d_table_lat);
+  if (t.d_comb_k) (void)hipFree(t.d_comb_k);
+  if (t.d_comb_k_lat) (void)hipFree(t.d_comb_k_lat);
+  t = CombTables{};
+}
+// Makes `t` the tables the context computes with.  Commitment and proof calls read them under ctx->lock; the tables they
+// replace are kept until kzg_ctx_destroy (launches already enqueued hold their addresses).
+static void tables_install(kzg_ctx* ctx, const CombTables& t) {
+  std::lock_guard<std::mutex> guard(ctx->lock);
+  if (ctx->d_table || ctx->d_table_lat || ctx->d_comb_k || ctx->d_comb_k_lat) {
+    CombTables old;
+    old.d_table = ctx->d_table;
+    old.d_table_lat = ctx->d_table_lat;
+    old.d_comb_k = ctx->d_comb_k;
+    old.d_comb_k_lat = ctx->d_comb_k_lat;
+    ctx->retired.push_back(old);
+  }
+  ctx->comb = t.comb;
+  ctx->comb_lat = t.comb_lat;
+  ctx->d_table = t.d_table;
+  ctx->d_table_lat = t.d_table_lat;
+  ctx->d_comb_k = t.d_comb_k;
+  ctx->d_comb_k_lat = t.d_comb_k_lat;
+  ctx->table_bytes = t.table_bytes;
+  ctx->window_class = t.window_class;
+}
+
 // ---- comb table (msm_comb.cuh): G groups x 64 chunks x ep64 subset sums, built a few chunks at a time through an XYZZ
-// staging buffer and the batch normaliser of the window table ----
-static int32_t comb_build_table(kzg_ctx* ctx, const CombGeom& cg, uint4** out_table, ScratchAllocs& scratch, TraceTimer& tt) {
-  hipStream_t st = nullptr;
+// staging buffer and the batch normaliser of the window table.  Everything runs on `st` (the background build of
+// KZG_CFG_BUILD_ASYNC has a stream of its own and never touches the null stream); `cancel` is polled between passes. ----
+static int32_t comb_build_table(const kzg_ctx* ctx, const CombGeom& cg, uint4** out_table, ScratchAllocs& scratch, TraceTimer& tt, hipStream_t st,
+                                const std::atomic<bool>* cancel) {
   uint4* d_table = nullptr;
   HIP_TRY(hipMalloc(&d_table, comb_table_entries(cg) * 96));
-  *out_table = d_table;  // owned by the context from here on (freed in kzg_ctx_destroy)
+  *out_table = d_table;  // owned by the caller's CombTables from here on
   tt.mark("table allocation");
   uint4 *d_B = nullptr, *d_D = nullptr;
   HIP_TRY(scratch.alloc(&d_B, (size_t)cg.G * 4096 * 96));
@@ -282,6 +348,10 @@ static int32_t comb_build_table(kzg_ctx* ctx, const CombGeom& cg, uint4** out_ta
   HIP_TRY(hipMemsetAsync(d_inf_seen, 0, sizeof(uint32_t), st));
   for (uint32_t grp = 0; grp < cg.G; grp++) {
     for (uint32_t q0 = 0; q0 < 64; q0 += nq) {
+      if (cancel && cancel->load()) {
+        (void)hipStreamSynchronize(st);
+        return fail(KZG_FAIL_ARGUMENT, "table build cancelled (context destroyed)");
+      }
       const uint64_t threads = (uint64_t)nq * (cg.ep64 >> sl);
       hipLaunchKernelGGL(k_comb_chain, dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, st, d_B, d_D, grp, q0, nq, cg, sl, d_tmp);
       constexpr int KN = 8;
@@ -290,10 +360,12 @@ static int32_t comb_build_table(kzg_ctx* ctx, const CombGeom& cg, uint4** out_ta
       hipLaunchKernelGGL(k_table_normalize<KN>, dim3((unsigned)((nthreads + 63) / 64)), dim3(64), 0, st, d_tmp, count, d_table,
                          (uint64_t)grp * cg.epg + (uint64_t)q0 * cg.ep64, true, d_inf_seen);
       HIP_TRY(hipGetLastError());
+      if (cancel) HIP_TRY(hipStreamSynchronize(st));  // background build: a pass at a time, so that a cancel is seen within one pass
     }
   }
   uint32_t inf_seen = 0;
-  HIP_TRY(hipMemcpy(&inf_seen, d_inf_seen, sizeof(uint32_t), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpyAsync(&inf_seen, d_inf_seen, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
   tt.mark("comb table build kernels");
   // A subset sum sum_p +-L_p over a block of consecutive setup points is the identity (e.g. repeated or opposite points):
   // the table cannot hold it (affine entries).  The reference's P1::lincomb would accept such a setup; the ceremony file and
@@ -303,79 +375,97 @@ static int32_t comb_build_table(kzg_ctx* ctx, const CombGeom& cg, uint4** out_ta
                                    "(repeated / opposite points); the fixed-base comb table cannot represent it");
   return 0;
 }
-static int32_t comb_build(kzg_ctx* ctx, ScratchAllocs& scratch, TraceTimer& tt) {
-  ctx->table_bytes = comb_table_entries(ctx->comb) * 96;
-  int32_t rc = comb_build_table(ctx, ctx->comb, &ctx->d_table, scratch, tt);
-  if (rc) return rc;
-  if (ctx->comb.nb == 3 && ctx->knobs.lat_table) {  // class 22: the latency comb beside it
-    ctx->comb_lat = comb_make_geom(8, 64);
-    ctx->comb_lat.fair = ctx->comb.fair;
-    rc = comb_build_table(ctx, ctx->comb_lat, &ctx->d_table_lat, scratch, tt);
-    if (rc) return rc;
+
+// class -> blocks per 64 points: 22: 22 + 21 + 21; 16..21: 4 x 16; 8..15: 8 x 8; 4..7: 16 x 4 (the small classes keep test contexts cheap)
+static inline uint32_t class_blocks(uint32_t c) { return c >= 22 ? 3u : (c >= 16 ? 4u : (c >= 8 ? 8u : 16u)); }
+
+// Tables of class c with G plane groups over the context's (already decoded) setup points.  On failure nothing is left allocated.
+static int32_t comb_build_tables(const kzg_ctx* ctx, uint32_t c, uint32_t G, CombTables& t, hipStream_t st, const std::atomic<bool>* cancel) {
+  TraceTimer tt(ctx->knobs.trace, cancel ? "comb_build (background)" : "comb_build");
+  ScratchAllocs scratch;
+  t = CombTables{};
+  const uint32_t nb = class_blocks(c);
+  t.comb = comb_make_geom(nb, G);
+  t.comb.fair = ctx->knobs.comb_fair;
+  t.window_class = nb == 3 ? 22u : 64u / nb;
+  t.table_bytes = comb_table_entries(t.comb) * 96;
+  int32_t rc = comb_build_table(ctx, t.comb, &t.d_table, scratch, tt, st, cancel);
+  if (rc == 0 && nb == 3 && ctx->knobs.lat_table) {  // class 22: the latency comb beside it
+    t.comb_lat = comb_make_geom(8, 64);
+    t.comb_lat.fair = t.comb.fair;
+    rc = comb_build_table(ctx, t.comb_lat, &t.d_table_lat, scratch, tt, st, cancel);
   }
   // K = [c0] S with S = sum of the setup points, summed on the device.  For a Lagrange basis S is the G1 generator (the
   // basis sums to one), but Setup::load_json (src/kzg/setup.rs:46-82) accepts any in-group points and P1::lincomb is
   // right for all of them, so nothing here assumes it.  The ladder runs on the host (255 doublings + additions, once).
-  {
+  auto constant_terms = [&]() -> int32_t {
     uint4* d_sum = nullptr;
     uint32_t* d_sum_inf = nullptr;
     HIP_TRY(scratch.alloc(&d_sum, 96));
     HIP_TRY(scratch.alloc(&d_sum_inf, sizeof(uint32_t)));
-    hipLaunchKernelGGL(k_setup_sum_bases, dim3(1), dim3(64), 0, nullptr, ctx->d_bases_brp, d_sum, d_sum_inf);
+    hipLaunchKernelGGL(k_setup_sum_bases, dim3(1), dim3(64), 0, st, ctx->d_bases_brp, d_sum, d_sum_inf);
     HIP_TRY(hipGetLastError());
     uint32_t h[24], sum_inf = 0;
-    HIP_TRY(hipMemcpy(h, d_sum, 96, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(&sum_inf, d_sum_inf, sizeof(uint32_t), hipMemcpyDeviceToHost));
-    if (!sum_inf) {  // S = O: K = O, no lane starts from it (d_comb_k stays null)
-      fp_t x, y;
-      for (int q = 0; q < 12; q++) {
-        x.v[q] = h[q];
-        y.v[q] = h[12 + q];
-      }
-      // One lane per blob STARTS from the constant term (k_msm_comb28).  That lane doubles its accumulator H - 1 times on
-      // its way down the planes, so it is given [c0 / 2^(H-1)] S: one point per table geometry (main comb, latency comb).
-      auto constant_for = [&](uint32_t H, uint4** d_out) -> int32_t {
-        const uint32_t c0p[8] = KZG_FR_COMB_C0_PLAIN;
-        fr_t c0, two, pw, inv, k;
-        for (int q = 0; q < 8; q++) c0.v[q] = c0p[q];
-        to_mont<FrParams>(c0, c0);
-        two = fr_one();
-        add_mod<FrParams>(two, two, two);
-        pw = fr_one();
-        for (uint32_t i = 0; i + 1 < H; i++) fr_mul(pw, pw, two);  // 2^(H-1)
-        fr_inv(inv, pw);
-        fr_mul(k, c0, inv);
-        from_mont<FrParams>(k, k);  // plain scalar c0 / 2^(H-1) mod r
-        g1_xyzz acc;
-        xyzz_set_inf(acc);
-        for (int bit = 255; bit >= 0; bit--) {
-          xyzz_dbl(acc);
-          if ((k.v[bit >> 5] >> (bit & 31)) & 1u) xyzz_madd(acc, x, y);
-        }
-        fp_t kx, ky;
-        if (!xyzz_to_affine(kx, ky, acc)) return 0;  // the identity: nothing to start from
-        fp_to_r392(kx, kx);  // the table's format: k_msm_comb28 loads K like an entry
-        fp_to_r392(ky, ky);
-        uint32_t hk[24];
-        for (int q = 0; q < 12; q++) {
-          hk[q] = kx.v[q];
-          hk[12 + q] = ky.v[q];
-        }
-        HIP_TRY(hipMalloc(d_out, 96));
-        HIP_TRY(hipMemcpy(*d_out, hk, 96, hipMemcpyHostToDevice));
-        return 0;
-      };
-      int32_t rck = constant_for(ctx->comb.H, &ctx->d_comb_k);
-      if (rck == 0 && ctx->d_table_lat) rck = constant_for(ctx->comb_lat.H, &ctx->d_comb_k_lat);
-      if (rck) return rck;
+    HIP_TRY(hipMemcpyAsync(h, d_sum, 96, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&sum_inf, d_sum_inf, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (sum_inf) return 0;  // S = O: K = O, no lane starts from it (d_comb_k stays null)
+    fp_t x, y;
+    for (int q = 0; q < 12; q++) {
+      x.v[q] = h[q];
+      y.v[q] = h[12 + q];
     }
-  }
-  HIP_TRY(hipDeviceSynchronize());
+    // One lane per blob STARTS from the constant term (k_msm_comb28).  That lane doubles its accumulator H - 1 times on
+    // its way down the planes, so it is given [c0 / 2^(H-1)] S: one point per table geometry (main comb, latency comb).
+    auto constant_for = [&](uint32_t H, uint4** d_out) -> int32_t {
+      const uint32_t c0p[8] = KZG_FR_COMB_C0_PLAIN;
+      fr_t c0, two, pw, inv, k;
+      for (int q = 0; q < 8; q++) c0.v[q] = c0p[q];
+      to_mont<FrParams>(c0, c0);
+      two = fr_one();
+      add_mod<FrParams>(two, two, two);
+      pw = fr_one();
+      for (uint32_t i = 0; i + 1 < H; i++) fr_mul(pw, pw, two);  // 2^(H-1)
+      fr_inv(inv, pw);
+      fr_mul(k, c0, inv);
+      from_mont<FrParams>(k, k);  // plain scalar c0 / 2^(H-1) mod r
+      g1_xyzz acc;
+      xyzz_set_inf(acc);
+      for (int bit = 255; bit >= 0; bit--) {
+        xyzz_dbl(acc);
+        if ((k.v[bit >> 5] >> (bit & 31)) & 1u) xyzz_madd(acc, x, y);
+      }
+      fp_t kx, ky;
+      if (!xyzz_to_affine(kx, ky, acc)) return 0;  // the identity: nothing to start from
+      fp_to_r392(kx, kx);  // the table's format: k_msm_comb28 loads K like an entry
+      fp_to_r392(ky, ky);
+      uint32_t hk[24];
+      for (int q = 0; q < 12; q++) {
+        hk[q] = kx.v[q];
+        hk[12 + q] = ky.v[q];
+      }
+      HIP_TRY(hipMalloc(d_out, 96));
+      HIP_TRY(hipMemcpyAsync(*d_out, hk, 96, hipMemcpyHostToDevice, st));
+      HIP_TRY(hipStreamSynchronize(st));  // hk is a stack buffer
+      return 0;
+    };
+    int32_t rck = constant_for(t.comb.H, &t.d_comb_k);
+    if (rck == 0 && t.d_table_lat) rck = constant_for(t.comb_lat.H, &t.d_comb_k_lat);
+    return rck;
+  };
+  if (rc == 0) rc = constant_terms();
+  if (rc == 0 && hipStreamSynchronize(st) != hipSuccess) rc = fail(KZG_FAIL_HIP, "table build: synchronize failed");
   tt.mark("comb constant term");
-  return 0;
+  if (rc) {
+    const ErrorSnapshot keep = error_snapshot();
+    (void)hipStreamSynchronize(st);
+    tables_free(t);
+    error_publish(keep);
+  }
+  return rc;
 }
 
-static int32_t ctx_build(kzg_ctx* ctx, const uint8_t* g1_lagrange, const uint8_t* g2_monomial) {
+static int32_t ctx_build(kzg_ctx* ctx, const uint8_t* g1_lagrange, const uint8_t* g2_monomial, uint32_t c, uint32_t G) {
   TraceTimer tt(ctx->knobs.trace, "ctx_build");
   ScratchAllocs scratch;
   hipStream_t st = nullptr;
@@ -439,13 +529,16 @@ static int32_t ctx_build(kzg_ctx* ctx, const uint8_t* g1_lagrange, const uint8_t
   hipLaunchKernelGGL(k_setup_eval_tab, dim3(EVAL_TAB_HEXES / 64), dim3(64), 0, st, ctx->d_roots_brp, ctx->d_eval_tab);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
+  tt.mark("roots + evaluation table");
   if (ctx->msm_override && ctx->msm_override->build) {  // test-only library (tests/window_msm)
     int32_t rco = ctx->msm_override->build(ctx);
     if (rco) return rco;
   }
   if (ctx->use_comb) {
-    int32_t rcc = comb_build(ctx, scratch, tt);
+    CombTables t;
+    int32_t rcc = comb_build_tables(ctx, c, G, t, st, nullptr);
     if (rcc) return rcc;
+    tables_install(ctx, t);
   }
   HIP_TRY(hipDeviceSynchronize());
   return 0;
@@ -456,10 +549,10 @@ static int32_t ctx_create_with(const uint8_t* g1_lagrange, const uint8_t* g2_mon
   kzg_ctx* ctx = new (std::nothrow) kzg_ctx();
   if (!ctx) return fail(KZG_FAIL_ARGUMENT, "out of host memory");
   ctx->device = device;
-  // 22: blocks of 22 + 21 + 21; 16..21: 4 x 16; 8..15: 8 x 8; 4..7: 16 x 4 (the small classes keep test contexts cheap)
-  const uint32_t nb = c >= 22 ? 3u : (c >= 16 ? 4u : (c >= 8 ? 8u : 16u));
+  const uint32_t nb = class_blocks(c);
+  ctx->knobs = read_env_knobs();
   ctx->comb = comb_make_geom(nb, G);
-  ctx->comb.fair = read_env_knobs().comb_fair;
+  ctx->comb.fair = ctx->knobs.comb_fair;
   ctx->window_class = nb == 3 ? 22u : 64u / nb;
   if (hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess) {
@@ -468,70 +561,180 @@ static int32_t ctx_create_with(const uint8_t* g1_lagrange, const uint8_t* g2_mon
   }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cus = (uint32_t)prop.multiProcessorCount;
-  ctx->knobs = read_env_knobs();
   if (g_msm_override_hook) ctx->msm_override = g_msm_override_hook(ctx, c);  // test-only library (tests/window_msm), never the product
-  int32_t rc = ctx_build(ctx, g1_lagrange, g2_monomial);
+  int32_t rc = ctx_build(ctx, g1_lagrange, g2_monomial, c, G);
   if (rc != 0) {
-    std::string keep = g_last_error;
-    const int32_t keep_detail = g_last_detail;
+    const ErrorSnapshot keep = error_snapshot();
     kzg_ctx_destroy(ctx);
-    g_last_error = keep;
-    g_last_detail = keep_detail;
+    error_publish(keep);
     return rc;
   }
   *out = ctx;
   return 0;
 }
 
-extern "C" int32_t kzg_ctx_create(const uint8_t* g1_lagrange, const uint8_t* g2_monomial, const kzg_config* cfg, kzg_ctx** out) {
-  if (!g1_lagrange || !g2_monomial || !out) return fail(KZG_FAIL_ARGUMENT, "null argument");
-  *out = nullptr;
+// KZG_CFG_BUILD_ASYNC: the chosen table, built beside the caller's first calls (which run on the first-use table) and
+// swapped in under ctx->lock.  An automatic choice whose allocation fails steps down the ladder; if nothing larger than the
+// first-use table can be built the context simply stays on it (kzg_ctx_wait_ready reports the code).
+static void build_thread_main(kzg_ctx* ctx, std::vector<TableChoice> ladder, bool automatic) {
+  int32_t rc = 0;
+  hipStream_t st = nullptr;
+  if (hipSetDevice(ctx->device) != hipSuccess || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess)
+    rc = fail(KZG_FAIL_HIP, "background table build: stream creation failed");
+  if (rc == 0) {
+    for (const TableChoice& ch : ladder) {
+      if (class_blocks(ch.c) == ctx->comb.nb && ch.G == ctx->comb.G) {  // what already serves: nothing larger could be built
+        break;
+      }
+      CombTables t;
+      rc = comb_build_tables(ctx, ch.c, ch.G, t, st, &ctx->build_cancel);
+      if (rc == 0) {
+        tables_install(ctx, t);
+        break;
+      }
+      if (!automatic || rc != KZG_FAIL_HIP || ctx->build_cancel.load()) break;
+      (void)hipGetLastError();  // an allocation failed: clear it and step down
+    }
+  }
+  if (st) (void)hipStreamDestroy(st);
+  {
+    std::lock_guard<std::mutex> guard(ctx->build_mu);
+    ctx->build_rc = rc;
+    if (rc) ctx->build_err = error_snapshot();
+    ctx->build_running = false;
+  }
+  ctx->build_cv.notify_all();
+}
+
+extern "C" int32_t kzg_ctx_ready(const kzg_ctx* ctx) {
+  if (!ctx) return 0;
+  {
+    std::lock_guard<std::mutex> guard(ctx->build_mu);
+    if (ctx->build_running) return 0;
+  }
+  for (const kzg_ctx* p : ctx->peers)
+    if (!kzg_ctx_ready(p)) return 0;
+  return 1;
+}
+extern "C" int32_t kzg_ctx_wait_ready(const kzg_ctx* ctx) {
+  if (!ctx) return fail(KZG_FAIL_ARGUMENT, "null argument");
+  int32_t rc = 0;
+  {
+    std::unique_lock<std::mutex> guard(ctx->build_mu);
+    ctx->build_cv.wait(guard, [&] { return !ctx->build_running; });
+    rc = ctx->build_rc;
+    if (rc) error_publish(ctx->build_err);
+  }
+  for (const kzg_ctx* p : ctx->peers) {
+    const int32_t rp = kzg_ctx_wait_ready(p);
+    if (rc == 0) rc = rp;
+  }
+  return rc;
+}
+
+extern "C" int32_t kzg_device_count(void) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(KZG_FAIL_NO_DEVICE, "no HIP device visible: the kateth_amd engine has no CPU fallback");
-  int device = cfg ? cfg->device : 0;
-  if (device < 0 || device >= ndev) return fail(KZG_FAIL_ARGUMENT, "device ordinal out of range");
+  return ndev;
+}
+
+// A single-device context on `device` (cfg's device / devices / ndev are not read here).
+int32_t ctx_create_single(const uint8_t* g1_lagrange, const uint8_t* g2_monomial, const kzg_config* cfg, int device, kzg_ctx** out) {
+  *out = nullptr;
   HIP_TRY(hipSetDevice(device));
   // Table class (index bits per lookup = points per block of the comb).  window_bits = 0 -- what Setup::load_json's drop-in
-  // passes, INTEGRATION.md section 5 -- takes the fastest class the device has room for RIGHT NOW, so that the default
-  // context is the benchmarked one on a 288-GB part:
+  // passes, INTEGRATION.md section 5 -- takes the fastest class that is within the caller's budget and that the device has
+  // room for RIGHT NOW (include/kateth_amd.h, kzg_config):
   //   class 22 (blocks of 22 + 21 + 21 points, 49,152 additions per blob), G = 8 plane groups = 192 GiB  if >= 232 GiB are free
   //   class 22, G = 4 = 96 GiB (63 instead of 31 Horner doublings per lane: -2 %)                         if >= 136 GiB
   //   class 16 (blocks of 16, G = 16, 65,536 additions per blob: -25 %) = 12.9 GB                         if >=  21 GiB
   //   class 8  (blocks of 8, G = 16) = 100 MB                                                             otherwise
   // (the margins cover the build's 13 GB of staging, the 0.4-GB latency comb, the call workspace and the caller's blobs).
-  // If the allocation of an automatically chosen table fails all the same (fragmentation, another process), the next
-  // smaller choice is tried.  An explicit window_bits is honoured as given (and fails if it cannot be built);
-  // kzg_ctx_window_bits / kzg_ctx_plane_groups report the choice.
+  // The default budget is 100 GiB: an unconfigured context stops at the 96-GiB table and leaves a 288-GB part two thirds free;
+  // KZG_CFG_TABLE_MAX or an explicit table_budget_bytes moves the cap.  If the allocation of an automatically
+  // chosen table fails all the same (fragmentation, another process), the next smaller choice is tried.  Precedence: a
+  // non-zero field of kzg_config beats the environment (KATETH_AMD_WINDOW_BITS / KATETH_AMD_COMB_GROUPS), which beats the
+  // automatic choice; an explicit class is honoured as given (and fails if it cannot be built).
   constexpr size_t GiB = (size_t)1 << 30;
   constexpr size_t GROUP22_BYTES = (size_t)64 * ((size_t)1 << 22) * 96;  // one plane group of class 22: 24 GiB
+  constexpr size_t CLASS16_BYTES = (size_t)16 * 64 * ((size_t)4 << 15) * 96;
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
-  const uint32_t want = cfg ? (uint32_t)cfg->window_bits : 0u;
+  const int32_t flags = cfg ? cfg->flags : 0;
+  if (flags & ~(KZG_CFG_TABLE_MAX | KZG_CFG_BUILD_ASYNC)) return fail(KZG_FAIL_ARGUMENT, "unknown kzg_config.flags bit");
+  if (cfg && cfg->reserved) return fail(KZG_FAIL_ARGUMENT, "kzg_config.reserved must be 0");
+  uint32_t want = cfg ? (uint32_t)cfg->window_bits : 0u;
+  if (want == 0)
+    if (const char* e = getenv("KATETH_AMD_WINDOW_BITS")) want = (uint32_t)atoi(e);
   if (want != 0 && (want < 4 || want > 22)) return fail(KZG_FAIL_ARGUMENT, "window_bits must be 0 (automatic) or in [4,22]");
   uint32_t G_fixed = (cfg && cfg->plane_groups) ? (uint32_t)cfg->plane_groups : 0u;
-  if (const char* e = getenv("KATETH_AMD_COMB_GROUPS")) G_fixed = (uint32_t)atoi(e);
+  if (G_fixed == 0)
+    if (const char* e = getenv("KATETH_AMD_COMB_GROUPS")) G_fixed = (uint32_t)atoi(e);
   if (G_fixed && !(G_fixed == 1 || G_fixed == 2 || G_fixed == 4 || G_fixed == 8 || G_fixed == 16))
     return fail(KZG_FAIL_ARGUMENT, "plane groups must be 1, 2, 4, 8 or 16");
+  size_t budget = cfg ? (size_t)cfg->table_budget_bytes : 0;
+  if (budget == 0) budget = (flags & KZG_CFG_TABLE_MAX) ? ~(size_t)0 : 100 * GiB;
   // candidates (class, plane groups), fastest first
-  struct Choice {
-    uint32_t c, G;
-    size_t need;
-  };
-  const Choice ladder[4] = {{22, 8, 8 * GROUP22_BYTES + 40 * GiB}, {22, 4, 4 * GROUP22_BYTES + 40 * GiB}, {16, 16, 21 * GiB}, {8, 16, 0}};
-  if (want != 0) {
-    uint32_t G = want >= 22 ? (free_b >= ladder[0].need ? 8u : 4u) : 16u;
+  const TableChoice full[4] = {{22, 8, 8 * GROUP22_BYTES + 40 * GiB}, {22, 4, 4 * GROUP22_BYTES + 40 * GiB}, {16, 16, 21 * GiB}, {8, 16, 0}};
+  const size_t table_of[4] = {8 * GROUP22_BYTES, 4 * GROUP22_BYTES, CLASS16_BYTES, 0};
+  std::vector<TableChoice> ladder;
+  const bool automatic = want == 0;
+  if (!automatic) {
+    uint32_t G = want >= 22 ? (free_b >= full[0].need ? 8u : 4u) : 16u;  // the budget bounds the AUTOMATIC choice only
     if (G_fixed) G = G_fixed;
-    return ctx_create_with(g1_lagrange, g2_monomial, device, want, G, out);
+    ladder.push_back(TableChoice{want, G, 0});
+  } else {
+    for (int k = 0; k < 4; k++)
+      if (free_b >= full[k].need && budget >= table_of[k]) ladder.push_back(TableChoice{full[k].c, G_fixed ? G_fixed : full[k].G, full[k].need});
+  }
+  if (ladder.empty()) ladder.push_back(TableChoice{8, G_fixed ? G_fixed : 16u, 0});
+  // KZG_CFG_BUILD_ASYNC: stand up on the 100-MB class-8 table (the reference's load_json is 4,096 + 65 decompressions,
+  // src/kzg/setup.rs:59-72 -- the context is usable after about as much work), build the chosen table beside the first calls
+  if ((flags & KZG_CFG_BUILD_ASYNC) && !g_msm_override_hook && class_blocks(ladder[0].c) < 8u) {
+    kzg_ctx* ctx = nullptr;
+    int32_t rc = ctx_create_with(g1_lagrange, g2_monomial, device, 8, 16, &ctx);
+    if (rc) return rc;
+    {
+      std::lock_guard<std::mutex> guard(ctx->build_mu);
+      ctx->build_running = true;
+    }
+    try {
+      ctx->build_thread = std::thread(build_thread_main, ctx, ladder, automatic);
+    } catch (...) {  // no thread to be had: build in the caller's time after all
+      build_thread_main(ctx, ladder, automatic);
+    }
+    *out = ctx;
+    return 0;
   }
   int32_t rc = fail(KZG_FAIL_HIP, "no table class fits");
-  for (const Choice& ch : ladder) {
-    if (free_b < ch.need) continue;
-    rc = ctx_create_with(g1_lagrange, g2_monomial, device, ch.c, G_fixed ? G_fixed : ch.G, out);
-    if (rc != KZG_FAIL_HIP) return rc;  // built, or rejected for a reason a smaller table would not cure (bad setup point, ...)
-    (void)hipGetLastError();             // an allocation failed: clear it and step down
+  for (const TableChoice& ch : ladder) {
+    rc = ctx_create_with(g1_lagrange, g2_monomial, device, ch.c, ch.G, out);
+    if (!automatic || rc != KZG_FAIL_HIP) return rc;  // built, or rejected for a reason a smaller table would not cure (bad setup point, ...)
+    (void)hipGetLastError();                          // an allocation failed: clear it and step down
   }
   return rc;
+}
+
+extern "C" int32_t kzg_ctx_create(const uint8_t* g1_lagrange, const uint8_t* g2_monomial, const kzg_config* cfg, kzg_ctx** out) {
+  if (!g1_lagrange || !g2_monomial || !out) return fail(KZG_FAIL_ARGUMENT, "null argument");
+  *out = nullptr;
+  const int32_t ndev = kzg_device_count();
+  if (ndev < 0) return ndev;
+  if (cfg && cfg->ndev != 0) return group_create(g1_lagrange, g2_monomial, cfg, out);  // engine_multi.hip
+  const int device = cfg ? cfg->device : 0;
+  if (device < 0 || device >= ndev) return fail(KZG_FAIL_ARGUMENT, "device ordinal out of range");
+  return ctx_create_single(g1_lagrange, g2_monomial, cfg, device, out);
+}
+
+extern "C" int32_t kzg_ctx_create_multi(const uint8_t* g1_lagrange, const uint8_t* g2_monomial, const int32_t* devices, uint32_t ndev,
+                                        const kzg_config* cfg, kzg_ctx** out) {
+  kzg_config c{};
+  if (cfg) c = *cfg;
+  c.devices = devices;
+  c.ndev = ndev;
+  if (ndev == 0) return fail(KZG_FAIL_ARGUMENT, "kzg_ctx_create_multi: ndev must not be 0 (KZG_ALL_DEVICES = every visible device)");
+  return kzg_ctx_create(g1_lagrange, g2_monomial, &c, out);
 }
 
 // ---------------------------------------------------------------------------
@@ -612,18 +815,13 @@ static std::vector<uint64_t> commit_host_plan(uint64_t n) {
   return plan;
 }
 
-static int32_t commit_host(const kzg_ctx* ctx, const uint8_t* blobs, uint64_t n, uint8_t* out48, uint8_t* out_affine96, int32_t* status) {
+int32_t commit_host(const kzg_ctx* ctx, const uint8_t* blobs, uint64_t n, uint8_t* out48, uint8_t* out_affine96, int32_t* status) {
   if (!ctx || (n && (!blobs || (!out48 && !out_affine96) || !status))) return fail(KZG_FAIL_ARGUMENT, "null argument");
   if (n == 0) return 0;
   HIP_TRY(hipSetDevice(ctx->device));
   const std::vector<uint64_t> plan = commit_host_plan(n);
-  uint64_t max_chunk = 0, max_units = 1;
-  for (uint64_t m : plan) {
-    const uint32_t sp = choose_splits(ctx, m);
-    const uint64_t units = msm_units(m, sp, msm_lanes_per_blob(ctx, m, sp));
-    max_chunk = m > max_chunk ? m : max_chunk;
-    max_units = units > max_units ? units : max_units;
-  }
+  uint64_t max_chunk = 0;
+  for (uint64_t m : plan) max_chunk = m > max_chunk ? m : max_chunk;
   // Pooled resources: the staging arena, the result buffers, the streams and the events belong to the context
   // (stage_lock), so a steady-state call allocates nothing; the streams are ordered by events only -- the host never waits
   // inside the loop.
@@ -640,6 +838,12 @@ static int32_t commit_host(const kzg_ctx* ctx, const uint8_t* blobs, uint64_t n,
   hipStream_t copy_st = ctx->stage_copy_stream;
   hipStream_t comp[2] = {ctx->stage_streams[0], ctx->stage_streams[1]};
   std::lock_guard<std::mutex> guard(ctx->lock);  // the workspace: per slot the lane sums, the sums and the bit-plane masks of a chunk
+  uint64_t max_units = 1;  // launch shapes follow the table in use, which only changes under this lock
+  for (uint64_t m : plan) {
+    const uint32_t sp = choose_splits(ctx, m);
+    const uint64_t units = msm_units(m, sp, msm_lanes_per_blob(ctx, m, sp));
+    max_units = units > max_units ? units : max_units;
+  }
   do {
     const size_t partial_bytes = align_up((size_t)max_units * 65 * sizeof(g1_xyzz), 256);
     const size_t sums_bytes = align_up((size_t)max_chunk * sizeof(g1_xyzz), 256);
@@ -699,10 +903,12 @@ static int32_t commit_host(const kzg_ctx* ctx, const uint8_t* blobs, uint64_t n,
 
 extern "C" int32_t kzg_blob_to_commitment_batch(const kzg_ctx* ctx, const uint8_t* blobs, uint64_t n, uint8_t* out48, int32_t* status) {
   if (n && !out48) return fail(KZG_FAIL_ARGUMENT, "null argument");
+  if (is_group(ctx)) return multi_commit(ctx, blobs, n, out48, nullptr, status);
   return commit_host(ctx, blobs, n, out48, nullptr, status);
 }
 extern "C" int32_t kzg_blob_to_commitment_batch_affine(const kzg_ctx* ctx, const uint8_t* blobs, uint64_t n, uint8_t* out_affine96, int32_t* status) {
   if (n && !out_affine96) return fail(KZG_FAIL_ARGUMENT, "null argument");
+  if (is_group(ctx)) return multi_commit(ctx, blobs, n, nullptr, out_affine96, status);
   return commit_host(ctx, blobs, n, nullptr, out_affine96, status);
 }
 
@@ -761,6 +967,68 @@ extern "C" int32_t kzg_microbench_fp_mul(const kzg_ctx* ctx, uint64_t lanes, uin
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   (void)hipFree(d_out);
+  return 0;
+}
+
+// ISSUE interval of the instruction the hot loops are made of (v_mad_u64_u32: 76-80 % of the MSM, evaluation and decoding
+// streams) with `w` waves per SIMD on the whole chip, and the shader clock that load sustains: 8 INDEPENDENT chains per
+// wave, so no dependent-latency effect is measured.  Occupancy is forced with LDS (a 256-thread workgroup = one wave per
+// SIMD takes 160 KiB / w).  bench.py prices SQ_INSTS_VALU with these two numbers (roofline.valu_issue).
+__global__ __launch_bounds__(256) void k_microbench_valu_issue(uint32_t* out, unsigned long long* ticks, uint32_t iters, uint32_t seed) {
+  extern __shared__ uint32_t issue_lds[];
+  uint64_t x[8];
+  for (int c = 0; c < 8; c++) x[c] = ((uint64_t)(seed + threadIdx.x * 7 + c * 0x9e3779b9u) << 20) | 0x3ff0000000000001ull;
+  const uint32_t y = seed ^ 0x5555u ^ threadIdx.x, z = seed + 3u;
+  if (threadIdx.x == 0) issue_lds[0] = seed;  // touch the allocation
+  __syncthreads();
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();      // shader clock
+#pragma unroll 1
+  for (uint32_t it = 0; it < iters; it++) {
+#pragma unroll
+    for (int rep = 0; rep < 4; rep++) {
+#pragma unroll
+      for (int c = 0; c < 8; c++) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(x[c]) : "v"(y), "v"(z) : "vcc");
+    }
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  uint64_t r = 0;
+  for (int c = 0; c < 8; c++) r ^= x[c];
+  out[blockIdx.x * 256 + threadIdx.x] = (uint32_t)r ^ (uint32_t)(r >> 32);
+  if ((threadIdx.x & 63) == 0) {
+    ticks[2 * (blockIdx.x * 4 + (threadIdx.x >> 6))] = t1 - t0;
+    ticks[2 * (blockIdx.x * 4 + (threadIdx.x >> 6)) + 1] = r1 - r0;
+  }
+}
+
+extern "C" int32_t kzg_microbench_valu_issue(const kzg_ctx* ctx, uint32_t waves_per_simd, uint32_t iters, double* cycles_per_inst, double* clock_ghz) {
+  if (!ctx || !cycles_per_inst || !clock_ghz || waves_per_simd < 1 || waves_per_simd > 4 || iters == 0) return fail(KZG_FAIL_ARGUMENT, "bad argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  const uint32_t blocks = ctx->num_cus * waves_per_simd;
+  const size_t lds = (size_t)(160 * 1024) / waves_per_simd - 1024;  // at most `waves_per_simd` workgroups per CU
+  HIP_TRY(hipFuncSetAttribute((const void*)k_microbench_valu_issue, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  uint32_t* d_out = nullptr;
+  unsigned long long* d_ticks = nullptr;
+  HIP_TRY(hipMalloc(&d_out, (size_t)blocks * 256 * 4));
+  HIP_TRY(hipMalloc(&d_ticks, (size_t)blocks * 4 * 2 * 8));
+  hipLaunchKernelGGL(k_microbench_valu_issue, dim3(blocks), dim3(256), lds, nullptr, d_out, d_ticks, 64u, 1u);  // warm-up: clocks ramp
+  hipLaunchKernelGGL(k_microbench_valu_issue, dim3(blocks), dim3(256), lds, nullptr, d_out, d_ticks, iters, 1u);
+  std::vector<unsigned long long> t((size_t)blocks * 4 * 2);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpy(t.data(), d_ticks, t.size() * 8, hipMemcpyDeviceToHost);
+  (void)hipFree(d_out);
+  (void)hipFree(d_ticks);
+  if (e != hipSuccess) return fail(KZG_FAIL_HIP, std::string("valu issue microbenchmark: ") + hipGetErrorString(e));
+  std::vector<double> cyc, ghz;
+  for (size_t i = 0; i < t.size(); i += 2) {
+    cyc.push_back((double)t[i] / ((double)iters * 32.0 * waves_per_simd));
+    if (t[i + 1]) ghz.push_back((double)t[i] / ((double)t[i + 1] * 10.0));
+  }
+  std::sort(cyc.begin(), cyc.end());
+  std::sort(ghz.begin(), ghz.end());
+  *cycles_per_inst = cyc[cyc.size() / 2];  // median over the waves
+  *clock_ghz = ghz.empty() ? 0.0 : ghz[ghz.size() / 2];
   return 0;
 }
 

@@ -8,9 +8,11 @@
 
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -24,6 +26,50 @@ using namespace kzg;
 
 int32_t fail(int32_t code, const std::string& msg);
 const std::string& last_error_text();
+// kzg_last_error / kzg_last_error_code are thread-local: work done on a helper thread hands its error to the calling thread
+struct ErrorSnapshot {
+  std::string text;
+  int32_t detail = 0;
+};
+ErrorSnapshot error_snapshot();
+void error_publish(const ErrorSnapshot& e);
+
+// Runs job(k) for k < count: job 0 on the calling thread, the others on one helper thread each (a helper that cannot be
+// started -- thread exhaustion -- runs inline instead: nothing throws across the C boundary).  Returns the first non-zero
+// code in k order, with THAT job's error text re-published on the calling thread.
+template <class Job>
+static int32_t run_on_helpers(uint32_t count, Job&& job) {
+  if (count == 0) return 0;
+  std::vector<int32_t> rc(count, 0);
+  std::vector<ErrorSnapshot> err(count);
+  std::vector<std::thread> helpers;
+  helpers.reserve(count);
+  std::vector<char> started(count, 0);
+  for (uint32_t k = 1; k < count; k++) {
+    try {
+      helpers.emplace_back([&, k]() {
+        rc[k] = job(k);
+        if (rc[k]) err[k] = error_snapshot();
+      });
+      started[k] = 1;
+    } catch (...) {  // std::system_error: no thread to be had
+    }
+  }
+  rc[0] = job(0);
+  if (rc[0]) err[0] = error_snapshot();
+  for (uint32_t k = 1; k < count; k++)
+    if (!started[k]) {
+      rc[k] = job(k);
+      if (rc[k]) err[k] = error_snapshot();
+    }
+  for (auto& t : helpers) t.join();
+  for (uint32_t k = 0; k < count; k++)
+    if (rc[k]) {
+      error_publish(err[k]);
+      return rc[k];
+    }
+  return 0;
+}
 
 #define HIP_TRY(expr)                                                                                      \
   do {                                                                                                     \
@@ -89,8 +135,34 @@ struct MsmOverride {
 };
 extern const MsmOverride* (*g_msm_override_hook)(kzg_ctx* ctx, uint32_t window_bits);  // nullptr in the product library
 
+// The fixed-base tables a context computes with: the main comb, (class 22) the latency comb, their constant terms.
+struct CombTables {
+  CombGeom comb{}, comb_lat{};
+  uint4 *d_table = nullptr, *d_table_lat = nullptr, *d_comb_k = nullptr, *d_comb_k_lat = nullptr;
+  uint64_t table_bytes = 0;
+  uint32_t window_class = 0;
+};
+struct TableChoice {  // a candidate (class, plane groups) of the automatic ladder and the free HBM it asks for
+  uint32_t c, G;
+  size_t need;
+};
+
 struct kzg_ctx {
   int device = 0;
+  // GROUP context (kzg_config.ndev != 0): this context is member 0, `peers` are the members on the other listed devices
+  // (owned, single-device contexts).  The host-buffer entry points shard over {this, peers...} (engine_multi.hip).
+  std::vector<kzg_ctx*> peers;
+  mutable std::atomic<uint32_t> rr{0};  // calls with fewer items than members start at a rotating member
+  // KZG_CFG_BUILD_ASYNC: the chosen table is built by `build_thread` and swapped in under `lock`; the tables it replaces
+  // stay allocated until kzg_ctx_destroy (launches already enqueued may still read them)
+  std::thread build_thread;
+  std::atomic<bool> build_cancel{false};
+  mutable std::mutex build_mu;
+  mutable std::condition_variable build_cv;
+  bool build_running = false;  // guarded by build_mu
+  int32_t build_rc = 0;
+  ErrorSnapshot build_err;
+  std::vector<CombTables> retired;
   uint4* d_table = nullptr;      // fixed-base comb table (msm_comb.cuh): comb_table_entries(comb) * 96 B
   bool use_comb = true;          // false only under a test override that replaces the table
   CombGeom comb{};
@@ -144,6 +216,29 @@ struct kzg_ctx {
   mutable hipEvent_t stage_copied[KZG_STAGE_SLOTS] = {}, stage_done[KZG_STAGE_SLOTS] = {}, stage_join[KZG_STAGE_STREAMS] = {};
 };
 void session_pool_clear(const kzg_ctx* ctx);
+
+// ---- single-device implementations behind the host-buffer entry points; the extern "C" wrappers hand GROUP contexts to
+// engine_multi.hip, which shards a batch over the members and calls these per member ----
+static inline bool is_group(const kzg_ctx* ctx) { return ctx && !ctx->peers.empty(); }
+int32_t ctx_create_single(const uint8_t* g1_lagrange, const uint8_t* g2_monomial, const kzg_config* cfg, int device, kzg_ctx** out);  // engine.hip
+int32_t commit_host(const kzg_ctx* ctx, const uint8_t* blobs, uint64_t n, uint8_t* out48, uint8_t* out_affine96, int32_t* status);    // engine.hip
+int32_t proof_host(const kzg_ctx* ctx, const uint8_t* blobs, const uint8_t* side, size_t side_bytes, bool side_is_commitment, uint64_t n, uint8_t* out48,
+                   uint8_t* out_affine96, uint8_t* out_y32, int32_t* status);  // engine_proof.hip
+int32_t verify_phase1_host(const kzg_ctx* ctx, const uint8_t* blobs, const uint8_t* commitments48, const uint8_t* proofs48, uint64_t n, uint8_t* out_root32,
+                           int32_t* err6, kzg_verify_session** session);  // engine_verify.hip
+int32_t verify_batch_host_single(const kzg_ctx* ctx, const uint8_t* blobs, const uint8_t* commitments48, const uint8_t* proofs48, uint64_t n, int32_t* ok);
+int32_t verify_proof_single(const kzg_ctx* ctx, const uint8_t* proof48, const uint8_t* commitment48, const uint8_t* z32, const uint8_t* y32, int32_t* ok);
+int32_t g1_decompress_single(const kzg_ctx* ctx, const uint8_t* in48, uint64_t n, uint8_t* out_affine96, int32_t* status);
+int32_t evaluate_blobs_single(const kzg_ctx* ctx, const uint8_t* blobs, const uint8_t* z32, uint64_t n, uint8_t* out_y32, int32_t* status);
+// engine_multi.hip
+int32_t group_create(const uint8_t* g1_lagrange, const uint8_t* g2_monomial, const kzg_config* cfg, kzg_ctx** out);
+int32_t multi_commit(const kzg_ctx* ctx, const uint8_t* blobs, uint64_t n, uint8_t* out48, uint8_t* out_affine96, int32_t* status);
+int32_t multi_proof(const kzg_ctx* ctx, const uint8_t* blobs, const uint8_t* side, size_t side_bytes, bool side_is_commitment, uint64_t n, uint8_t* out48,
+                    uint8_t* out_affine96, uint8_t* out_y32, int32_t* status);
+int32_t multi_verify_batch(const kzg_ctx* ctx, const uint8_t* blobs, const uint8_t* commitments48, const uint8_t* proofs48, uint64_t n, int32_t* ok);
+int32_t multi_verify_proof(const kzg_ctx* ctx, const uint8_t* proof48, const uint8_t* commitment48, const uint8_t* z32, const uint8_t* y32, int32_t* ok);
+int32_t multi_g1_decompress(const kzg_ctx* ctx, const uint8_t* in48, uint64_t n, uint8_t* out_affine96, int32_t* status);
+int32_t multi_evaluate_blobs(const kzg_ctx* ctx, const uint8_t* blobs, const uint8_t* z32, uint64_t n, uint8_t* out_y32, int32_t* status);
 int32_t stage_init(const kzg_ctx* ctx);                                             // caller holds stage_lock
 int32_t stage_reserve(const kzg_ctx* ctx, size_t arena_bytes, size_t io_bytes);   // caller holds stage_lock
 void stage_destroy(const kzg_ctx* ctx);

@@ -155,7 +155,7 @@ extern "C" int32_t kzg_compute_blob_proof_batch_dev(const kzg_ctx* ctx, const vo
 // streams, every chunk's MSM as one wave per SIMD: 44.7 ms at 4,096 but 170 ms at 16,384 -- the short kernels of later chunks
 // (k_poly: 8-wave workgroups of 126 VGPRs) find no register space beside two resident MSM chunks (2 x 232 VGPRs per SIMD)
 // and wait for a whole chunk to drain, so the pipeline degenerates to two-deep serial passes.
-static int32_t proof_host(const kzg_ctx* ctx, const uint8_t* blobs, const uint8_t* side, size_t side_bytes, bool side_is_commitment, uint64_t n,
+int32_t proof_host(const kzg_ctx* ctx, const uint8_t* blobs, const uint8_t* side, size_t side_bytes, bool side_is_commitment, uint64_t n,
                           uint8_t* out48, uint8_t* out_affine96, uint8_t* out_y32, int32_t* status) {
   if (n == 0) return 0;
   HIP_TRY(hipSetDevice(ctx->device));
@@ -236,21 +236,21 @@ static int32_t proof_host(const kzg_ctx* ctx, const uint8_t* blobs, const uint8_
 extern "C" int32_t kzg_compute_blob_proof_batch(const kzg_ctx* ctx, const uint8_t* blobs, const uint8_t* commitments48, uint64_t n,
                                                 uint8_t* out48, int32_t* status) {
   if (!ctx || (n && (!blobs || !commitments48 || !out48 || !status))) return fail(KZG_FAIL_ARGUMENT, "null argument");
-  return proof_host(ctx, blobs, commitments48, 48, true, n, out48, nullptr, nullptr, status);
+  return (is_group(ctx) ? multi_proof : proof_host)(ctx, blobs, commitments48, 48, true, n, out48, nullptr, nullptr, status);
 }
 extern "C" int32_t kzg_compute_blob_proof_batch_affine(const kzg_ctx* ctx, const uint8_t* blobs, const uint8_t* commitments48, uint64_t n,
                                                        uint8_t* out_affine96, int32_t* status) {
   if (!ctx || (n && (!blobs || !commitments48 || !out_affine96 || !status))) return fail(KZG_FAIL_ARGUMENT, "null argument");
-  return proof_host(ctx, blobs, commitments48, 48, true, n, nullptr, out_affine96, nullptr, status);
+  return (is_group(ctx) ? multi_proof : proof_host)(ctx, blobs, commitments48, 48, true, n, nullptr, out_affine96, nullptr, status);
 }
 
 extern "C" int32_t kzg_compute_proof_batch(const kzg_ctx* ctx, const uint8_t* blobs, const uint8_t* z32, uint64_t n, uint8_t* out_proof48,
                                            uint8_t* out_y32, int32_t* status) {
   if (!ctx || (n && (!blobs || !z32 || !out_proof48 || !out_y32 || !status))) return fail(KZG_FAIL_ARGUMENT, "null argument");
-  return proof_host(ctx, blobs, z32, 32, false, n, out_proof48, nullptr, out_y32, status);
+  return (is_group(ctx) ? multi_proof : proof_host)(ctx, blobs, z32, 32, false, n, out_proof48, nullptr, out_y32, status);
 }
 extern "C" int32_t kzg_compute_proof_batch_affine(const kzg_ctx* ctx, const uint8_t* blobs, const uint8_t* z32, uint64_t n, uint8_t* out_proof_affine96,
                                                   uint8_t* out_y32, int32_t* status) {
   if (!ctx || (n && (!blobs || !z32 || !out_proof_affine96 || !out_y32 || !status))) return fail(KZG_FAIL_ARGUMENT, "null argument");
-  return proof_host(ctx, blobs, z32, 32, false, n, nullptr, out_proof_affine96, out_y32, status);
+  return (is_group(ctx) ? multi_proof : proof_host)(ctx, blobs, z32, 32, false, n, nullptr, out_proof_affine96, out_y32, status);
 }

@@ -593,8 +593,8 @@ void stage_destroy(const kzg_ctx* ctx) {
 // copy stream while the per-blob kernels (challenge + evaluation are per blob) of earlier chunks run on rotating compute
 // streams -- the n * 128 KiB never have to be resident at once and the transfer overlaps the hashing.  Commitments and
 // proofs (96 B per item) are copied whole and decoded once on the session's side stream.
-static int32_t verify_phase1_host(const kzg_ctx* ctx, const uint8_t* blobs, const uint8_t* commitments48, const uint8_t* proofs48, uint64_t n,
-                                  uint8_t* out_root32, int32_t* err6, kzg_verify_session** session) {
+int32_t verify_phase1_host(const kzg_ctx* ctx, const uint8_t* blobs, const uint8_t* commitments48, const uint8_t* proofs48, uint64_t n, uint8_t* out_root32,
+                           int32_t* err6, kzg_verify_session** session) {
   *session = nullptr;
   TraceTimer tt(ctx->knobs.trace, "phase1(host buffers)");
   for (int k = 0; k < 6; k++) err6[k] = (k % 2 == 0) ? -1 : 0;
@@ -719,6 +719,9 @@ __global__ __launch_bounds__(64) void k_g1_decompress_public(const uint8_t* __re
 extern "C" int32_t kzg_g1_decompress_batch(const kzg_ctx* ctx, const uint8_t* in48, uint64_t n, uint8_t* out_affine96, int32_t* status) {
   if (!ctx || (n && (!in48 || !out_affine96 || !status))) return fail(KZG_FAIL_ARGUMENT, "null argument");
   if (n == 0) return 0;
+  return (is_group(ctx) ? multi_g1_decompress : g1_decompress_single)(ctx, in48, n, out_affine96, status);
+}
+int32_t g1_decompress_single(const kzg_ctx* ctx, const uint8_t* in48, uint64_t n, uint8_t* out_affine96, int32_t* status) {
   HIP_TRY(hipSetDevice(ctx->device));
   std::lock_guard<std::mutex> guard(ctx->stage_lock);  // pooled device buffers + an idle stream of the host-buffer pipelines
   int32_t rc = stage_init(ctx);
@@ -748,42 +751,70 @@ extern "C" int32_t kzg_g1_decompress_batch(const kzg_ctx* ctx, const uint8_t* in
 extern "C" int32_t kzg_evaluate_blobs(const kzg_ctx* ctx, const uint8_t* blobs, const uint8_t* z32, uint64_t n, uint8_t* out_y32, int32_t* status) {
   if (!ctx || (n && (!blobs || !z32 || !out_y32 || !status))) return fail(KZG_FAIL_ARGUMENT, "null argument");
   if (n == 0) return 0;
-  if (n > 16384) return fail(KZG_FAIL_ARGUMENT, "kzg_evaluate_blobs: at most 16384 pairs per call");
+  return (is_group(ctx) ? multi_evaluate_blobs : evaluate_blobs_single)(ctx, blobs, z32, n, out_y32, status);
+}
+// The blobs cross PCIe through the staging arena in chunks of up to 2,048 (two slots: the copy of chunk k+1 beside the
+// evaluation of chunk k); only z, y and the statuses live in the small host-i/o pool, so a large call pins nothing.
+int32_t evaluate_blobs_single(const kzg_ctx* ctx, const uint8_t* blobs, const uint8_t* z32, uint64_t n, uint8_t* out_y32, int32_t* status) {
   HIP_TRY(hipSetDevice(ctx->device));
-  std::lock_guard<std::mutex> guard(ctx->stage_lock);  // pooled device buffers + an idle stream of the host-buffer pipelines
+  std::lock_guard<std::mutex> guard(ctx->stage_lock);  // pooled device buffers + idle streams of the host-buffer pipelines
   int32_t rc = stage_init(ctx);
   if (rc) return rc;
-  const size_t o_z32 = align_up((size_t)n * KZG_BYTES_PER_BLOB, 256), o_y32 = o_z32 + align_up((size_t)n * 32, 256);
-  const size_t o_z = o_y32 + align_up((size_t)n * 32, 256), o_y = o_z + align_up((size_t)n * sizeof(fr_t), 256);
+  const uint64_t chunk = n < 2048 ? n : 2048;
+  const uint64_t nchunks = (n + chunk - 1) / chunk;
+  const uint64_t slots = nchunks > 1 ? 2 : 1;
+  const size_t slot_bytes = (size_t)chunk * KZG_BYTES_PER_BLOB;
+  const size_t o_y32 = align_up((size_t)n * 32, 256), o_z = o_y32 + align_up((size_t)n * 32, 256), o_y = o_z + align_up((size_t)n * sizeof(fr_t), 256);
   const size_t o_st = o_y + align_up((size_t)n * sizeof(fr_t), 256);
-  rc = stage_reserve(ctx, 0, o_st + (size_t)n * sizeof(int32_t));
+  rc = stage_reserve(ctx, slots * slot_bytes, o_st + (size_t)n * sizeof(int32_t));
   if (rc) return rc;
-  uint8_t* d_blobs = ctx->hostio;
-  uint8_t* d_z32 = ctx->hostio + o_z32;
+  uint8_t* d_z32 = ctx->hostio;
   uint8_t* d_y32 = ctx->hostio + o_y32;
   fr_t* d_z = reinterpret_cast<fr_t*>(ctx->hostio + o_z);
   fr_t* d_y = reinterpret_cast<fr_t*>(ctx->hostio + o_y);
   int32_t* d_st = reinterpret_cast<int32_t*>(ctx->hostio + o_st);
-  hipStream_t st = ctx->stage_streams[0];
-  HIP_TRY(hipMemcpyAsync(d_blobs, blobs, (size_t)n * KZG_BYTES_PER_BLOB, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(d_z32, z32, (size_t)n * 32, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemsetAsync(d_st, 0, (size_t)n * sizeof(int32_t), st));
-  hipLaunchKernelGGL(k_fr_parse, dim3(blocks_for(n, 64)), dim3(64), 0, st, d_z32, n, d_z, d_st);
-  bool wide_groups = n < 4096;
-  if (ctx->knobs.eval_group) wide_groups = ctx->knobs.eval_group != 16;
-  {
-    ProfScope ps(ctx, PROF_EVAL, st);
-    if (!wide_groups)
-      hipLaunchKernelGGL(k_eval_frac<16>, dim3(blocks_for(n, 4)), dim3(64), 0, st, d_blobs, d_z, ctx->d_roots_brp, ctx->d_eval_tab, d_y, d_st, n);
-    else
-      hipLaunchKernelGGL(k_eval_frac<64>, dim3((unsigned)n), dim3(64), 0, st, d_blobs, d_z, ctx->d_roots_brp, ctx->d_eval_tab, d_y, d_st, n);
+  hipStream_t st = ctx->stage_streams[0], copy_st = ctx->stage_copy_stream;
+  do {
+    if (hipMemcpyAsync(d_z32, z32, (size_t)n * 32, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemsetAsync(d_st, 0, (size_t)n * sizeof(int32_t), st) != hipSuccess) {
+      rc = fail(KZG_FAIL_HIP, "host-to-device copy failed");
+      break;
+    }
+    hipLaunchKernelGGL(k_fr_parse, dim3(blocks_for(n, 64)), dim3(64), 0, st, d_z32, n, d_z, d_st);
+    bool wide_groups = n < 4096;
+    if (ctx->knobs.eval_group) wide_groups = ctx->knobs.eval_group != 16;
+    for (uint64_t k = 0; k < nchunks && rc == 0; k++) {
+      const uint64_t slot = k % slots, base = k * chunk;
+      const uint64_t m = (n - base < chunk) ? (n - base) : chunk;
+      uint8_t* d_blobs = ctx->stage + slot * slot_bytes;
+      if (k >= slots) (void)hipStreamWaitEvent(copy_st, ctx->stage_done[slot], 0);  // the chunk that used this slot has been evaluated
+      if (hipMemcpyAsync(d_blobs, blobs + base * (size_t)KZG_BYTES_PER_BLOB, m * (size_t)KZG_BYTES_PER_BLOB, hipMemcpyHostToDevice, copy_st) != hipSuccess ||
+          hipEventRecord(ctx->stage_copied[slot], copy_st) != hipSuccess || hipStreamWaitEvent(st, ctx->stage_copied[slot], 0) != hipSuccess) {
+        rc = fail(KZG_FAIL_HIP, "host-to-device copy failed");
+        break;
+      }
+      {
+        ProfScope ps(ctx, PROF_EVAL, st);
+        if (!wide_groups)
+          hipLaunchKernelGGL(k_eval_frac<16>, dim3(blocks_for(m, 4)), dim3(64), 0, st, d_blobs, d_z + base, ctx->d_roots_brp, ctx->d_eval_tab, d_y + base,
+                             d_st + base, m);
+        else
+          hipLaunchKernelGGL(k_eval_frac<64>, dim3((unsigned)m), dim3(64), 0, st, d_blobs, d_z + base, ctx->d_roots_brp, ctx->d_eval_tab, d_y + base,
+                             d_st + base, m);
+      }
+      (void)hipEventRecord(ctx->stage_done[slot], st);
+    }
+    if (rc) break;
+    hipLaunchKernelGGL(k_fr_store_be, dim3(blocks_for(n, 256)), dim3(256), 0, st, d_y, n, d_st, d_y32);
+    if (hipGetLastError() != hipSuccess || hipMemcpyAsync(out_y32, d_y32, (size_t)n * 32, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(status, d_st, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+      rc = fail(KZG_FAIL_HIP, "evaluation: launch or read-back failed");
+  } while (0);
+  if (rc) {
+    (void)hipStreamSynchronize(copy_st);
+    (void)hipStreamSynchronize(st);
   }
-  hipLaunchKernelGGL(k_fr_store_be, dim3(blocks_for(n, 256)), dim3(256), 0, st, d_y, n, d_st, d_y32);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(out_y32, d_y32, (size_t)n * 32, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(status, d_st, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
-  return 0;
+  return rc;
 }
 
 extern "C" int32_t kzg_verify_phase2_dev(kzg_verify_session* s, const uint8_t* roots32, uint64_t world, uint64_t first_index, uint64_t n_total,
@@ -844,17 +875,19 @@ extern "C" int32_t kzg_verify_phase2_dev(kzg_verify_session* s, const uint8_t* r
       int32_t rca = 0, rcb = 0;
       if (ja.active && jb.active && (ja.nout + jb.nout) >= 64) {
         const int device = ctx->device;
-        std::thread helper([&ja, &Ax, &rca, device]() {
+        // job 0 (B, the longer one) here, job 1 (A) on a helper thread; a helper's error text is re-published on this thread and
+        // a helper that cannot be started runs inline (run_on_helpers)
+        const int32_t first = run_on_helpers(2, [&](uint32_t k) -> int32_t {
+          if (k == 0) return rcb = msm_var_finish(jb, Bx);
           (void)hipSetDevice(device);
-          rca = msm_var_finish(ja, Ax);
+          return rca = msm_var_finish(ja, Ax);
         });
-        rcb = msm_var_finish(jb, Bx);
-        helper.join();
+        (void)first;
       } else {
         rca = msm_var_finish(ja, Ax);
         rcb = msm_var_finish(jb, Bx);
       }
-      if (rc == 0) rc = rca ? rca : rcb;
+      if (rc == 0) rc = rcb ? rcb : rca;
       tt.mark("msm A || msm B (incl. host horner)");
     } while (0);
     (void)hipStreamSynchronize(st);
@@ -948,6 +981,10 @@ extern "C" int32_t kzg_verify_blob_proof_batch(const kzg_ctx* ctx, const uint8_t
     *ok = 1;
     return 0;
   }
+  return (is_group(ctx) ? multi_verify_batch : verify_batch_host_single)(ctx, blobs, commitments48, proofs48, n, ok);
+}
+int32_t verify_batch_host_single(const kzg_ctx* ctx, const uint8_t* blobs, const uint8_t* commitments48, const uint8_t* proofs48, uint64_t n, int32_t* ok) {
+  *ok = 0;
   HIP_TRY(hipSetDevice(ctx->device));
   uint8_t root[32];
   int32_t err6[6];
@@ -979,6 +1016,9 @@ extern "C" int32_t kzg_verify_blob_proof(const kzg_ctx* ctx, const uint8_t* blob
 extern "C" int32_t kzg_verify_proof(const kzg_ctx* ctx, const uint8_t* proof48, const uint8_t* commitment48, const uint8_t* z32, const uint8_t* y32,
                                     int32_t* ok) {
   if (!ctx || !proof48 || !commitment48 || !z32 || !y32 || !ok) return fail(KZG_FAIL_ARGUMENT, "null argument");
+  return (is_group(ctx) ? multi_verify_proof : verify_proof_single)(ctx, proof48, commitment48, z32, y32, ok);
+}
+int32_t verify_proof_single(const kzg_ctx* ctx, const uint8_t* proof48, const uint8_t* commitment48, const uint8_t* z32, const uint8_t* y32, int32_t* ok) {
   *ok = 0;
   HIP_TRY(hipSetDevice(ctx->device));
   kzg_verify_session* s = nullptr;

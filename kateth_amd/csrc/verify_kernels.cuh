@@ -91,7 +91,7 @@ static __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)
   // z stays in registers (two products per pair); seven multiples of powers of z are read once or twice per hex and live in
   // LDS (one copy per blob group of the wave) -- with the pair-sized prefetch below that keeps the kernel at three waves per SIMD
   enum { Z2 = 0, IZ2 = 1, Z4 = 2, CZ4 = 3, Z8 = 4, SZ8 = 5, Z16 = 6, NZP = 7 };
-  __shared__ uint32_t zpow[64 / G][NZP][12];
+  __shared__ alignas(16) uint32_t zpow[64 / G][NZP][12];
   fr29 z;
   {
     fr29 zp, z2, z4, z8, z16, kR, t;

@@ -227,14 +227,35 @@ class Setup {
   static constexpr size_t BLOB_BYTES = KZG_BYTES_PER_BLOB;  // Blob::<4096>::BYTES
 
   // g1_lagrange: 4096 x 48 B, g2_monomial: 65 x 96 B, in file order
-  // window_bits = 0 / plane_groups = 0: the engine picks the fastest table class the device has room for (kzg_config)
-  static Setup load(const uint8_t* g1_lagrange, const uint8_t* g2_monomial, int device = 0, int window_bits = 0, int plane_groups = 0) {
-    kzg_config cfg{device, window_bits, 0, plane_groups};
+  // window_bits = 0 / plane_groups = 0: the engine picks the fastest table class within its default budget (the 96-GiB table)
+  // that the device has room for; flags: KZG_CFG_TABLE_MAX lifts the budget, KZG_CFG_BUILD_ASYNC returns on a first-use table
+  static Setup load(const uint8_t* g1_lagrange, const uint8_t* g2_monomial, int device = 0, int window_bits = 0, int plane_groups = 0, int flags = 0) {
+    kzg_config cfg{};
+    cfg.device = device;
+    cfg.window_bits = window_bits;
+    cfg.flags = flags;
+    cfg.plane_groups = plane_groups;
     kzg_ctx* ctx = nullptr;
     int32_t rc = kzg_ctx_create(g1_lagrange, g2_monomial, &cfg, &ctx);
     if (rc != 0) throw EngineFailure("kzg_ctx_create", rc);  // includes LoadSetupError::Bls (-4 / -5)
     return Setup(ctx);
   }
+  // The same over several GPUs of the node (an empty list = every visible device): a GROUP context whose methods shard
+  // every host-buffer batch over the members (include/kateth_amd.h, kzg_config.devices); single items go to a rotating member.
+  static Setup load_multi(const uint8_t* g1_lagrange, const uint8_t* g2_monomial, const std::vector<int32_t>& devices = {}, int window_bits = 0,
+                          int plane_groups = 0, int flags = 0) {
+    kzg_config cfg{};
+    cfg.window_bits = window_bits;
+    cfg.flags = flags;
+    cfg.plane_groups = plane_groups;
+    kzg_ctx* ctx = nullptr;
+    int32_t rc = kzg_ctx_create_multi(g1_lagrange, g2_monomial, devices.empty() ? nullptr : devices.data(),
+                                      devices.empty() ? KZG_ALL_DEVICES : (uint32_t)devices.size(), &cfg, &ctx);
+    if (rc != 0) throw EngineFailure("kzg_ctx_create_multi", rc);
+    return Setup(ctx);
+  }
+  uint32_t members() const { return kzg_ctx_members(ctx_.get()); }
+  void wait_ready() const { check(kzg_ctx_wait_ready(ctx_.get()), "kzg_ctx_wait_ready"); }
 
   Bytes48 blob_to_commitment(const uint8_t* blob, size_t len) const {
     if (len != BLOB_BYTES) throw Error(ErrorKind::BlobInvalidLen);  // src/blob.rs:27-29

@@ -95,7 +95,14 @@ def _kzg_error(code: int) -> KzgError:
 # library loading -- fails loudly, no fallback
 # ---------------------------------------------------------------------------
 class _Config(ctypes.Structure):
-    _fields_ = [("device", ctypes.c_int32), ("window_bits", ctypes.c_int32), ("flags", ctypes.c_int32), ("plane_groups", ctypes.c_int32)]
+    """kzg_config (include/kateth_amd.h)"""
+    _fields_ = [("device", ctypes.c_int32), ("window_bits", ctypes.c_int32), ("flags", ctypes.c_int32), ("plane_groups", ctypes.c_int32),
+                ("table_budget_bytes", ctypes.c_uint64), ("devices", ctypes.POINTER(ctypes.c_int32)), ("ndev", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
+
+
+CFG_TABLE_MAX = 0x1    # KZG_CFG_TABLE_MAX: the automatic table choice may take the largest table the device has room for (192 GiB)
+CFG_BUILD_ASYNC = 0x2  # KZG_CFG_BUILD_ASYNC: usable on a small first-use table at once, the chosen table is built in the background
+ALL_DEVICES = 0xFFFFFFFF  # KZG_ALL_DEVICES
 
 
 def library_path() -> str:
@@ -112,7 +119,14 @@ _SIGNATURES = {
     "kzg_last_error": (ctypes.c_char_p, []),
     "kzg_last_error_code": (ctypes.c_int32, []),
     "kzg_ctx_create": (ctypes.c_int32, [_u8p, _u8p, ctypes.POINTER(_Config), ctypes.POINTER(ctypes.c_void_p)]),
+    "kzg_ctx_create_multi": (ctypes.c_int32, [_u8p, _u8p, ctypes.POINTER(ctypes.c_int32), ctypes.c_uint32, ctypes.POINTER(_Config), ctypes.POINTER(ctypes.c_void_p)]),
     "kzg_ctx_destroy": (None, [ctypes.c_void_p]),
+    "kzg_device_count": (ctypes.c_int32, []),
+    "kzg_ctx_members": (ctypes.c_uint32, [ctypes.c_void_p]),
+    "kzg_ctx_member_device": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_uint32]),
+    "kzg_ctx_member": (ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_uint32]),
+    "kzg_ctx_ready": (ctypes.c_int32, [ctypes.c_void_p]),
+    "kzg_ctx_wait_ready": (ctypes.c_int32, [ctypes.c_void_p]),
     "kzg_ctx_window_bits": (ctypes.c_int32, [ctypes.c_void_p]),
     "kzg_ctx_msm_kernel_name": (ctypes.c_char_p, [ctypes.c_void_p]),
     "kzg_ctx_plane_groups": (ctypes.c_int32, [ctypes.c_void_p]),
@@ -147,6 +161,7 @@ _SIGNATURES = {
     "kzg_ctx_adds_per_blob": (ctypes.c_uint64, [ctypes.c_void_p]),
     "kzg_selftest_field_mul": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]),
     "kzg_microbench_fp_mul": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(ctypes.c_float)]),
+    "kzg_microbench_valu_issue": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
@@ -313,9 +328,13 @@ class Setup:
 
     # -- construction --------------------------------------------------------
     @classmethod
-    def load_json(cls, path, device: int = 0, window_bits: int = 0, lib_path: Optional[str] = None, plane_groups: int = 0) -> "Setup":
-        """`Setup::load_json` (src/kzg/setup.rs:46-82).  window_bits = 0: the engine picks the fastest table class the device
-        has room for (include/kateth_amd.h, kzg_config)."""
+    def load_json(cls, path, device: int = 0, window_bits: int = 0, lib_path: Optional[str] = None, plane_groups: int = 0, devices=None,
+                  table_max: bool = False, build_async: bool = False, table_budget_bytes: int = 0) -> "Setup":
+        """`Setup::load_json` (src/kzg/setup.rs:46-82).  window_bits = 0: the engine picks the fastest table class within the
+        budget (default 100 GiB -> the 96-GiB table; `table_max` lifts the cap -> 192 GiB on an idle MI355X) that the device
+        has room for (include/kateth_amd.h, kzg_config).  `devices`: a list of HIP ordinals, or "all" -- a GROUP context whose
+        host-buffer methods shard every batch over the listed GPUs.  `build_async`: return as soon as a small first-use table
+        stands; the chosen table is built in the background (`ready`, `wait_ready`)."""
         try:
             with open(path) as fh:
                 raw = json.load(fh)
@@ -328,11 +347,13 @@ class Setup:
             g2 = [_unhex(s) for s in raw["g2_monomial"]]
         except (KeyError, ValueError, AttributeError) as err:
             raise LoadSetupError("Serde(%s)" % err)
-        return cls.from_bytes(g1, g2, device=device, window_bits=window_bits, lib_path=lib_path, plane_groups=plane_groups)
+        return cls.from_bytes(g1, g2, device=device, window_bits=window_bits, lib_path=lib_path, plane_groups=plane_groups, devices=devices,
+                              table_max=table_max, build_async=build_async, table_budget_bytes=table_budget_bytes)
 
     @classmethod
     def from_bytes(cls, g1_lagrange: Sequence[bytes], g2_monomial: Sequence[bytes], device: int = 0, window_bits: int = 0,
-                   lib_path: Optional[str] = None, plane_groups: int = 0) -> "Setup":
+                   lib_path: Optional[str] = None, plane_groups: int = 0, devices=None, table_max: bool = False, build_async: bool = False,
+                   table_budget_bytes: int = 0) -> "Setup":
         if len(g1_lagrange) != cls.G1:
             raise LoadSetupError("InvalidLenG1Lagrange")  # src/kzg/setup.rs:52-54
         if len(g2_monomial) != cls.G2:
@@ -340,8 +361,17 @@ class Setup:
         if any(len(p) != 48 for p in g1_lagrange) or any(len(p) != 96 for p in g2_monomial):
             raise LoadSetupError("Bls(ECGroup(InvalidEncoding))")
         lib = load_library(lib_path)
-        window_bits = window_bits or int(os.environ.get("KATETH_AMD_WINDOW_BITS", "0"))
-        cfg = _Config(device, window_bits, 0, plane_groups)
+        flags = (CFG_TABLE_MAX if table_max else 0) | (CFG_BUILD_ASYNC if build_async else 0)
+        cfg = _Config(device, window_bits, flags, plane_groups, table_budget_bytes, None, 0, 0)
+        keep = None
+        if devices is not None:
+            if isinstance(devices, str):
+                assert devices == "all", devices
+                cfg.ndev = ALL_DEVICES
+            else:
+                keep = (ctypes.c_int32 * len(devices))(*devices)
+                cfg.devices = ctypes.cast(keep, ctypes.POINTER(ctypes.c_int32))
+                cfg.ndev = len(devices)
         out = ctypes.c_void_p()
         rc = lib.kzg_ctx_create(b"".join(g1_lagrange), b"".join(g2_monomial), ctypes.byref(cfg), ctypes.byref(out))
         if rc in (-4, -5):  # LoadSetupError::Bls(bls::Error::ECGroup(..)), src/kzg/setup.rs:59-72
@@ -354,9 +384,36 @@ class Setup:
             raise EngineError("kzg_ctx_create failed (%d): %s" % (rc, lib.kzg_last_error().decode()))
         return cls(out.value, lib)
 
+    # -- group contexts / background build ------------------------------------
+    @property
+    def members(self) -> int:
+        """devices this context shards host-buffer batches over (1 = a single-device context)"""
+        return self._lib.kzg_ctx_members(self._h)
+
+    def member_device(self, k: int) -> int:
+        return self._lib.kzg_ctx_member_device(self._h, k)
+
+    def member(self, k: int) -> "Setup":
+        """member k as a single-device Setup (borrowed: it lives as long as this context; close() on it is a no-op)"""
+        h = self._lib.kzg_ctx_member(self._h, k)
+        if not h:
+            raise IndexError(k)
+        m = Setup(h, self._lib)
+        m._borrowed = True
+        m._owner = self
+        return m
+
+    @property
+    def ready(self) -> bool:
+        return bool(self._lib.kzg_ctx_ready(self._h))
+
+    def wait_ready(self):
+        self._check(self._lib.kzg_ctx_wait_ready(self._h), "kzg_ctx_wait_ready")
+
     def close(self):
         if self._h:
-            self._lib.kzg_ctx_destroy(self._h)
+            if not getattr(self, "_borrowed", False):
+                self._lib.kzg_ctx_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -694,6 +751,12 @@ class Setup:
         bad = ctypes.c_uint64(0)
         self._check(self._lib.kzg_selftest_field_mul(self._h, lanes, iters, ctypes.byref(bad)), "kzg_selftest_field_mul")
         return bad.value
+
+    def microbench_valu_issue(self, waves_per_simd: int = 2, iters: int = 20000):
+        """(SIMD cycles per wave-instruction of v_mad_u64_u32 at `waves_per_simd`, shader clock in GHz under that load)"""
+        cyc, ghz = ctypes.c_double(0), ctypes.c_double(0)
+        self._check(self._lib.kzg_microbench_valu_issue(self._h, waves_per_simd, iters, ctypes.byref(cyc), ctypes.byref(ghz)), "kzg_microbench_valu_issue")
+        return cyc.value, ghz.value
 
     def microbench_fp_mul(self, lanes: int, iters: int) -> float:
         ms = ctypes.c_float(0)

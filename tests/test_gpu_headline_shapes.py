@@ -90,8 +90,8 @@ def _free_bytes(torch):
 
 @pytest.mark.parametrize("window_bits,plane_groups,want", [(0, 0, (22, 8)), (22, 4, (22, 4)), (16, 0, (16, 16))])
 def test_headline_shapes_half_wave(window_bits, plane_groups, want, headline_reference, torch_cuda):
-    """class 22 x half-wave x 4,096 / 4,099 blobs with G = 8 (what `window_bits = 0` builds on an empty 288-GB part, and what
-    bench.py times) and with the G = 4 fallback; class 16 at the same sizes: ALL commitments and proofs equal the class-8
+    """class 22 x half-wave x 4,096 / 4,099 blobs with G = 8 (what `window_bits = 0` + KZG_CFG_TABLE_MAX builds on an empty 288-GB
+    part, and what bench.py times) and with the G = 4 fallback; class 16 at the same sizes: ALL commitments and proofs equal the class-8
     engine's, commit -> prove -> verify closes on the class under test"""
     import kateth_amd
 
@@ -99,7 +99,8 @@ def test_headline_shapes_half_wave(window_bits, plane_groups, want, headline_ref
     d_blobs, cs, ps = headline_reference
     if want == (22, 8) and _free_bytes(torch) < 8 * GROUP22 + 40 * GiB:
         pytest.skip("needs 232 GiB of free HBM (an otherwise idle 288-GB part)")
-    s = kateth_amd.Setup.load_json(TRUSTED_SETUP, window_bits=window_bits, plane_groups=plane_groups)
+    # window_bits = 0 takes the 192-GiB table only when the caller lifts the default budget (KZG_CFG_TABLE_MAX: what bench.py passes)
+    s = kateth_amd.Setup.load_json(TRUSTED_SETUP, window_bits=window_bits, plane_groups=plane_groups, table_max=(window_bits == 0))
     try:
         assert (s.window_bits, s.plane_groups) == want
         assert s.table_bytes == want[1] * 64 * {22: 1 << 22, 16: 4 << 15}[want[0]] * 96
@@ -135,7 +136,7 @@ def test_commit_131072_blobs_in_one_call(engine8, torch_cuda):
 
     torch = torch_cuda
     n = 131072
-    s = kateth_amd.Setup.load_json(TRUSTED_SETUP, window_bits=0)
+    s = kateth_amd.Setup.load_json(TRUSTED_SETUP, window_bits=0, table_max=True)
     try:
         d_blobs = torch.empty(n * 131072, dtype=torch.uint8, device="cuda")
         s.synth_blobs_dev(0xC0F164, 0, n, d_blobs.data_ptr())
@@ -161,8 +162,8 @@ def test_commit_131072_blobs_in_one_call(engine8, torch_cuda):
 @pytest.mark.parametrize("leave_free_gib,want", [(200, (22, 4)), (100, (16, 16)), (14, (8, 16))])
 def test_automatic_class_follows_free_memory(leave_free_gib, want, torch_cuda, golden):
     """kzg_config.window_bits = 0: with only `leave_free_gib` of HBM free at kzg_ctx_create (the rest held by a ballast
-    allocation) the engine steps down -- class 22 with 4 plane groups below 232 GiB, class 16 below 136 GiB, class 8 below
-    21 GiB -- and still commits correctly; an explicit request is honoured regardless"""
+    allocation) the engine steps down -- class 22 with 4 plane groups below 232 GiB (and, with the default 100-GiB budget, also
+    above), class 16 below 136 GiB, class 8 below 21 GiB -- and still commits correctly; an explicit request is honoured regardless"""
     import kateth_amd
 
     torch = torch_cuda

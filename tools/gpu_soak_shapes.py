@@ -21,7 +21,7 @@ import kateth_amd  # noqa: E402
 SETUP = os.path.join(ROOT, "tests", "golden", "trusted_setup_4096.json")
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 NMAX = 16500
-big = kateth_amd.Setup.load_json(SETUP, window_bits=0)
+big = kateth_amd.Setup.load_json(SETUP, window_bits=0, table_max=True)
 ref = kateth_amd.Setup.load_json(SETUP, window_bits=8)
 d_blobs = torch.empty(NMAX * 131072, dtype=torch.uint8, device="cuda")
 big.synth_blobs_dev(0x50A4, 0, NMAX, d_blobs.data_ptr())
