@@ -30,6 +30,11 @@ of `value`.
 import argparse
 import json
 import os
+
+# Several HIP streams are live in a run (the engine's copy / side / session streams, the lanes of calls kept in flight) and
+# the runtime multiplexes them onto GPU_MAX_HW_QUEUES hardware queues -- 4 by default: two streams that land on one queue run
+# strictly one after the other (seen: both lanes of `--in-flight 2` on one queue, profiles/r04).  Set before HIP initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import subprocess
 import sys
 import time
@@ -63,6 +68,9 @@ def parse():
                          "16 -> 12.9 GB, 65,536 additions; 8 -> 100 MB, 131,072 additions")
     ap.add_argument("--default-budget", action="store_true", help="do NOT pass KZG_CFG_TABLE_MAX: the library's default budget (100 GiB -> the 96-GiB table, G = 4) "
                     "instead of the largest table the device has room for (192 GiB, G = 8)")
+    ap.add_argument("--in-flight", type=int, default=0, help="calls kept in flight: step i is enqueued on stream i mod F with result buffers of its own (0 = default: 2 for "
+                    "--workload proof -- one call's hash + quotient kernels run in the shadow of the other's MSM --, 1 otherwise; the timed region is still K steps "
+                    "between two full synchronisations)")
     ap.add_argument("--blocking-setup", action="store_true", help="create the context without KZG_CFG_BUILD_ASYNC (kzg_ctx_create returns when the full table stands)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL, the measured path) or gloo (rehearsal: ranks may share one card, gathers go through the host)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -255,9 +263,11 @@ CALL_KERNELS = {
     "commit": ("k_comb_transpose", "k_msm_comb28", "k_msm_reduce", "k_msm_reduce_half4", "k_msm_reduce_splits", "k_g1_compress"),
     "proof": ("k_comb_transpose", "k_msm_comb28", "k_msm_reduce", "k_msm_reduce_half4", "k_msm_reduce_splits", "k_g1_compress", "k_challenge", "k_challenge_split",
               "k_challenge_pair", "k_challenge_and_decode", "k_challenge_pair_and_decode", "k_g1_decompress", "k_poly_root_inverse", "k_poly", "k_merge_status"),
-    "verify": ("k_challenge", "k_challenge_split", "k_challenge_pair", "k_challenge_and_decode", "k_challenge_pair_and_decode", "k_eval_frac", "k_g1_decompress_range",
-               "k_g1_decompress", "k_transcript_leaves", "k_transcript_nodes", "k_batch_scalars", "k_batch_ysum_finish", "k_var_count", "k_var_scan", "k_var_scan_wide",
-               "k_var_scatter", "k_var_buckets", "k_var_buckets_flat", "k_var_fold", "k_var_windows", "k_var_bitsums"),
+    # batches above 16,384 triples (the child's own setup -- commit + prove of the triples in chunks of 16,384 -- launches
+    # k_challenge_pair* and k_g1_decompress, which a verification of this size does not)
+    "verify": ("k_challenge", "k_challenge_split", "k_eval_frac", "k_g1_decompress_range", "k_transcript_leaves", "k_transcript_nodes", "k_batch_scalars",
+               "k_batch_ysum_finish", "k_var_count", "k_var_scan", "k_var_scan_wide", "k_var_scan_lean", "k_var_scatter", "k_var_buckets", "k_var_buckets_flat", "k_var_fold",
+               "k_var_windows", "k_var_bitsums"),
 }
 PMC_CHILD_STEPS, PMC_CHILD_WARMUP = 2, 1
 
@@ -334,7 +344,7 @@ def traffic_from_pmc(pmc, workload):
             "how": "two rocprofv3 --pmc child passes of this bench.py run (FETCH_SIZE, WRITE_SIZE; KiB per dispatch)"}
 
 
-def valu_issue_object(pmc, workload, issue, simds, call_ms, kernel_ms=None, extra_calls=0):
+def valu_issue_object(pmc, workload, issue, simds, call_ms, kernel_ms=None, extra_calls=0, run_clock=None):
     """The floor these kernels are actually bound by: VALU instruction ISSUE.  SQ_INSTS_VALU (wave-instructions,
     whole chip, one rocprofv3 --pmc child pass of this run) / SIMDs x the measured issue interval of v_mad_u64_u32 at two waves per
     SIMD (kzg_microbench_valu_issue: cycles per wave-instruction, and the shader clock that load sustains) = the time the
@@ -342,7 +352,8 @@ def valu_issue_object(pmc, workload, issue, simds, call_ms, kernel_ms=None, extr
     the same for the dominant kernel alone."""
     if "error" in pmc or "SQ_INSTS_VALU" not in pmc:
         return {"error": pmc.get("error", "SQ_INSTS_VALU missing")}
-    cpi, ghz = issue
+    cpi, ghz_microbench = issue
+    ghz = run_clock[0] if run_clock else ghz_microbench
     per = pmc["SQ_INSTS_VALU"]
     calls = PMC_CHILD_STEPS + PMC_CHILD_WARMUP
     by_kernel = {}
@@ -354,10 +365,12 @@ def valu_issue_object(pmc, workload, issue, simds, call_ms, kernel_ms=None, extr
             by_kernel[name] = tot / c
     total = sum(by_kernel.values())
     obj = {"insts_per_call": total, "insts_per_simd": total / simds, "cycles_per_inst": cpi, "clock_ghz": ghz, "simds": simds,
+           "clock_source": "sleeping probe waves beside the timed calls (kzg_clock_probe_*): mean over the XCDs; lowest / highest: %r" % (list(run_clock[1:]),) if run_clock
+           else "the issue microbenchmark's own clock (no probe ran)", "clock_ghz_issue_microbenchmark": ghz_microbench,
            "floor_ms": total / simds * cpi / (ghz * 1e6), "call_ms": call_ms,
            "insts_by_kernel_per_call": by_kernel,
-           "how": "SQ_INSTS_VALU: one rocprofv3 --pmc child pass of this run; cycles_per_inst / clock_ghz: kzg_microbench_valu_issue (v_mad_u64_u32, 8 independent chains, "
-                  "2 waves per SIMD, whole chip) in this process"}
+           "how": "SQ_INSTS_VALU: one rocprofv3 --pmc child pass of this run; cycles_per_inst: kzg_microbench_valu_issue (v_mad_u64_u32, 8 independent chains, "
+                  "2 waves per SIMD, whole chip) in this process; floor_ms = insts_per_simd x cycles_per_inst / clock"}
     obj["frac"] = obj["floor_ms"] / call_ms if call_ms else None
     k = PMC_KERNEL[workload]
     if kernel_ms and k in per:
@@ -406,6 +419,7 @@ def roofline_object(workload, n, prof, window_bits, call_ms=None):
         "blobs_per_launch": blobs_per_launch,
         "algorithmic_bytes_per_blob": ALG_BYTES[workload],
         "kernel_ms_by_class_per_call": {k: v[0] / calls for k, v in kinds.items()},
+        "shader_clock_ghz_during_run": prof.get("clock_ghz"),
         "summed_kernel_ms_per_call": summed / calls,
         "achieved_over_summed_kernels": ALG_BYTES[workload] * n / (summed / calls * 1e-3) / 1e9,
         "note": "frac is the algorithmic HBM rate the north star asks for; the kernels are bound by VALU instruction issue: valu_issue.frac is the fraction of THAT floor"
@@ -500,19 +514,28 @@ class Rank:
         self.setup.synth_blobs_dev(SEED, first_index, n, d.data_ptr(), self.stream)
         return d
 
-    def commit(self, d_blobs, n, d_out=None, d_status=None):
+    def commit(self, d_blobs, n, d_out=None, d_status=None, stream=None):
         t = self.torch
         d_out = t.empty(n * 48, dtype=t.uint8, device=self.dev) if d_out is None else d_out
         d_status = t.empty(n, dtype=t.int32, device=self.dev) if d_status is None else d_status
-        self.setup.blob_to_commitment_batch_dev(d_blobs.data_ptr(), n, d_out.data_ptr(), d_status.data_ptr(), self.stream)
+        self.setup.blob_to_commitment_batch_dev(d_blobs.data_ptr(), n, d_out.data_ptr(), d_status.data_ptr(), self.stream if stream is None else stream)
         return d_out, d_status
 
-    def prove(self, d_blobs, d_com, n, d_out=None, d_status=None):
+    def prove(self, d_blobs, d_com, n, d_out=None, d_status=None, stream=None):
         t = self.torch
         d_out = t.empty(n * 48, dtype=t.uint8, device=self.dev) if d_out is None else d_out
         d_status = t.empty(n, dtype=t.int32, device=self.dev) if d_status is None else d_status
-        self.setup.compute_blob_proof_batch_dev(d_blobs.data_ptr(), d_com.data_ptr(), n, d_out.data_ptr(), d_status.data_ptr(), self.stream)
+        self.setup.compute_blob_proof_batch_dev(d_blobs.data_ptr(), d_com.data_ptr(), n, d_out.data_ptr(), d_status.data_ptr(), self.stream if stream is None else stream)
         return d_out, d_status
+
+    def lanes(self, flight, n):
+        """`flight` (torch stream, its raw handle, result buffer, status buffer) sets for calls kept in flight side by side"""
+        t = self.torch
+        out = []
+        for k in range(flight):
+            st = t.cuda.current_stream() if flight == 1 else t.cuda.Stream(device=self.dev)
+            out.append((st, st.cuda_stream, t.empty(n * 48, dtype=t.uint8, device=self.dev), t.zeros(n, dtype=t.int32, device=self.dev)))
+        return out
 
     def verify(self, d_blobs, d_com, d_prf, n, first_index, n_total):
         if not self.use_dist:
@@ -539,19 +562,48 @@ class Rank:
         self.torch.cuda.synchronize()
 
     # -- the timed region -----------------------------------------------------------------------------------------
-    def timed(self, step):
-        a = self.args
-        for _ in range(a.warmup):
-            step()
-        self.fence()
+    def _run(self, fn, reps):
+        """`reps` calls of fn between two fences: (seconds, profile)"""
         self.setup.profile_begin()
         t0 = time.perf_counter()
-        for _ in range(a.steps):
-            step()
+        for _ in range(reps):
+            fn()
         self.fence()
         elapsed = time.perf_counter() - t0
         prof = self.setup.profile_end()
-        prof["calls"] = a.steps
+        prof["calls"] = reps
+        return elapsed, prof
+
+    def _run_with_clock_probe(self, fn, reps, step_s):
+        """the same with sleeping probe waves beside the calls (kzg_clock_probe_*: the shader clock this workload sustains, for
+        roofline.valu_issue).  The probe runs for HALF the expected duration (`step_s` = one call, measured on the last warm-up
+        call); should it outlast the calls all the same -- the closing fence would then wait for it -- the calls are timed again
+        without a probe."""
+        probe_s = 0.5 * step_s * reps
+        if probe_s < 1e-3:
+            return self._run(fn, reps)
+        self.setup.clock_probe_launch(int(1e6 * probe_s))
+        elapsed, prof = self._run(fn, reps)
+        clock = self.setup.clock_probe_read()
+        if probe_s > 0.9 * elapsed:
+            elapsed, prof = self._run(fn, reps)
+        prof["clock_ghz"] = clock
+        return elapsed, prof
+
+    def timed(self, step):
+        a = self.args
+        last = 0.0
+        for _ in range(a.warmup):  # untimed; each between fences so that the last one gives the probe its duration
+            self.fence()
+            t0 = time.perf_counter()
+            step()
+            self.fence()
+            last = time.perf_counter() - t0
+        self.fence()
+        if not self.use_dist and a.warmup:  # (single process only: a repeated timed loop on one rank would break the ranks' barriers)
+            elapsed, prof = self._run_with_clock_probe(step, a.steps, last)
+        else:
+            elapsed, prof = self._run(step, a.steps)
         if self.use_dist:
             t = self.torch.tensor([elapsed], dtype=self.torch.float64, device=self.dev if a.backend == "nccl" else "cpu")
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
@@ -559,18 +611,15 @@ class Rank:
         return elapsed, prof
 
     def measure(self, fn, reps):
-        """secondary workloads: (seconds per call, profile) over `reps` calls after one warm-up call"""
+        """secondary workloads: (seconds per call, profile) over `reps` calls after two warm-up calls (the second one timed, for the
+        clock probe's duration)"""
         fn()
         self.torch.cuda.synchronize()
-        self.setup.profile_begin()
         t0 = time.perf_counter()
-        for _ in range(reps):
-            fn()
+        fn()
         self.torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / reps
-        prof = self.setup.profile_end()
-        prof["calls"] = reps
-        return dt, prof
+        elapsed, prof = self._run_with_clock_probe(fn, reps, time.perf_counter() - t0)
+        return elapsed / reps, prof
 
 
 def check_golden(out48, n, first_index, what):
@@ -608,6 +657,23 @@ def extra_workloads(R, d_blobs, d_com, n):
     dt, prof = R.measure(lambda: R.prove(d_blobs, d_com, n, d_prf, d_st), 3)
     out["compute_blob_kzg_proof"] = {"workload": "batch=%d blobs resident in HBM (BASELINE configs[2])" % n, "blobs_per_s": n / dt, "ms_per_batch": 1e3 * dt,
                                      "algorithmic_GBps": n * ALG_BYTES["proof"] / dt / 1e9, "roofline": roofline_object("proof", n, prof, setup.window_bits)}
+    # the same with TWO calls in flight (two streams, result buffers of their own): a call starts with ~5 ms in which the chip is
+    # nearly idle -- one SHA-256 stream per blob, then the quotients -- and no stream can order a call's hash before its own
+    # inputs; a caller that keeps two batches in flight has the second call's preparation run in the shadow of the first one's MSM
+    lanes = R.lanes(2, n)
+    tick = [0]
+
+    def two():
+        st, raw, o, stt = lanes[tick[0] % 2]
+        tick[0] += 1
+        with torch.cuda.stream(st):
+            R.prove(d_blobs, d_com, n, o, stt, raw)
+
+    dt2, _ = R.measure(two, 6)
+    for _, _, o, stt in lanes:
+        assert int(stt.abs().sum()) == 0 and torch.equal(o, d_prf), "two calls in flight must not change a byte"
+    out["compute_blob_kzg_proof"].update({"blobs_per_s_two_calls_in_flight": n / dt2, "ms_per_batch_two_calls_in_flight": 1e3 * dt2})
+    del lanes
     # ---- verify: 65,536 distinct triples
     nv = 65536
     vb = R.make_blobs(nv, 0)
@@ -656,16 +722,34 @@ def run_rank(args, rank, local_rank, world):
     gathered = torch.empty(world * n * 48, dtype=torch.uint8, device=R.dev) if R.use_dist else None
     verdicts = []
 
+    flight = args.in_flight or (2 if wl == "proof" else 1)
+    lanes = R.lanes(flight, n) if wl != "verify" else []
+    tick = [0]
+
+    def on_lane(fn):
+        """step i on lane i mod F: its own stream (the gather rides on it too) and its own result buffers"""
+        st, raw, o, stt = lanes[tick[0] % flight]
+        tick[0] += 1
+        if flight == 1:
+            return fn(raw, d_out, d_status)
+        with torch.cuda.stream(st):
+            return fn(raw, o, stt)
+
     if wl == "commit":
         def step():
-            R.commit(d_blobs, n, d_out, d_status)
-            R.gather48(d_out, gathered)
+            def one(raw, o, stt):
+                R.commit(d_blobs, n, o, stt, raw)
+                R.gather48(o, gathered)
+            on_lane(one)
     elif wl == "proof":
         d_com, _ = R.commit(d_blobs, n)
+        torch.cuda.synchronize()
 
         def step():
-            R.prove(d_blobs, d_com, n, d_out, d_status)
-            R.gather48(d_out, gathered)
+            def one(raw, o, stt):
+                R.prove(d_blobs, d_com, n, o, stt, raw)
+                R.gather48(o, gathered)
+            on_lane(one)
     else:
         d_com, st1 = R.commit(d_blobs, n)
         d_prf, st2 = R.prove(d_blobs, d_com, n)
@@ -677,6 +761,12 @@ def run_rank(args, rank, local_rank, world):
             verdicts.append(R.verify(d_blobs, d_com, d_prf, n, first, world * n))
 
     elapsed, prof = R.timed(step)
+    if flight > 1:  # every lane's results: valid, and identical (the same blobs)
+        for _, _, o, stt in lanes:
+            assert int(stt.abs().sum()) == 0, "synthetic blobs must all be valid"
+            assert torch.equal(o, lanes[0][2]), "calls in flight side by side must not change a byte"
+        d_out.copy_(lanes[0][2])
+        d_status.copy_(lanes[0][3])
     assert int(d_status.abs().sum()) == 0, "synthetic blobs must all be valid"
     if wl == "verify":
         assert all(v is True for v in verdicts), "verify_blob_kzg_proof_batch rejected the engine's own proofs"
@@ -707,6 +797,7 @@ def run_rank(args, rank, local_rank, world):
                          "verify": "verify_blob_kzg_proof_batch batch=%d (blob, commitment, proof) triples per GPU, host pairing included (BASELINE configs[3])"}[wl] % n
             + (" -- configs[4] shape: %d blobs over %d GPUs" % (world * n, world) if (wl == "commit" and world * n >= 1 << 20) else ""),
             "blobs_per_gpu": n,
+            "calls_in_flight": flight,
             "window_bits": setup.window_bits,
             "table_gib": setup.table_bytes / 2**30,
             "parallelism": "blob-sharded x%d, %s" % (world, "RCCL all-gather of 48-B results" if wl != "verify" else "all-gather of 32-B transcript roots + 192-B partial sums, one pairing"),
@@ -747,12 +838,13 @@ def run_rank(args, rank, local_rank, world):
                 # BASELINE.json's metric string names both functions; `value` is the first (blob_to_kzg_commitment), `values` carries both
                 result["metric"] = "blobs/sec for blob_to_kzg_commitment and verify_blob_kzg_proof_batch (n=4096)"
                 result["values"] = {"blob_to_kzg_commitment": result["value"], "verify_blob_kzg_proof_batch": v["blobs_per_s"], "compute_blob_kzg_proof": p["blobs_per_s"],
-                                    "unit": "blobs/s", "note": "`value` = blob_to_kzg_commitment at batch 4,096 (configs[1]); verify at batch 65,536 (configs[3]); proof at 4,096 (configs[2])"}
+                                    "compute_blob_kzg_proof_two_calls_in_flight": p.get("blobs_per_s_two_calls_in_flight"), "unit": "blobs/s", "note": "`value` = blob_to_kzg_commitment at batch 4,096 (configs[1]); verify at batch 65,536 (configs[3]); proof at 4,096 (configs[2])"}
                 result["secondary_metrics"] = [
                     {"metric": METRIC["verify"], "value": v["blobs_per_s"], "unit": "blobs/s", "ms_per_step": v["ms_per_batch"], "workload": v["workload"],
                      "roofline_frac": v["roofline"]["frac"] if v.get("roofline") else None, "result": v["result"]},
                     {"metric": METRIC["proof"], "value": p["blobs_per_s"], "unit": "blobs/s", "ms_per_step": p["ms_per_batch"], "workload": p["workload"],
-                     "roofline_frac": p["roofline"]["frac"] if p.get("roofline") else None}]
+                     "roofline_frac": p["roofline"]["frac"] if p.get("roofline") else None, "value_two_calls_in_flight": p.get("blobs_per_s_two_calls_in_flight"),
+                     "ms_per_step_two_calls_in_flight": p.get("ms_per_batch_two_calls_in_flight")}]
             except Exception as err:  # secondary numbers never hide the headline
                 result["extra"] = {"error": repr(err)}
         if not args.no_cpu_baseline and world == 1:
@@ -788,7 +880,8 @@ def run_rank(args, rank, local_rank, world):
                 roof["traffic_over_algorithmic"] = live["hbm_bytes_per_launch"] / (ALG_BYTES[wl] * roof["blobs_per_launch"])
             else:
                 roof["traffic_live_error"] = live.get("error")
-            roof["valu_issue"] = valu_issue_object(pmc, wl, issue, simds, 1e3 * elapsed / args.steps, roof.get("kernel_ms"), extra_calls=1 if wl == "proof" else 0)
+            roof["valu_issue"] = valu_issue_object(pmc, wl, issue, simds, 1e3 * elapsed / args.steps, roof.get("kernel_ms"), extra_calls=1 if wl == "proof" else 0,
+                                                   run_clock=roof.get("shader_clock_ghz_during_run"))
             # the two other workloads of the default run: one SQ_INSTS_VALU pass each, priced the same way
             extra = result.get("extra") if isinstance(result.get("extra"), dict) else None
             if extra and "error" not in extra:
@@ -798,7 +891,7 @@ def run_rank(args, rank, local_rank, world):
                         continue
                     pmc2 = live_pmc(args, w2, n2, ("SQ_INSTS_VALU",))
                     rec["roofline"]["valu_issue"] = valu_issue_object(pmc2, w2, issue, simds, rec["ms_per_batch"], rec["roofline"].get("kernel_ms"),
-                                                                      extra_calls=1 if w2 == "proof" else 0)
+                                                                      extra_calls=1 if w2 == "proof" else 0, run_clock=rec["roofline"].get("shader_clock_ghz_during_run"))
                 for sm in result.get("secondary_metrics", []):
                     key = "verify_blob_kzg_proof_batch" if "verify" in sm["metric"] else "compute_blob_kzg_proof"
                     vi = extra.get(key, {}).get("roofline", {}).get("valu_issue", {})

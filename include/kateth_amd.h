@@ -290,6 +290,14 @@ int32_t kzg_microbench_fp_mul(const kzg_ctx* ctx, uint64_t lanes, uint64_t iters
  * ticks per 100-MHz real-time tick).  floor of a kernel = SQ_INSTS_VALU / SIMDs x cycles_per_inst / clock.
  */
 int32_t kzg_microbench_valu_issue(const kzg_ctx* ctx, uint32_t waves_per_simd, uint32_t iters, double* cycles_per_inst, double* clock_ghz);
+/*
+ * The shader clock under a REAL workload: kzg_clock_probe_launch enqueues eight sleeping single-wave workgroups (one per
+ * XCD) on a stream of the context's own; for `duration_us` they compare the shader-clock counter with the 100-MHz real-time
+ * counter while the caller's kernels run beside them (a probe wave needs a handful of registers and issues one instruction
+ * every 2 us).  kzg_clock_probe_read waits for them and returns the mean / lowest / highest XCD clock in GHz.
+ */
+int32_t kzg_clock_probe_launch(const kzg_ctx* ctx, uint32_t duration_us);
+int32_t kzg_clock_probe_read(const kzg_ctx* ctx, double* ghz_mean, double* ghz_min, double* ghz_max);
 
 /*
  * On-device self-test of the hand-scheduled multiply: every lane multiplies

@@ -8,6 +8,12 @@
 #include "setup_kernels.cuh"
 
 #include <algorithm>
+// The engine overlaps kernels on several HIP streams; the runtime multiplexes all streams of a process onto
+// GPU_MAX_HW_QUEUES hardware queues (4 by default) and streams that share a queue run one after the other.  The flag is read
+// when HIP initialises (the first API call), so a load-time default is in time for every caller that has not touched HIP yet;
+// an explicit setting in the environment is left alone.
+__attribute__((constructor)) static void kzg_default_hw_queues() { (void)setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
 // ---------------------------------------------------------------------------
 // error plumbing
 // ---------------------------------------------------------------------------
@@ -40,28 +46,43 @@ void error_publish(const ErrorSnapshot& e) {
 // ---------------------------------------------------------------------------
 
 
-int32_t ws_reserve(const kzg_ctx* ctx, size_t bytes) {
-  if (ctx->ws_bytes >= bytes) return 0;
-  if (ctx->ws) {
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipFree(ctx->ws));
-    ctx->ws = nullptr;
-    ctx->ws_bytes = 0;
+static int32_t ws_grow(WsSlot& w, size_t bytes) {
+  if (w.bytes >= bytes) return 0;
+  if (w.p) {
+    if (w.ev) HIP_TRY(hipEventSynchronize(w.ev));  // nothing enqueued may still use the old buffer
+    HIP_TRY(hipFree(w.p));
+    w.p = nullptr;
+    w.bytes = 0;
   }
-  size_t want = bytes + bytes / 8;
-  HIP_TRY(hipMalloc(&ctx->ws, want));
-  ctx->ws_bytes = want;
+  const size_t want = bytes + bytes / 8;
+  HIP_TRY(hipMalloc(&w.p, want));
+  w.bytes = want;
+  return 0;
+}
+int32_t ws_reserve(const kzg_ctx* ctx, size_t bytes) { return ws_grow(ctx->wss[ctx->ws_cur], bytes); }
+int32_t ws_reserve_all(const kzg_ctx* ctx, size_t bytes) {
+  for (WsSlot& w : ctx->wss) {
+    int32_t rc = ws_grow(w, bytes);
+    if (rc) return rc;
+  }
   return 0;
 }
 
-// `ws` is shared by successive calls that may be enqueued on different streams: order them.
-int32_t ws_acquire(const kzg_ctx* ctx, hipStream_t st) {
-  if (ctx->ws_event) HIP_TRY(hipStreamWaitEvent(st, ctx->ws_event, 0));
+// Successive calls take the slots in turn; a slot's users on different streams are ordered by its event.
+int32_t ws_begin(const kzg_ctx* ctx, hipStream_t st) {
+  ctx->ws_cur = ctx->ws_next;
+  ctx->ws_next = (ctx->ws_next + 1u) % KZG_WS_SLOTS;
+  return ws_wait(ctx, st);
+}
+int32_t ws_wait(const kzg_ctx* ctx, hipStream_t st) {
+  const WsSlot& w = ctx->wss[ctx->ws_cur];
+  if (w.ev) HIP_TRY(hipStreamWaitEvent(st, w.ev, 0));
   return 0;
 }
-int32_t ws_release(const kzg_ctx* ctx, hipStream_t st) {
-  if (!ctx->ws_event) HIP_TRY(hipEventCreateWithFlags(&ctx->ws_event, hipEventDisableTiming));
-  HIP_TRY(hipEventRecord(ctx->ws_event, st));
+int32_t ws_end(const kzg_ctx* ctx, hipStream_t st) {
+  WsSlot& w = ctx->wss[ctx->ws_cur];
+  if (!w.ev) HIP_TRY(hipEventCreateWithFlags(&w.ev, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(w.ev, st));
   return 0;
 }
 
@@ -264,10 +285,14 @@ extern "C" void kzg_ctx_destroy(kzg_ctx* ctx) {
   if (ctx->d_comb_k_lat) (void)hipFree(ctx->d_comb_k_lat);
   if (ctx->msm_override && ctx->msm_override->destroy) ctx->msm_override->destroy(ctx);
   delete ctx->pairing;
-  if (ctx->ws) (void)hipFree(ctx->ws);
+  for (WsSlot& w : ctx->wss) {
+    if (w.p) (void)hipFree(w.p);
+    if (w.ev) (void)hipEventDestroy(w.ev);
+  }
+  if (ctx->d_clock_probe) (void)hipFree(ctx->d_clock_probe);
+  if (ctx->probe_stream) (void)hipStreamDestroy(ctx->probe_stream);
   if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
-  if (ctx->ws_event) (void)hipEventDestroy(ctx->ws_event);
   for (auto e : ctx->proof_events) (void)hipEventDestroy(e);
   for (auto& pe : ctx->prof_events) {
     (void)hipEventDestroy(pe.e0);
@@ -751,9 +776,9 @@ static int32_t commit_dev_locked(const kzg_ctx* ctx, const void* d_blobs, uint64
   const size_t need = partial_bytes + sums_bytes + msm_scratch_bytes(ctx, cn);
   int32_t rc = ws_reserve(ctx, need);
   if (rc) return rc;
-  g1_xyzz* partials = reinterpret_cast<g1_xyzz*>(ctx->ws);
-  g1_xyzz* sums = reinterpret_cast<g1_xyzz*>(reinterpret_cast<uint8_t*>(ctx->ws) + partial_bytes);
-  void* msm_scratch = reinterpret_cast<uint8_t*>(ctx->ws) + partial_bytes + sums_bytes;
+  g1_xyzz* partials = reinterpret_cast<g1_xyzz*>(ws_ptr(ctx));
+  g1_xyzz* sums = reinterpret_cast<g1_xyzz*>(ws_ptr(ctx) + partial_bytes);
+  void* msm_scratch = ws_ptr(ctx) + partial_bytes + sums_bytes;
   HIP_TRY(hipMemsetAsync(d_status, 0, n * sizeof(int32_t), st));
   for (uint64_t base = 0; base < n; base += cn) {
     const uint64_t m = (n - base < cn) ? (n - base) : cn;
@@ -772,9 +797,9 @@ extern "C" int32_t kzg_blob_to_commitment_batch_dev(const kzg_ctx* ctx, const vo
   HIP_TRY(hipSetDevice(ctx->device));
   std::lock_guard<std::mutex> guard(ctx->lock);
   hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
-  int32_t rc = ws_acquire(ctx, st);
+  int32_t rc = ws_begin(ctx, st);
   if (rc == 0) rc = commit_dev_locked(ctx, d_blobs, n, d_out48, nullptr, reinterpret_cast<int32_t*>(d_status), st);
-  if (rc == 0) rc = ws_release(ctx, st);
+  if (rc == 0) rc = ws_end(ctx, st);
   return rc;
 }
 
@@ -849,10 +874,9 @@ int32_t commit_host(const kzg_ctx* ctx, const uint8_t* blobs, uint64_t n, uint8_
     const size_t sums_bytes = align_up((size_t)max_chunk * sizeof(g1_xyzz), 256);
     const size_t scratch_bytes = align_up(msm_scratch_bytes(ctx, max_chunk), 256);
     const size_t per_slot = partial_bytes + sums_bytes + scratch_bytes;
-    rc = ws_reserve(ctx, nslots * per_slot);
-    if (rc) break;
-    rc = ws_acquire(ctx, comp[0]);
-    if (rc == 0) rc = ws_acquire(ctx, comp[1]);
+    rc = ws_begin(ctx, comp[0]);
+    if (rc == 0) rc = ws_wait(ctx, comp[1]);
+    if (rc == 0) rc = ws_reserve(ctx, nslots * per_slot);
     if (rc) break;
     if (hipMemsetAsync(d_status, 0, n * sizeof(int32_t), comp[0]) != hipSuccess || hipEventRecord(ctx->stage_join[0], comp[0]) != hipSuccess ||
         hipStreamWaitEvent(comp[1], ctx->stage_join[0], 0) != hipSuccess) {
@@ -865,7 +889,7 @@ int32_t commit_host(const kzg_ctx* ctx, const uint8_t* blobs, uint64_t n, uint8_
       const uint64_t m = plan[k];
       const uint32_t splits = choose_splits(ctx, m);
       const uint32_t lpb = msm_lanes_per_blob(ctx, m, splits);
-      uint8_t* wslot = reinterpret_cast<uint8_t*>(ctx->ws) + (size_t)slot * per_slot;
+      uint8_t* wslot = ws_ptr(ctx) + (size_t)slot * per_slot;
       g1_xyzz* partials = reinterpret_cast<g1_xyzz*>(wslot);
       g1_xyzz* sums = reinterpret_cast<g1_xyzz*>(wslot + partial_bytes);
       // chunk k-2 (same slot) must have been transposed out of the staging buffer before it is overwritten
@@ -890,7 +914,7 @@ int32_t commit_host(const kzg_ctx* ctx, const uint8_t* blobs, uint64_t n, uint8_
       rc = fail(KZG_FAIL_HIP, "stream join failed");
       break;
     }
-    rc = ws_release(ctx, comp[0]);
+    rc = ws_end(ctx, comp[0]);
     if (rc) break;
     if (hipMemcpyAsync(out48 ? out48 : out_affine96, d_res, (size_t)n * (out48 ? 48 : 96), hipMemcpyDeviceToHost, comp[0]) != hipSuccess ||
         hipMemcpyAsync(status, d_status, n * sizeof(int32_t), hipMemcpyDeviceToHost, comp[0]) != hipSuccess ||
@@ -986,7 +1010,7 @@ __global__ __launch_bounds__(256) void k_microbench_valu_issue(uint32_t* out, un
 #pragma unroll 1
   for (uint32_t it = 0; it < iters; it++) {
 #pragma unroll
-    for (int rep = 0; rep < 4; rep++) {
+    for (int rep = 0; rep < 32; rep++) {  // 256 instructions per trip: the loop's scalar bookkeeping and taken branch disappear in them
 #pragma unroll
       for (int c = 0; c < 8; c++) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(x[c]) : "v"(y), "v"(z) : "vcc");
     }
@@ -1022,13 +1046,70 @@ extern "C" int32_t kzg_microbench_valu_issue(const kzg_ctx* ctx, uint32_t waves_
   if (e != hipSuccess) return fail(KZG_FAIL_HIP, std::string("valu issue microbenchmark: ") + hipGetErrorString(e));
   std::vector<double> cyc, ghz;
   for (size_t i = 0; i < t.size(); i += 2) {
-    cyc.push_back((double)t[i] / ((double)iters * 32.0 * waves_per_simd));
+    cyc.push_back((double)t[i] / ((double)iters * 256.0 * waves_per_simd));
     if (t[i + 1]) ghz.push_back((double)t[i] / ((double)t[i + 1] * 10.0));
   }
   std::sort(cyc.begin(), cyc.end());
   std::sort(ghz.begin(), ghz.end());
   *cycles_per_inst = cyc[cyc.size() / 2];  // median over the waves
   *clock_ghz = ghz.empty() ? 0.0 : ghz[ghz.size() / 2];
+  return 0;
+}
+
+// Shader clock UNDER A REAL WORKLOAD: eight single-wave workgroups (dealt round-robin over the XCDs) that do nothing but
+// sleep for `ticks` of the 100-MHz real-time counter and report how far the shader-clock counter moved meanwhile.  A probe
+// wave needs a handful of registers, so it sits beside whatever fills the chip (two MSM waves hold 464 of a SIMD's 512 VGPRs)
+// and issues one instruction per 2 us: the kernels it watches do not notice it.  bench.py launches it on a stream of its
+// own next to the timed calls and prices SQ_INSTS_VALU with the clock it reports (roofline.valu_issue.clock_ghz).
+__global__ __launch_bounds__(64) void k_clock_probe(unsigned long long* out, unsigned long long ticks) {
+  if (threadIdx.x != 0) return;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  unsigned long long r1 = r0;
+  while (r1 - r0 < ticks) {
+    __builtin_amdgcn_s_sleep(127);
+    r1 = __builtin_amdgcn_s_memrealtime();
+  }
+  out[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t0;
+  out[2 * blockIdx.x + 1] = r1 - r0;
+}
+constexpr int KZG_CLOCK_PROBES = 8;
+extern "C" int32_t kzg_clock_probe_launch(const kzg_ctx* ctx, uint32_t duration_us) {
+  if (!ctx || duration_us == 0 || duration_us > 10000000u) return fail(KZG_FAIL_ARGUMENT, "bad argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  std::lock_guard<std::mutex> guard(ctx->prof_lock);
+  if (!ctx->d_clock_probe) {
+    HIP_TRY(hipMalloc(&ctx->d_clock_probe, KZG_CLOCK_PROBES * 2 * sizeof(unsigned long long)));
+    HIP_TRY(hipStreamCreateWithFlags(&ctx->probe_stream, hipStreamNonBlocking));
+  }
+  HIP_TRY(hipMemsetAsync(ctx->d_clock_probe, 0, KZG_CLOCK_PROBES * 2 * sizeof(unsigned long long), ctx->probe_stream));
+  hipLaunchKernelGGL(k_clock_probe, dim3(KZG_CLOCK_PROBES), dim3(64), 0, ctx->probe_stream, ctx->d_clock_probe, (unsigned long long)duration_us * 100ull);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+extern "C" int32_t kzg_clock_probe_read(const kzg_ctx* ctx, double* ghz_mean, double* ghz_min, double* ghz_max) {
+  if (!ctx || !ghz_mean || !ghz_min || !ghz_max) return fail(KZG_FAIL_ARGUMENT, "null argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  std::lock_guard<std::mutex> guard(ctx->prof_lock);
+  if (!ctx->d_clock_probe) return fail(KZG_FAIL_ARGUMENT, "kzg_clock_probe_read without kzg_clock_probe_launch");
+  unsigned long long h[KZG_CLOCK_PROBES * 2];
+  HIP_TRY(hipStreamSynchronize(ctx->probe_stream));
+  HIP_TRY(hipMemcpyAsync(h, ctx->d_clock_probe, sizeof(h), hipMemcpyDeviceToHost, ctx->probe_stream));
+  HIP_TRY(hipStreamSynchronize(ctx->probe_stream));
+  double sum = 0, lo = 1e30, hi = 0;
+  int cnt = 0;
+  for (int k = 0; k < KZG_CLOCK_PROBES; k++) {
+    if (!h[2 * k + 1]) continue;
+    const double g = (double)h[2 * k] / ((double)h[2 * k + 1] * 10.0);
+    sum += g;
+    lo = g < lo ? g : lo;
+    hi = g > hi ? g : hi;
+    cnt++;
+  }
+  if (!cnt) return fail(KZG_FAIL_HIP, "clock probe returned nothing");
+  *ghz_mean = sum / cnt;
+  *ghz_min = lo;
+  *ghz_max = hi;
   return 0;
 }
 

@@ -119,6 +119,12 @@ struct ProfEvent {
 
 struct kzg_verify_session;
 struct kzg_ctx;
+constexpr int KZG_WS_SLOTS = 2;
+struct WsSlot {
+  void* p = nullptr;
+  size_t bytes = 0;
+  hipEvent_t ev = nullptr;  // recorded after the last enqueued user of the slot; the next user's stream waits on it
+};
 // Extension point for the TEST-ONLY library (tests/window_msm/window_msm.hip = the product objects + one more translation
 // unit): an alternative fixed-base MSM -- round 1's window-table kernels as independent cross-checks of the comb, and a
 // time-stamping instance of the comb kernel.  The product library never sets g_msm_override_hook: kzg_ctx_create then has one
@@ -190,9 +196,12 @@ struct kzg_ctx {
   EnvKnobs knobs;  // read once at kzg_ctx_create
   // workspace (grown on demand, guarded by lock)
   mutable std::mutex lock;
-  mutable void* ws = nullptr;
-  mutable size_t ws_bytes = 0;
-  mutable hipEvent_t ws_event = nullptr;  // recorded after the last enqueued user of `ws`; the next user's stream waits on it
+  // KZG_WS_SLOTS workspaces taken in turn by successive commitment / proof calls: a call's stream waits for the previous
+  // user of ITS slot only, so two calls enqueued on two streams run side by side (one call's hash and quotient kernels in
+  // the shadow of the other's MSM) instead of queueing behind one shared buffer
+  mutable WsSlot wss[KZG_WS_SLOTS];
+  mutable uint32_t ws_next = 0;  // slot of the next call
+  mutable uint32_t ws_cur = 0;   // slot of the call being enqueued (between ws_begin and ws_end, under `lock`)
   mutable std::vector<hipEvent_t> proof_events;  // pooled fork/join events of the proof path's chunk pipeline (guarded by lock)
   // profiling (kzg_profile_begin/end): event pairs around the launches of the kernels named by ProfKind, each pair on the
   // stream its kernel runs on; own lock (the verify entry points do not take `lock`)
@@ -200,6 +209,8 @@ struct kzg_ctx {
   mutable std::atomic<bool> profiling{false};  // read without prof_lock by ProfScope on every launch
   mutable std::vector<ProfEvent> prof_events;
   mutable size_t prof_used = 0;
+  mutable unsigned long long* d_clock_probe = nullptr;  // kzg_clock_probe_launch / _read (guarded by prof_lock)
+  mutable hipStream_t probe_stream = nullptr;
   // pooled verify sessions (device scratch + side stream + events), engine_verify.hip
   mutable std::mutex pool_lock;
   mutable std::vector<kzg_verify_session*> session_pool;
@@ -243,9 +254,13 @@ int32_t stage_init(const kzg_ctx* ctx);                                         
 int32_t stage_reserve(const kzg_ctx* ctx, size_t arena_bytes, size_t io_bytes);   // caller holds stage_lock
 void stage_destroy(const kzg_ctx* ctx);
 
-int32_t ws_reserve(const kzg_ctx* ctx, size_t bytes);
-int32_t ws_acquire(const kzg_ctx* ctx, hipStream_t st);
-int32_t ws_release(const kzg_ctx* ctx, hipStream_t st);
+// workspace of the call being enqueued (caller holds ctx->lock from ws_begin to ws_end)
+int32_t ws_begin(const kzg_ctx* ctx, hipStream_t st);    // takes the next slot; `st` waits for the slot's previous user
+int32_t ws_wait(const kzg_ctx* ctx, hipStream_t st);     // a further stream of the same call waits for it too
+int32_t ws_reserve(const kzg_ctx* ctx, size_t bytes);    // grows the slot (waits for its previous user on the host first)
+int32_t ws_reserve_all(const kzg_ctx* ctx, size_t bytes);  // every slot: a pipeline sizes them once, before anything is in flight
+int32_t ws_end(const kzg_ctx* ctx, hipStream_t st);      // records the slot's event on `st`
+static inline uint8_t* ws_ptr(const kzg_ctx* ctx) { return reinterpret_cast<uint8_t*>(ctx->wss[ctx->ws_cur].p); }
 int32_t prof_next(const kzg_ctx* ctx, int kind, hipEvent_t* e0, hipEvent_t* e1);
 // brackets the launches enqueued on `st` during its lifetime with an event pair (no-op unless profiling)
 struct ProfScope {

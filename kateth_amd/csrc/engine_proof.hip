@@ -6,6 +6,38 @@ __global__ __launch_bounds__(256) void k_merge_status(int32_t* __restrict__ prim
   if (i < n && primary[i] == 0) primary[i] = secondary[i];
 }
 
+// workspace of a proof call over n items: chunks of cn items, two slots of per-chunk preparation results (z, 1/(z^4096 - 1), y,
+// commitment statuses, quotient scalars) and one set of MSM buffers
+struct ProofLayout {
+  uint64_t cn = 0;
+  uint32_t splits = 1;
+  size_t o_z[2], o_y[2], o_cs[2], o_q[2], o_ir[2], o_part = 0, o_sum = 0, o_msm = 0, total = 0;
+};
+static ProofLayout proof_layout(const kzg_ctx* ctx, uint64_t n) {
+  ProofLayout L;
+  const uint64_t chunk_max = ctx->knobs.proof_chunk ? ctx->knobs.proof_chunk : 16384;
+  L.cn = n < chunk_max ? n : chunk_max;
+  L.splits = choose_splits(ctx, L.cn);
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    size_t o = off;
+    off = align_up(off + bytes, 256);
+    return o;
+  };
+  for (int sl = 0; sl < 2; sl++) {
+    L.o_z[sl] = take(L.cn * sizeof(fr_t));
+    L.o_ir[sl] = take(L.cn * sizeof(fr_t));
+    L.o_y[sl] = take(L.cn * sizeof(fr_t));
+    L.o_cs[sl] = take(L.cn * sizeof(int32_t));
+    L.o_q[sl] = take(L.cn * 4096 * sizeof(fr_t));
+  }
+  L.o_part = take(L.cn * L.splits * 65 * sizeof(g1_xyzz));  // 64 lane sums + 1 unit sum per (blob, split)
+  L.o_sum = take(L.cn * sizeof(g1_xyzz));
+  L.o_msm = take(msm_scratch_bytes(ctx, L.cn));
+  L.total = off;
+  return L;
+}
+
 // proofs for n (blob, commitment) or (blob, z) items resident on the device.
 //   d_commitments48 != null : blob proofs (z from the Fiat-Shamir challenge)
 //   d_z32 != null           : proofs at caller-supplied points; y written to d_y32
@@ -19,33 +51,17 @@ static int32_t proof_dev_locked(const kzg_ctx* ctx, const uint8_t* d_blobs, cons
   // when the MSM finished).  So FEW, LARGE chunks win -- measured at n = 16,384, c = 12: 4 x 4,096 serial 244 ms,
   // 4 x 4,096 on two streams 242 ms, 2 x 8,192 224 ms, 8 x 2,048 279 ms (profiles/r01/proof_pipeline_variants.txt).
   // The two-stream pipeline stays selectable (KATETH_AMD_PROOF_OVERLAP=1, KATETH_AMD_PROOF_CHUNK).
-  uint64_t chunk_max = ctx->knobs.proof_chunk ? ctx->knobs.proof_chunk : 16384;
   bool overlap = ctx->knobs.proof_overlap > 0;
-  const uint64_t cn = n < chunk_max ? n : chunk_max;
-  const uint64_t nchunks = (n + cn - 1) / cn;
-  const uint32_t splits = choose_splits(ctx, cn);
-  size_t off = 0;
-  auto take = [&](size_t bytes) {
-    size_t o = off;
-    off = align_up(off + bytes, 256);
-    return o;
-  };
-  size_t o_z[2], o_y[2], o_cs[2], o_q[2], o_ir[2];
-  for (int sl = 0; sl < 2; sl++) {
-    o_z[sl] = take(cn * sizeof(fr_t));
-    o_ir[sl] = take(cn * sizeof(fr_t));
-    o_y[sl] = take(cn * sizeof(fr_t));
-    o_cs[sl] = take(cn * sizeof(int32_t));
-    o_q[sl] = take(cn * 4096 * sizeof(fr_t));
-  }
-  const size_t o_part = take(cn * splits * 65 * sizeof(g1_xyzz));  // 64 lane sums + 1 unit sum per (blob, split)
-  const size_t o_sum = take(cn * sizeof(g1_xyzz));
-  const size_t o_msm = take(msm_scratch_bytes(ctx, cn));
-  int32_t rc = ws_reserve(ctx, off);
+  const ProofLayout L = proof_layout(ctx, n);
+  const uint64_t cn = L.cn, nchunks = (n + cn - 1) / cn;
+  const uint32_t splits = L.splits;
+  int32_t rc = ws_reserve(ctx, L.total);
   if (rc) return rc;
-  uint8_t* ws = reinterpret_cast<uint8_t*>(ctx->ws);
-  g1_xyzz* partials = reinterpret_cast<g1_xyzz*>(ws + o_part);
-  g1_xyzz* sums = reinterpret_cast<g1_xyzz*>(ws + o_sum);
+  uint8_t* ws = ws_ptr(ctx);
+  const size_t *o_z = L.o_z, *o_y = L.o_y, *o_cs = L.o_cs, *o_q = L.o_q, *o_ir = L.o_ir;
+  const size_t o_msm = L.o_msm;
+  g1_xyzz* partials = reinterpret_cast<g1_xyzz*>(ws + L.o_part);
+  g1_xyzz* sums = reinterpret_cast<g1_xyzz*>(ws + L.o_sum);
   hipStream_t side = overlap ? ctx->side_stream : st;
   // events come from the context's pool (guarded by ctx->lock, which the caller holds): 4 per chunk + 1, created once
   std::vector<hipEvent_t>& pool = ctx->proof_events;
@@ -133,11 +149,11 @@ extern "C" int32_t kzg_compute_blob_proof_batch_dev(const kzg_ctx* ctx, const vo
   HIP_TRY(hipSetDevice(ctx->device));
   std::lock_guard<std::mutex> guard(ctx->lock);
   hipStream_t st = (hipStream_t)hip_stream;
-  int32_t rc = ws_acquire(ctx, st);
+  int32_t rc = ws_begin(ctx, st);
   if (rc == 0)
     rc = proof_dev_locked(ctx, (const uint8_t*)d_blobs, (const uint8_t*)d_commitments48, nullptr, n, (uint8_t*)d_out48, nullptr, nullptr,
                           (int32_t*)d_status, st);
-  if (rc == 0) rc = ws_release(ctx, st);
+  if (rc == 0) rc = ws_end(ctx, st);
   return rc;
 }
 
@@ -199,7 +215,10 @@ int32_t proof_host(const kzg_ctx* ctx, const uint8_t* blobs, const uint8_t* side
       rc = fail(KZG_FAIL_HIP, "host-to-device copy failed");
       break;
     }
-    rc = ws_acquire(ctx, st);
+    // one workspace slot for all passes (they follow each other on `st`), sized for the largest pass BEFORE anything is in
+    // flight: growing it between passes would free memory under the pipeline
+    rc = ws_begin(ctx, st);
+    if (rc == 0) rc = ws_reserve(ctx, proof_layout(ctx, max_pass).total);
     uint64_t base = 0;
     for (size_t k = 0; k < plan.size() && rc == 0; base += plan[k], k++) {
       const int slot = (int)(k & 1);
@@ -221,7 +240,7 @@ int32_t proof_host(const kzg_ctx* ctx, const uint8_t* blobs, const uint8_t* side
       if (rc == 0 && hipEventRecord(ctx->stage_done[slot], st) != hipSuccess) rc = fail(KZG_FAIL_HIP, "event record failed");
     }
     if (rc) break;
-    rc = ws_release(ctx, st);
+    rc = ws_end(ctx, st);
     if (rc) break;
     if ((out48 && hipMemcpyAsync(out48, d_out, n * 48, hipMemcpyDeviceToHost, st) != hipSuccess) ||
         (out_affine96 && hipMemcpyAsync(out_affine96, d_aff, n * 96, hipMemcpyDeviceToHost, st) != hipSuccess) ||

@@ -17,8 +17,10 @@ struct kzg_verify_session {
   const kzg_ctx* ctx = nullptr;
   uint64_t n = 0;
   hipStream_t st = nullptr;    // the caller's stream of the current use
-  hipStream_t side = nullptr;  // owned
+  hipStream_t side = nullptr;  // owned: the point decoder
+  hipStream_t aux = nullptr;   // owned: lincomb A (the decoder may still hold `side` when its sorting starts)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;  // owned
+  hipEvent_t ev_nodes = nullptr, ev_stat = nullptr, ev_aux = nullptr;  // owned: transcript digests read back; statuses read back; aux fork
   uint8_t* buf = nullptr;      // owned: one device allocation of `cap` bytes, carved below
   size_t cap = 0;
   uint4* aff = nullptr;    // [2n+1] affine points: proofs, commitments, generator
@@ -35,16 +37,21 @@ struct kzg_verify_session {
   uint8_t* msm_b = nullptr;
   fr_t* rpow2 = nullptr;     // [64] r^(2^k)
   fr_t* ysum = nullptr;      // per-block partial sums of r_i*y_i
-  std::vector<int32_t> h_stat;   // host read-back
-  std::vector<uint32_t> h_nodes;
+  // host read-back, PINNED (owned): the copies are enqueued and waited for by event, so the host can go on enqueueing while the
+  // decoder still runs
+  int32_t* h_stat = nullptr;    // [3n]
+  uint32_t* h_nodes = nullptr;  // [ceil(n / 256) * 8]
+  size_t h_cap = 0;
 };
 
 static void session_free(kzg_verify_session* s) {
   if (!s) return;
   if (s->buf) (void)hipFree(s->buf);
+  if (s->h_stat) (void)hipHostFree(s->h_stat);
   if (s->side) (void)hipStreamDestroy(s->side);
-  if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
-  if (s->ev_join) (void)hipEventDestroy(s->ev_join);
+  if (s->aux) (void)hipStreamDestroy(s->aux);
+  for (hipEvent_t e : {s->ev_fork, s->ev_join, s->ev_nodes, s->ev_stat, s->ev_aux})
+    if (e) (void)hipEventDestroy(e);
   delete s;
 }
 void session_pool_clear(const kzg_ctx* ctx) {
@@ -60,6 +67,7 @@ extern "C" void kzg_verify_session_destroy(kzg_verify_session* s) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(s->st);  // nothing enqueued by this use may still touch the buffers
   (void)hipStreamSynchronize(s->side);
+  (void)hipStreamSynchronize(s->aux);
   std::lock_guard<std::mutex> guard(ctx->pool_lock);
   if (ctx->session_pool.size() < 8)
     ctx->session_pool.push_back(s);
@@ -189,6 +197,8 @@ static MsmVarLayout msm_var_layout(const kzg_ctx* ctx, uint64_t nterms) {
 }
 
 struct MsmVarJob {
+  MsmVarLayout L{};
+  uint64_t nterms = 0;
   VarGeom g{};
   uint32_t nout = 0;  // points read back: W window sums, or W*c bit sums on the flat path
   uint8_t* buf = nullptr;
@@ -199,15 +209,22 @@ struct MsmVarJob {
   bool active = false;
 };
 
-static int32_t msm_var_launch(const kzg_ctx* ctx, MsmVarJob& job, const uint4* d_points, const uint8_t* d_inf, const fr_t* d_scalars, uint64_t nterms,
-                              hipStream_t st, uint8_t* prealloc = nullptr) {
+// The launch comes in two halves so that batch verification can run the first beside the point decoder:
+//   msm_var_sort        -- digits, histogram, scan, scatter: needs the SCALARS only.  `d_inf` = null: points at infinity are not
+//                          filtered here (their flags may not exist yet); they are all-zero entries that the bucket chains skip.
+//                          `lean`: the scan kernel that fits beside two decoder waves (flat path).
+//   msm_var_accumulate  -- bucket sums and bit / window sums: needs the decoded POINTS.
+static int32_t msm_var_sort(const kzg_ctx* ctx, MsmVarJob& job, const uint8_t* d_inf, const fr_t* d_scalars, uint64_t nterms, hipStream_t st,
+                            uint8_t* prealloc, bool lean) {
   job.active = false;
   job.st = st;
+  job.nterms = nterms;
   if (nterms == 0) return 0;
-  const MsmVarLayout L = msm_var_layout(ctx, nterms);
+  job.L = msm_var_layout(ctx, nterms);
+  const MsmVarLayout& L = job.L;
   const VarGeom g = L.g;
   job.g = g;
-  const uint32_t nb = L.nb, K = L.K;
+  const uint32_t nb = L.nb;
   if (prealloc) {
     job.buf = prealloc;
     job.owns_buf = false;
@@ -220,25 +237,43 @@ static int32_t msm_var_launch(const kzg_ctx* ctx, MsmVarJob& job, const uint4* d
   uint32_t* offsets = (uint32_t*)(buf + L.o_offsets);
   uint32_t* cursors = (uint32_t*)(buf + L.o_cursors);
   uint32_t* entries = (uint32_t*)(buf + L.o_entries);
-  g1_xyzz28* bpart = (g1_xyzz28*)(buf + L.o_part);
-  g1_xyzz28* bsum = (g1_xyzz28*)(buf + L.o_bsum);
-  g1_xyzz* winsum = (g1_xyzz*)(buf + L.o_win);
   job.nout = g.top_n ? g.W * g.c : g.W;
   job.win.resize(job.nout);
   job.active = true;
   HIP_TRY(hipMemsetAsync(counts, 0, (size_t)(nb + 1) * 4, st));
   hipLaunchKernelGGL(k_var_count, dim3(blocks_for(nterms, 256)), dim3(256), 0, st, d_scalars, d_inf, nterms, g, counts);
   if (g.top_n) {
-    const uint32_t regular = (g.W - 1) * g.half;
     if (nb > 1024u * 80u || g.top_n * g.ktop > g.half) return fail(KZG_FAIL_ARGUMENT, "flat MSM geometry out of range");
-    hipLaunchKernelGGL(k_var_scan_wide<80>, dim3(1), dim3(1024), 0, st, counts, nb, offsets, cursors);  // nb = 20 * 4096 = 1024 * 80
-    hipLaunchKernelGGL(k_var_scatter, dim3(blocks_for(nterms, 256)), dim3(256), 0, st, d_scalars, d_inf, nterms, g, cursors, entries);
+    if (lean)
+      hipLaunchKernelGGL(k_var_scan_lean, dim3(1), dim3(256), 0, st, counts, nb, (nb / 256u + 3u) & ~3u, offsets, cursors);  // nb = 20 * 4096 = 256 * 320
+    else
+      hipLaunchKernelGGL(k_var_scan_wide<80>, dim3(1), dim3(1024), 0, st, counts, nb, offsets, cursors);  // nb = 20 * 4096 = 1024 * 80
+  } else {
+    hipLaunchKernelGGL(k_var_scan, dim3(1), dim3(1024), 0, st, counts, nb, offsets, cursors);
+  }
+  hipLaunchKernelGGL(k_var_scatter, dim3(blocks_for(nterms, 256)), dim3(256), 0, st, d_scalars, d_inf, nterms, g, cursors, entries);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+static int32_t msm_var_accumulate(const kzg_ctx* ctx, MsmVarJob& job, const uint4* d_points, hipStream_t st) {
+  (void)ctx;
+  if (!job.active) return 0;
+  const MsmVarLayout& L = job.L;
+  const VarGeom g = L.g;
+  const uint32_t nb = L.nb, K = L.K;
+  uint8_t* buf = job.buf;
+  uint32_t* offsets = (uint32_t*)(buf + L.o_offsets);
+  uint32_t* entries = (uint32_t*)(buf + L.o_entries);
+  g1_xyzz28* bpart = (g1_xyzz28*)(buf + L.o_part);
+  g1_xyzz28* bsum = (g1_xyzz28*)(buf + L.o_bsum);
+  g1_xyzz* winsum = (g1_xyzz*)(buf + L.o_win);
+  if (g.top_n) {
+    const uint32_t regular = (g.W - 1) * g.half;
     hipLaunchKernelGGL(k_var_buckets_flat, dim3(blocks_for((uint64_t)regular + (uint64_t)g.top_n * g.ktop, 64)), dim3(64), 0, st, d_points, offsets,
                        entries, regular, g.top_n, g.ktop, bsum, bpart);
     hipLaunchKernelGGL(k_var_bitsums, dim3(g.W * g.c), dim3(256), 0, st, bsum, bpart, g, winsum);
   } else {
-    hipLaunchKernelGGL(k_var_scan, dim3(1), dim3(1024), 0, st, counts, nb, offsets, cursors);
-    hipLaunchKernelGGL(k_var_scatter, dim3(blocks_for(nterms, 256)), dim3(256), 0, st, d_scalars, d_inf, nterms, g, cursors, entries);
     hipLaunchKernelGGL(k_var_buckets, dim3(blocks_for((uint64_t)nb * K, 64)), dim3(64), 0, st, d_points, offsets, entries, nb, K, bpart);
     hipLaunchKernelGGL(k_var_fold, dim3(blocks_for((uint64_t)nb * K, 64)), dim3(64), 0, st, bpart, nb, K, bsum);
     hipLaunchKernelGGL(k_var_windows, dim3(g.W), dim3(64), 0, st, bsum, g, winsum);
@@ -248,6 +283,13 @@ static int32_t msm_var_launch(const kzg_ctx* ctx, MsmVarJob& job, const uint4* d
   // until the stream has drained, which would keep a second job from being enqueued beside this one
   job.d_win = winsum;
   return 0;
+}
+
+static int32_t msm_var_launch(const kzg_ctx* ctx, MsmVarJob& job, const uint4* d_points, const uint8_t* d_inf, const fr_t* d_scalars, uint64_t nterms,
+                              hipStream_t st, uint8_t* prealloc = nullptr) {
+  int32_t rc = msm_var_sort(ctx, job, d_inf, d_scalars, nterms, st, prealloc, false);
+  if (rc == 0) rc = msm_var_accumulate(ctx, job, d_points, st);
+  return rc;
 }
 
 static int32_t msm_var_finish(MsmVarJob& job, g1_xyzz& result) {
@@ -349,8 +391,12 @@ static int32_t session_acquire(const kzg_ctx* ctx, uint64_t n, hipStream_t st, k
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     if (hipStreamCreateWithPriority(&s->side, hipStreamNonBlocking, prio_greatest) != hipSuccess ||
+        hipStreamCreateWithFlags(&s->aux, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&s->ev_nodes, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&s->ev_stat, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&s->ev_aux, hipEventDisableTiming) != hipSuccess) {
       session_free(s);
       return fail(KZG_FAIL_HIP, "verify session: stream/event creation failed");
     }
@@ -365,6 +411,22 @@ static int32_t session_acquire(const kzg_ctx* ctx, uint64_t n, hipStream_t st, k
       return fail(KZG_FAIL_HIP, "hipMalloc(verify session) failed");
     }
     s->cap = want;
+  }
+  {
+    const size_t hneed = (3 * n + 1) * sizeof(int32_t) + ((n + 255) / 256 + 1) * 32;
+    if (s->h_cap < hneed) {
+      if (s->h_stat) (void)hipHostFree(s->h_stat);
+      s->h_stat = nullptr;
+      s->h_cap = 0;
+      void* hp = nullptr;
+      if (hipHostMalloc(&hp, hneed + hneed / 8, hipHostMallocDefault) != hipSuccess) {
+        session_free(s);
+        return fail(KZG_FAIL_HIP, "hipHostMalloc(verify session) failed");
+      }
+      s->h_stat = reinterpret_cast<int32_t*>(hp);
+      s->h_cap = hneed + hneed / 8;
+    }
+    s->h_nodes = reinterpret_cast<uint32_t*>(s->h_stat + (3 * n + 1));
   }
   if (st == KZG_SESSION_STREAM) st = s->side;
   s->n = n;
@@ -463,34 +525,50 @@ static int32_t phase1_items(kzg_verify_session* s, const uint8_t* blobs, const u
   return 0;
 }
 
-// Transcript over all n items (it hashes the input BYTES and (z, y): it does not wait for the decoded points), join of
-// the decode stream, read-back of statuses and node digests, first-error scan, local transcript root.
-static int32_t phase1_finish(kzg_verify_session* s, const uint8_t* com, const uint8_t* prf, uint8_t* out_root32, int32_t* err6, TraceTimer& tt) {
+// ---- phase 1 in three pieces (the fused single-context call interleaves them with phase 2's, see verify_fused) -------------
+// (a) transcript over all n items -- it hashes the input BYTES and (z, y): it does not wait for the decoded points -- and the
+//     read-back of its node digests, enqueued on `st`
+static int32_t p1_transcript(kzg_verify_session* s, const uint8_t* com, const uint8_t* prf) {
   const uint64_t n = s->n;
   hipStream_t st = s->st;
   const uint64_t groups = (n + 255) / 256;
-  s->h_stat.resize(3 * n);
-  s->h_nodes.resize(groups * 8);
   hipLaunchKernelGGL(k_transcript_leaves, dim3(blocks_for(n, 256)), dim3(256), 0, st, com, prf, s->z, s->y, n, s->leaves);
   const uint64_t nmid = (n + 15) / 16;  // groups == ceil(nmid / 16)
   hipLaunchKernelGGL(k_transcript_nodes, dim3(blocks_for(nmid, 64)), dim3(64), 0, st, s->leaves, n, 16u, s->mids);
   hipLaunchKernelGGL(k_transcript_nodes, dim3(blocks_for(groups, 64)), dim3(64), 0, st, s->mids, nmid, 16u, s->nodes);
-  (void)hipStreamWaitEvent(st, s->ev_join, 0);
   if (hipGetLastError() != hipSuccess) return fail(KZG_FAIL_HIP, "verify phase 1 launch failed");
-  if (hipMemcpyAsync(s->h_stat.data(), s->stat, 3 * n * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
-      hipMemcpyAsync(s->h_nodes.data(), s->nodes, groups * 32, hipMemcpyDeviceToHost, st) != hipSuccess)
+  if (hipMemcpyAsync(s->h_nodes, s->nodes, groups * 32, hipMemcpyDeviceToHost, st) != hipSuccess || hipEventRecord(s->ev_nodes, st) != hipSuccess)
     return fail(KZG_FAIL_HIP, "verify phase 1 readback failed");
-  if (hipStreamSynchronize(st) != hipSuccess) return fail(KZG_FAIL_HIP, "verify phase 1 synchronize failed");
-  tt.mark("gpu kernels + readback");
-  scan_first_error(s->h_stat.data(), n, &err6[0], &err6[1]);
-  scan_first_error(s->h_stat.data() + n, n, &err6[2], &err6[3]);
-  scan_first_error(s->h_stat.data() + 2 * n, n, &err6[4], &err6[5]);
-  // local transcript root = SHA-256 over the node digests (big-endian bytes)
+  return 0;
+}
+// (b) local transcript root = SHA-256 over the node digests (big-endian bytes); waits for (a) only -- the decoder may still run
+static int32_t p1_root(kzg_verify_session* s, uint8_t* out_root32) {
+  if (hipEventSynchronize(s->ev_nodes) != hipSuccess) return fail(KZG_FAIL_HIP, "verify phase 1 synchronize failed");
+  const uint64_t groups = (s->n + 255) / 256;
   std::vector<uint8_t> nb(groups * 32);
   for (uint64_t k = 0; k < groups * 8; k++) store_be32(nb.data() + 4 * k, s->h_nodes[k]);
   sha256_bytes(out_root32, nb.data(), nb.size());
-  tt.mark("status scan + root hash");
   return 0;
+}
+// (c) join of the decode stream, read-back of the statuses, first-error scan
+static int32_t p1_status(kzg_verify_session* s, int32_t* err6) {
+  const uint64_t n = s->n;
+  hipStream_t st = s->st;
+  if (hipStreamWaitEvent(st, s->ev_join, 0) != hipSuccess ||
+      hipMemcpyAsync(s->h_stat, s->stat, 3 * n * 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipEventRecord(s->ev_stat, st) != hipSuccess ||
+      hipEventSynchronize(s->ev_stat) != hipSuccess)
+    return fail(KZG_FAIL_HIP, "verify phase 1 status readback failed");
+  scan_first_error(s->h_stat, n, &err6[0], &err6[1]);
+  scan_first_error(s->h_stat + n, n, &err6[2], &err6[3]);
+  scan_first_error(s->h_stat + 2 * n, n, &err6[4], &err6[5]);
+  return 0;
+}
+static int32_t phase1_finish(kzg_verify_session* s, const uint8_t* com, const uint8_t* prf, uint8_t* out_root32, int32_t* err6, TraceTimer& tt) {
+  int32_t rc = p1_transcript(s, com, prf);
+  if (rc == 0) rc = p1_root(s, out_root32);
+  if (rc == 0) rc = p1_status(s, err6);
+  tt.mark("gpu kernels + readback + status scan + root hash");
+  return rc;
 }
 
 extern "C" int32_t kzg_verify_phase1_dev(const kzg_ctx* ctx, const void* d_blobs, const void* d_commitments48, const void* d_proofs48,
@@ -597,7 +675,8 @@ int32_t verify_phase1_host(const kzg_ctx* ctx, const uint8_t* blobs, const uint8
                            int32_t* err6, kzg_verify_session** session) {
   *session = nullptr;
   TraceTimer tt(ctx->knobs.trace, "phase1(host buffers)");
-  for (int k = 0; k < 6; k++) err6[k] = (k % 2 == 0) ? -1 : 0;
+  if (err6)
+    for (int k = 0; k < 6; k++) err6[k] = (k % 2 == 0) ? -1 : 0;
   std::lock_guard<std::mutex> guard(ctx->stage_lock);  // the arena and the copy/compute streams below are shared
   int32_t rc = stage_init(ctx);
   if (rc) return rc;
@@ -672,7 +751,14 @@ int32_t verify_phase1_host(const kzg_ctx* ctx, const uint8_t* blobs, const uint8
     }
     if (rc) break;
     tt.mark("enqueue copies + per-chunk kernels");
-    rc = phase1_finish(s, com, prf, out_root32, err6, tt);
+    // err6 == null (the fused single-context call): only the transcript and its root here -- once the root is known every blob
+    // has been hashed and evaluated, so the staging arena can be handed on; the statuses are read by the caller, later
+    if (err6) {
+      rc = phase1_finish(s, com, prf, out_root32, err6, tt);
+    } else {
+      rc = p1_transcript(s, com, prf);
+      if (rc == 0) rc = p1_root(s, out_root32);
+    }
   } while (0);
   if (rc) {
     (void)hipStreamSynchronize(ctx->stage_copy_stream);
@@ -817,88 +903,165 @@ int32_t evaluate_blobs_single(const kzg_ctx* ctx, const uint8_t* blobs, const ui
   return rc;
 }
 
+static int32_t first_error_code(const int32_t* err6);
+// ---- phase 2 in four pieces ---------------------------------------------------------------------------------------------
+struct Phase2 {
+  MsmVarJob ja, jb;
+};
+// (a) r = hash_to_fr("RCKZGBATCH___V1_" || u128(4096) || u128(n_total) || roots); scalars r_i, r_i z_i, -sum r_i y_i on `st`
+static int32_t p2_scalars(kzg_verify_session* s, const uint8_t* roots32, uint64_t world, uint64_t first_index, uint64_t n_total) {
+  hipStream_t st = s->st;
+  const uint64_t n = s->n;
+  std::vector<uint8_t> msg(48 + 32 * world);
+  memcpy(msg.data(), "RCKZGBATCH___V1_", 16);
+  memset(msg.data() + 16, 0, 32);
+  msg[30] = 0x10;  // 4096 as u128 big-endian
+  for (int k = 0; k < 8; k++) msg[47 - k] = (uint8_t)(n_total >> (8 * k));
+  memcpy(msg.data() + 48, roots32, 32 * world);
+  uint8_t digest[32];
+  sha256_bytes(digest, msg.data(), msg.size());
+  fr_t r;
+  fr_from_be_bytes_plain(r, digest);
+  fr_reduce_256(r);
+  to_mont<FrParams>(r, r);
+  fr_t rpow2[64];
+  rpow2[0] = r;
+  for (int k = 1; k < 64; k++) fr_sqr(rpow2[k], rpow2[k - 1]);
+  const unsigned nblk = blocks_for(n, 256);
+  if (hipMemcpyAsync(s->rpow2, rpow2, sizeof(rpow2), hipMemcpyHostToDevice, st) != hipSuccess) return fail(KZG_FAIL_HIP, "copy");  // pageable source: staged before the call returns
+  hipLaunchKernelGGL(k_batch_scalars, dim3(nblk), dim3(256), 0, st, s->rpow2, s->z, s->y, n, first_index, s->scal + n, s->scal, s->ysum);
+  hipLaunchKernelGGL(k_batch_ysum_finish, dim3(1), dim3(256), 0, st, s->ysum, nblk, s->scal + 2 * n);
+  if (hipGetLastError() != hipSuccess) return fail(KZG_FAIL_HIP, "verify phase 2 launch failed");
+  return 0;
+}
+// (b) the sorting halves of the two lincombs  A = sum r_i proof_i  (aux stream)  and
+//     B = sum (r_i z_i) proof_i + sum r_i commitment_i - (sum r_i y_i) G  (the caller's stream; the longer one, enqueued first).
+//     They need the scalars only: `beside_decoder` uses the kernels that fit next to two decoder waves and ignores the
+//     infinity flags (which the decoder may not have written yet).
+static int32_t p2_sort(kzg_verify_session* s, Phase2& p2, bool beside_decoder) {
+  const kzg_ctx* ctx = s->ctx;
+  const uint64_t n = s->n;
+  (void)hipEventRecord(s->ev_aux, s->st);
+  (void)hipStreamWaitEvent(s->aux, s->ev_aux, 0);
+  const uint8_t* inf = beside_decoder ? nullptr : s->inf;
+  int32_t rc = 0;
+  {
+    ProfScope psb(ctx, PROF_VAR_MSM, s->st);
+    rc = msm_var_sort(ctx, p2.jb, inf, s->scal, 2 * n + 1, s->st, s->msm_b, beside_decoder);
+  }
+  if (rc == 0) {
+    ProfScope psa(ctx, PROF_VAR_MSM, s->aux);
+    rc = msm_var_sort(ctx, p2.ja, inf, s->scal + n, n, s->aux, s->msm_a, beside_decoder);
+  }
+  return rc;
+}
+// (c) bucket sums and bit sums: both streams wait for the decoded points first
+static int32_t p2_accumulate(kzg_verify_session* s, Phase2& p2) {
+  const kzg_ctx* ctx = s->ctx;
+  (void)hipStreamWaitEvent(s->st, s->ev_join, 0);
+  (void)hipStreamWaitEvent(s->aux, s->ev_join, 0);
+  int32_t rc = 0;
+  {
+    ProfScope psb(ctx, PROF_VAR_MSM, s->st);
+    rc = msm_var_accumulate(ctx, p2.jb, s->aff, s->st);
+  }
+  if (rc == 0) {
+    ProfScope psa(ctx, PROF_VAR_MSM, s->aux);
+    rc = msm_var_accumulate(ctx, p2.ja, s->aff, s->aux);
+  }
+  return rc;
+}
+// (d) read-backs and the host's Horner loops over the window / bit sums (0.25-0.3 ms each at 65,536 items) side by side: B's
+//     here, A's on a helper thread (both jobs finish on the GPU within 0.2 ms of each other, so one after the other the second
+//     loop was exposed in full); a helper's error text is re-published on this thread and a helper that cannot be started
+//     runs inline (run_on_helpers).  out192 = A || B, affine big-endian.
+static int32_t p2_finish(kzg_verify_session* s, Phase2& p2, uint8_t* out192) {
+  const kzg_ctx* ctx = s->ctx;
+  g1_xyzz Ax, Bx;
+  int32_t rca = 0, rcb = 0;
+  if (p2.ja.active && p2.jb.active && (p2.ja.nout + p2.jb.nout) >= 64) {
+    const int device = ctx->device;
+    (void)run_on_helpers(2, [&](uint32_t k) -> int32_t {
+      if (k == 0) return rcb = msm_var_finish(p2.jb, Bx);
+      (void)hipSetDevice(device);
+      return rca = msm_var_finish(p2.ja, Ax);
+    });
+  } else {
+    rca = msm_var_finish(p2.ja, Ax);
+    rcb = msm_var_finish(p2.jb, Bx);
+  }
+  (void)hipStreamSynchronize(s->st);
+  if (rcb || rca) return rcb ? rcb : rca;
+  host::g1_host_affine A, B;
+  host_affine_from_xyzz(A, Ax);
+  host_affine_from_xyzz(B, Bx);
+  host_affine_to_be96(out192, A);
+  host_affine_to_be96(out192 + 96, B);
+  return 0;
+}
+
 extern "C" int32_t kzg_verify_phase2_dev(kzg_verify_session* s, const uint8_t* roots32, uint64_t world, uint64_t first_index, uint64_t n_total,
                                          uint8_t* out192) {
   if (!s || !roots32 || !out192 || world == 0) return fail(KZG_FAIL_ARGUMENT, "null argument");
   const kzg_ctx* ctx = s->ctx;
   TraceTimer tt(ctx->knobs.trace, "phase2");
   HIP_TRY(hipSetDevice(ctx->device));
-  hipStream_t st = s->st;
-  const uint64_t n = s->n;
-  host::g1_host_affine A, B;
-  A.inf = B.inf = true;
-  bn_zero(A.x); bn_zero(A.y); bn_zero(B.x); bn_zero(B.y);
-  if (n) {
-    // r = hash_to_fr("RCKZGBATCH___V1_" || u128(4096) || u128(n_total) || roots)
-    std::vector<uint8_t> msg(48 + 32 * world);
-    memcpy(msg.data(), "RCKZGBATCH___V1_", 16);
-    memset(msg.data() + 16, 0, 32);
-    msg[30] = 0x10;  // 4096 as u128 big-endian
-    for (int k = 0; k < 8; k++) msg[47 - k] = (uint8_t)(n_total >> (8 * k));
-    memcpy(msg.data() + 48, roots32, 32 * world);
-    uint8_t digest[32];
-    sha256_bytes(digest, msg.data(), msg.size());
-    fr_t r;
-    fr_from_be_bytes_plain(r, digest);
-    fr_reduce_256(r);
-    to_mont<FrParams>(r, r);
-    fr_t rpow2[64];
-    rpow2[0] = r;
-    for (int k = 1; k < 64; k++) fr_sqr(rpow2[k], rpow2[k - 1]);
-    fr_t* d_rpow2 = s->rpow2;
-    fr_t* d_ysum = s->ysum;
-    const unsigned nblk = blocks_for(n, 256);
-    int32_t rc = 0;
-    g1_xyzz Ax, Bx;
-    do {
-      if (hipMemcpyAsync(d_rpow2, rpow2, sizeof(rpow2), hipMemcpyHostToDevice, st) != hipSuccess) { rc = fail(KZG_FAIL_HIP, "copy"); break; }
-      hipLaunchKernelGGL(k_batch_scalars, dim3(nblk), dim3(256), 0, st, d_rpow2, s->z, s->y, n, first_index, s->scal + n, s->scal, d_ysum);
-      hipLaunchKernelGGL(k_batch_ysum_finish, dim3(1), dim3(256), 0, st, d_ysum, nblk, s->scal + 2 * n);
-      if (hipGetLastError() != hipSuccess) { rc = fail(KZG_FAIL_HIP, "verify phase 2 launch failed"); break; }
-      // A = sum r_i * proof_i ; B = sum (r_i z_i) proof_i + sum r_i commitment_i - (sum r_i y_i) G
-      tt.mark("seed + scalars enqueue");
-      // the two lincombs are independent: A on the session's side stream, B on the caller's stream
-      (void)hipEventRecord(s->ev_fork, st);
-      (void)hipStreamWaitEvent(s->side, s->ev_fork, 0);
-      MsmVarJob ja, jb;
-      {  // B (2n + 1 terms) is the longer of the two: it is enqueued first so that its kernels are ahead in the dispatch order
-        ProfScope psb(ctx, PROF_VAR_MSM, st);
-        rc = msm_var_launch(ctx, jb, s->aff, s->inf, s->scal, 2 * n + 1, st, s->msm_b);
-      }
-      if (rc == 0) {
-        ProfScope psa(ctx, PROF_VAR_MSM, s->side);
-        rc = msm_var_launch(ctx, ja, s->aff, s->inf, s->scal + n, n, s->side, s->msm_a);
-      }
-      // The read-backs and the host's Horner loops over the window / bit sums (0.25-0.3 ms each at 65,536 items) run side by
-      // side: A's on a helper thread, B's here.  Both jobs finish on the GPU within 0.2 ms of each other, so one after the
-      // other the second loop was exposed in full.
-      int32_t rca = 0, rcb = 0;
-      if (ja.active && jb.active && (ja.nout + jb.nout) >= 64) {
-        const int device = ctx->device;
-        // job 0 (B, the longer one) here, job 1 (A) on a helper thread; a helper's error text is re-published on this thread and
-        // a helper that cannot be started runs inline (run_on_helpers)
-        const int32_t first = run_on_helpers(2, [&](uint32_t k) -> int32_t {
-          if (k == 0) return rcb = msm_var_finish(jb, Bx);
-          (void)hipSetDevice(device);
-          return rca = msm_var_finish(ja, Ax);
-        });
-        (void)first;
-      } else {
-        rca = msm_var_finish(ja, Ax);
-        rcb = msm_var_finish(jb, Bx);
-      }
-      if (rc == 0) rc = rcb ? rcb : rca;
-      tt.mark("msm A || msm B (incl. host horner)");
-    } while (0);
-    (void)hipStreamSynchronize(st);
-    if (rc) return rc;
-    host_affine_from_xyzz(A, Ax);
-    host_affine_from_xyzz(B, Bx);
-    tt.mark("to affine");
+  if (s->n == 0) {
+    memset(out192, 0, 192);  // A = B = infinity
+    return 0;
   }
-  host_affine_to_be96(out192, A);
-  host_affine_to_be96(out192 + 96, B);
-  return 0;
+  Phase2 p2;
+  int32_t rc = p2_scalars(s, roots32, world, first_index, n_total);
+  tt.mark("seed + scalars enqueue");
+  if (rc == 0) rc = p2_sort(s, p2, false);
+  if (rc == 0) rc = p2_accumulate(s, p2);
+  if (rc == 0) rc = p2_finish(s, p2, out192);
+  tt.mark("msm A || msm B (incl. host horner)");
+  if (rc) {
+    (void)hipStreamSynchronize(s->st);
+    (void)hipStreamSynchronize(s->aux);
+  }
+  return rc;
+}
+
+// The single-context call, phases interleaved: everything that does not need the decoded POINTS -- transcript, root, r, the
+// scalars, and the digit / histogram / scan / scatter halves of both lincombs -- is enqueued while the point decoder still runs
+// on the session's side stream (its 2 x 224-VGPR waves leave every SIMD 64 registers, and each of those kernels fits in 64),
+// so the bucket kernels start the moment the decoder ends.  Before, all of that queued up behind it: a host round trip and
+// ~0.7 ms of short kernels on a nearly idle chip (profiles/r03/verify65536_kernel_timeline.txt).  The statuses are read after
+// the bucket kernels are enqueued; a rejected input still wins (its code is returned, the sums are discarded).
+static int32_t verify_fused(kzg_verify_session* s, const uint8_t* com, const uint8_t* prf, int32_t* ok, const uint8_t* root_done = nullptr) {
+  const kzg_ctx* ctx = s->ctx;
+  TraceTimer tt(ctx->knobs.trace, "verify (fused phases)");
+  uint8_t root[32], partial[192];
+  int32_t err6[6];
+  for (int k = 0; k < 6; k++) err6[k] = (k % 2 == 0) ? -1 : 0;
+  Phase2 p2;
+  int32_t rc = 0;
+  if (root_done) {  // host-buffer path: transcript and root were taken while the staging arena was still locked
+    memcpy(root, root_done, 32);
+  } else {
+    rc = p1_transcript(s, com, prf);
+    if (rc == 0) rc = p1_root(s, root);
+  }
+  tt.mark("hash + evaluation + transcript, root");
+  if (rc == 0) rc = p2_scalars(s, root, 1, 0, s->n);
+  if (rc == 0) rc = p2_sort(s, p2, true);
+  if (rc == 0) rc = p2_accumulate(s, p2);
+  if (rc == 0) rc = p1_status(s, err6);
+  tt.mark("decoder done, statuses");
+  int32_t code = 0;
+  if (rc == 0) code = first_error_code(err6);
+  if (rc == 0 && code == 0) rc = p2_finish(s, p2, partial);
+  tt.mark("lincombs + host horner");
+  if (rc || code) {  // drain what is enqueued before the session goes back to the pool
+    (void)hipStreamSynchronize(s->st);
+    (void)hipStreamSynchronize(s->aux);
+    if (p2.ja.owns_buf && p2.ja.buf) (void)hipFree(p2.ja.buf);
+    if (p2.jb.owns_buf && p2.jb.buf) (void)hipFree(p2.jb.buf);
+    return rc ? rc : code;
+  }
+  return kzg_verify_batch_finish(ctx, partial, 1, ok);
 }
 
 // introspection: challenge z_i and evaluation y_i of items [first, first + count) of a session after phase 1
@@ -950,27 +1113,22 @@ static int32_t first_error_code(const int32_t* err6) {
 
 extern "C" int32_t kzg_verify_blob_proof_batch_dev(const kzg_ctx* ctx, const void* d_blobs, const void* d_commitments48, const void* d_proofs48,
                                                    uint64_t n, int32_t* ok, void* hip_stream) {
-  if (!ctx || !ok) return fail(KZG_FAIL_ARGUMENT, "null argument");
+  if (!ctx || !ok || (n && (!d_blobs || !d_commitments48 || !d_proofs48))) return fail(KZG_FAIL_ARGUMENT, "null argument");
   *ok = 0;
   if (n == 0) {  // reference quirk Q4: the spec answer for an empty batch is true
     *ok = 1;
     return 0;
   }
-  uint8_t root[32];
-  int32_t err6[6];
+  HIP_TRY(hipSetDevice(ctx->device));
   kzg_verify_session* s = nullptr;
-  int32_t rc = kzg_verify_phase1_dev(ctx, d_blobs, d_commitments48, d_proofs48, n, root, err6, &s, hip_stream);
+  int32_t rc = session_acquire(ctx, n, (hipStream_t)hip_stream, &s);
   if (rc) return rc;
-  const int32_t code = first_error_code(err6);
-  if (code) {
-    kzg_verify_session_destroy(s);
-    return code;
-  }
-  uint8_t partial[192];
-  rc = kzg_verify_phase2_dev(s, root, 1, 0, n, partial);
+  const uint8_t* com = (const uint8_t*)d_commitments48;
+  const uint8_t* prf = (const uint8_t*)d_proofs48;
+  rc = phase1_items(s, (const uint8_t*)d_blobs, com, prf, 0, n, s->st, true);
+  if (rc == 0) rc = verify_fused(s, com, prf, ok);
   kzg_verify_session_destroy(s);
-  if (rc) return rc;
-  return kzg_verify_batch_finish(ctx, partial, 1, ok);
+  return rc;
 }
 
 extern "C" int32_t kzg_verify_blob_proof_batch(const kzg_ctx* ctx, const uint8_t* blobs, const uint8_t* commitments48, const uint8_t* proofs48,
@@ -987,20 +1145,12 @@ int32_t verify_batch_host_single(const kzg_ctx* ctx, const uint8_t* blobs, const
   *ok = 0;
   HIP_TRY(hipSetDevice(ctx->device));
   uint8_t root[32];
-  int32_t err6[6];
   kzg_verify_session* s = nullptr;
-  int32_t rc = verify_phase1_host(ctx, blobs, commitments48, proofs48, n, root, err6, &s);
+  int32_t rc = verify_phase1_host(ctx, blobs, commitments48, proofs48, n, root, nullptr, &s);
   if (rc) return rc;
-  const int32_t code = first_error_code(err6);
-  if (code) {
-    kzg_verify_session_destroy(s);
-    return code;
-  }
-  uint8_t partial[192];
-  rc = kzg_verify_phase2_dev(s, root, 1, 0, n, partial);
+  rc = verify_fused(s, s->pts48 + n * 48, s->pts48, ok, root);  // the device copies: proofs || commitments
   kzg_verify_session_destroy(s);
-  if (rc) return rc;
-  return kzg_verify_batch_finish(ctx, partial, 1, ok);
+  return rc;
 }
 
 // Setup::verify_blob_proof (src/kzg/setup.rs:208-221): a batch of one (the random

@@ -6,6 +6,13 @@
 // Cost per point: square root a^((p+1)/4) by a width-3 sliding window (378 squarings + 108 products; a squaring is
 // 105 + 196 v_mad_u64_u32), subgroup test phi(P) == -[z^2]P by a Jacobian ladder over z^2 (127 doublings of 4 S + 3 M and
 // 16 mixed additions of the affine input) -- about 0.65 M VALU instructions against 1.3 M for the 12 x 32-bit-limb path.
+//
+// Everything on the decoding path is INLINED into its kernel (round 4): out of line, the square root, the ladder and its
+// adder took their operands by address -- i.e. through scratch -- and saved their callers' registers: 247 VGPRs + 720 B of
+// scratch per lane, 2.76 GB of scratch write-through per 131,072 points.  Inlined, hipcc keeps the two loop bodies (one
+// squaring + one product; one doubling + one mixed addition) in 224 VGPRs with no scratch at all, which also leaves a SIMD
+// holding two decoder waves 64 registers for a third, small wave (the transcript / scalar / sorting kernels of batch
+// verification run in the decoder's shadow: engine_verify.hip).
 #pragma once
 #include "fp28.cuh"
 #include "issue_fair.cuh"
@@ -54,7 +61,7 @@ KZG_HD void f28_pow_sched(fp28& r, const fp28& a, const uint8_t* sched, int len,
   r = acc;
 }
 // a^((p+1)/4): the square root of a when a is a square (378 squarings + 105 products)
-KZG_HD_NOINLINE void f28_sqrt_candidate(fp28& r, const fp28& a) {
+KZG_HD void f28_sqrt_candidate(fp28& r, const fp28& a) {
   const uint8_t sched[2 * KZG_FP_SQRT_SCHED_LEN] = KZG_FP_SQRT_SCHED;
   f28_pow_sched(r, a, sched, KZG_FP_SQRT_SCHED_LEN, KZG_FP_SQRT_FIRST_DIGIT_INDEX);
 }
@@ -185,7 +192,7 @@ KZG_HD void jac28_dbl(g1_jac28& p) {
 
 // p += (x2, y2), an affine point in N-form; complete (identity, P + P, P + (-P)).
 // U2 = x2 Z^2, S2 = y2 Z^3, H = U2 - X, r = S2 - Y, X3 = r^2 - H^3 - 2 X H^2, Y3 = r (X H^2 - X3) - Y H^3, Z3 = Z H.
-KZG_HD_NOINLINE void jac28_madd(g1_jac28& p, const fp28& x2, const fp28& y2) {
+KZG_HD void jac28_madd(g1_jac28& p, const fp28& x2, const fp28& y2) {
   if (p.inf) {
     p.x = x2;
     p.y = y2;
@@ -242,7 +249,7 @@ KZG_HD_NOINLINE void jac28_madd(g1_jac28& p, const fp28& x2, const fp28& y2) {
 }
 
 // [z^2]P for the affine point (x, y) (N-form), z the BLS12-381 parameter: z^2 = 0xac45a4010001a4020000000100000000
-KZG_HD_NOINLINE void g1_mul_by_z2_jac28(g1_jac28& acc, const fp28& x, const fp28& y) {
+KZG_HD void g1_mul_by_z2_jac28(g1_jac28& acc, const fp28& x, const fp28& y) {
   const uint64_t hi = 0xac45a4010001a402ull, lo = 0x0000000100000000ull;
   acc.x = x;
   acc.y = y;
@@ -253,17 +260,13 @@ KZG_HD_NOINLINE void g1_mul_by_z2_jac28(g1_jac28& acc, const fp28& x, const fp28
     issue_fair_tick(18);
     jac28_dbl(acc);  // inline: the accumulator stays in registers over the runs of doublings
     const uint64_t w = i >= 64 ? hi : lo;
-    if ((w >> (i & 63)) & 1ull) {
-      g1_jac28 mine = acc;  // copy: the out-of-line adder takes addresses
-      jac28_madd(mine, x, y);
-      acc = mine;
-    }
+    if ((w >> (i & 63)) & 1ull) jac28_madd(acc, x, y);
   }
 }
 
 // blst_p1_affine_in_g1 via the endomorphism (see g1_in_subgroup in g1.cuh for the argument):
 // (x, y) in G1  <=>  (beta x, y) == -[z^2](x, y).   x, y: 2^392-Montgomery N-form.
-KZG_HD_NOINLINE bool g1_in_subgroup28(const fp28& x, const fp28& y) {
+KZG_HD bool g1_in_subgroup28(const fp28& x, const fp28& y) {
   g1_jac28 q;
   g1_mul_by_z2_jac28(q, x, y);
   if (q.inf) return false;
@@ -288,7 +291,7 @@ KZG_HD_NOINLINE bool g1_in_subgroup28(const fp28& x, const fp28& y) {
 // Same contract as g1_decompress (g1.cuh): status code, canonical 2^384-Montgomery x and y (unless r392_out), *inf.
 // r392_out: leave the coordinates in the 2^392-Montgomery domain (canonical, 12 x 32 limbs) -- the operand format of
 // the radix-2^28 adders (k_var_buckets) -- instead of converting to 2^384.
-KZG_HD_NOINLINE int32_t g1_decompress28(fp_t& x, fp_t& y, bool& inf, const uint8_t* in48, bool r392_out = false) {
+KZG_HD int32_t g1_decompress28(fp_t& x, fp_t& y, bool& inf, const uint8_t* in48, bool r392_out = false) {
   inf = false;
   const uint8_t b0 = in48[0];
   if (!(b0 & 0x80)) return KZG_ERR_EC_INVALID_ENCODING;

@@ -327,31 +327,37 @@ static __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)
 // (Fan-out 16 twice instead of 256 once: a thread hashes 9 blocks, not 129 -- the
 // 256-ary level was a 0.6 ms serial chain at the end of phase 1.)
 // ---------------------------------------------------------------------------
-static __global__ __launch_bounds__(256) void k_transcript_leaves(const uint8_t* __restrict__ commitments48, const uint8_t* __restrict__ proofs48,
-                                                          const fr_t* __restrict__ z_plain, const fr_t* __restrict__ y_plain, uint64_t n,
-                                                          uint32_t* __restrict__ leaves /* n x 8 words, big-endian word values */) {
+// Both transcript kernels stay within 64 VGPRs (second launch bound: eight waves per SIMD): a SIMD that holds two point-decoder
+// waves (2 x 224 registers) has 64 left, so these run in the decoder's shadow instead of after it.  The leaf's 160 bytes are
+// fetched block by block for that.
+static __global__ __launch_bounds__(256, 8) void k_transcript_leaves(const uint8_t* __restrict__ commitments48, const uint8_t* __restrict__ proofs48,
+                                                             const fr_t* __restrict__ z_plain, const fr_t* __restrict__ y_plain, uint64_t n,
+                                                             uint32_t* __restrict__ leaves /* n x 8 words, big-endian word values */) {
   issue_priority_latency();  // short kernels in the shadow of the point decoder (whose waves trade priorities 3 / 1)
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  uint32_t m[40];  // 160 bytes as big-endian words
   const uint32_t* c = reinterpret_cast<const uint32_t*>(commitments48 + i * 48);
   const uint32_t* p = reinterpret_cast<const uint32_t*>(proofs48 + i * 48);
-#pragma unroll
-  for (int q = 0; q < 12; q++) m[q] = __builtin_bswap32(c[q]);
-  fr_t z = z_plain[i], y = y_plain[i];
-#pragma unroll
-  for (int q = 0; q < 8; q++) m[12 + q] = z.v[7 - q];
-#pragma unroll
-  for (int q = 0; q < 8; q++) m[20 + q] = y.v[7 - q];
-#pragma unroll
-  for (int q = 0; q < 12; q++) m[28 + q] = __builtin_bswap32(p[q]);
+  const uint32_t* zw = reinterpret_cast<const uint32_t*>(z_plain + i);
+  const uint32_t* yw = reinterpret_cast<const uint32_t*>(y_plain + i);
   sha256_state s;
   sha256_init(s);
-  sha256_block(s, m);
-  sha256_block(s, m + 16);
   uint32_t w[16];
+  // words 0..39 of the message: C (12, byte-swapped), z (8, limbs 7..0), y (8), pi (12, byte-swapped)
 #pragma unroll
-  for (int q = 0; q < 8; q++) w[q] = m[32 + q];
+  for (int q = 0; q < 12; q++) w[q] = __builtin_bswap32(c[q]);
+#pragma unroll
+  for (int q = 0; q < 4; q++) w[12 + q] = zw[7 - q];
+  sha256_block(s, w);
+#pragma unroll
+  for (int q = 0; q < 4; q++) w[q] = zw[3 - q];
+#pragma unroll
+  for (int q = 0; q < 8; q++) w[4 + q] = yw[7 - q];
+#pragma unroll
+  for (int q = 0; q < 4; q++) w[12 + q] = __builtin_bswap32(p[q]);
+  sha256_block(s, w);
+#pragma unroll
+  for (int q = 0; q < 8; q++) w[q] = __builtin_bswap32(p[4 + q]);
   w[8] = 0x80000000u;
 #pragma unroll
   for (int q = 9; q < 15; q++) w[q] = 0;
@@ -362,7 +368,7 @@ static __global__ __launch_bounds__(256) void k_transcript_leaves(const uint8_t*
 }
 
 // out[g] = H(in[g * fan] .. in[min(n_in, (g + 1) * fan) - 1]) over 32-byte digests (8 big-endian word values each)
-static __global__ __launch_bounds__(64) void k_transcript_nodes(const uint32_t* __restrict__ in, uint64_t n_in, uint32_t fan, uint32_t* __restrict__ nodes) {
+static __global__ __launch_bounds__(64, 8) void k_transcript_nodes(const uint32_t* __restrict__ in, uint64_t n_in, uint32_t fan, uint32_t* __restrict__ nodes) {
   issue_priority_latency();
   const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t groups = (n_in + fan - 1) / fan;
@@ -515,7 +521,7 @@ __device__ __forceinline__ void var_digits(const fr_t& s_plain, const VarGeom& g
 static __global__ __launch_bounds__(256) void k_var_count(const fr_t* __restrict__ scalars, const uint8_t* __restrict__ inf, uint64_t nterms,
                                                    VarGeom g, uint32_t* __restrict__ counts) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= nterms || inf[t]) return;
+  if (t >= nterms || (inf && inf[t])) return;  // inf == null: points at infinity are skipped in the bucket chains instead (zero entries)
   var_digits(scalars[t], g, [&](uint32_t j, uint32_t d, bool) { atomicAdd(&counts[(uint64_t)j * g.half + (d - 1)], 1u); });
 }
 
@@ -611,10 +617,57 @@ static __global__ __launch_bounds__(1024) void k_var_scan_wide(const uint32_t* _
   if (t == 1023) offsets[len] = sh[1023];
 }
 
+// The same scan for the sorting that runs in the point decoder's shadow: ONE workgroup of four waves within 64 VGPRs (a SIMD
+// holding two decoder waves has 64 registers left), every thread walks its contiguous run of counters twice -- totals, then
+// offsets -- instead of holding it in registers.  len <= 256 * per, per a multiple of 4.
+static __global__ __launch_bounds__(256, 8) void k_var_scan_lean(const uint32_t* __restrict__ counts, uint32_t len, uint32_t per, uint32_t* __restrict__ offsets,
+                                                         uint32_t* __restrict__ cursors) {
+  __shared__ uint32_t sh[256];
+  const uint32_t t = threadIdx.x;
+  const uint32_t lo = t * per, hi = (lo + per < len) ? lo + per : len;
+  uint32_t sum = 0;
+  for (uint32_t q = lo; q + 3u < hi; q += 4u) {
+    const uint4 x = *reinterpret_cast<const uint4*>(counts + q);
+    sum += x.x + x.y + x.z + x.w;
+  }
+  for (uint32_t q = lo + ((hi > lo ? hi - lo : 0u) & ~3u); q < hi; q++) sum += counts[q];
+  sh[t] = sum;
+  __syncthreads();
+  for (uint32_t off = 1; off < 256u; off <<= 1) {
+    const uint32_t add = (t >= off) ? sh[t - off] : 0u;
+    __syncthreads();
+    sh[t] += add;
+    __syncthreads();
+  }
+  uint32_t run = sh[t] - sum;  // exclusive prefix of this run
+  uint32_t q = lo;
+  for (; q + 3u < hi; q += 4u) {
+    const uint4 x = *reinterpret_cast<const uint4*>(counts + q);
+    uint4 o;
+    o.x = run;
+    o.y = o.x + x.x;
+    o.z = o.y + x.y;
+    o.w = o.z + x.z;
+    run = o.w + x.w;
+    *reinterpret_cast<uint4*>(offsets + q) = o;
+    *reinterpret_cast<uint4*>(cursors + q) = o;
+  }
+  for (; q < hi; q++) {
+    const uint32_t v = counts[q];
+    offsets[q] = run;
+    cursors[q] = run;
+    run += v;
+  }
+  if (t == 255u) {
+    offsets[len] = sh[255];
+    cursors[len] = sh[255];
+  }
+}
+
 static __global__ __launch_bounds__(256) void k_var_scatter(const fr_t* __restrict__ scalars, const uint8_t* __restrict__ inf, uint64_t nterms,
                                                      VarGeom g, uint32_t* __restrict__ cursors, uint32_t* __restrict__ entries) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= nterms || inf[t]) return;
+  if (t >= nterms || (inf && inf[t])) return;
   var_digits(scalars[t], g, [&](uint32_t j, uint32_t d, bool neg) {
     const uint32_t pos = atomicAdd(&cursors[(uint64_t)j * g.half + (d - 1)], 1u);
     entries[pos] = ((uint32_t)t << 1) | (neg ? 1u : 0u);
@@ -640,12 +693,16 @@ __device__ __forceinline__ void var_bucket_chain(g1_xyzz28& acc, const uint4* __
 #pragma unroll 1
   for (uint32_t k = lo + k0; k < hi; k += K) {
     const uint32_t e = ne;
+    // an all-zero entry is the point at infinity (x = y = 0 is not on the curve): it contributes nothing.  The sorting kernels
+    // do not look at the decoder's infinity flags any more -- they run BESIDE the decoder -- so such terms reach the chains.
+    const bool skip = bn_is_zero(nx) && bn_is_zero(ny);
     fp28 cx, cy;
     f28_load_entry(cx, cy, nx, ny, (e & 1u) != 0);
     if (k + K < hi) {
       ne = entries[k + K];
       load_affine96(nx, ny, points, ne >> 1);
     }
+    if (skip) continue;
     bool done = false;
     if (!acc.inf) done = xyzz28_madd_fast(acc, cx, cy);
     if (!done) {

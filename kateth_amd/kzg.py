@@ -161,6 +161,8 @@ _SIGNATURES = {
     "kzg_ctx_adds_per_blob": (ctypes.c_uint64, [ctypes.c_void_p]),
     "kzg_selftest_field_mul": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]),
     "kzg_microbench_fp_mul": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(ctypes.c_float)]),
+    "kzg_clock_probe_launch": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_uint32]),
+    "kzg_clock_probe_read": (ctypes.c_int32, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "kzg_microbench_valu_issue": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
 }
 
@@ -757,6 +759,16 @@ class Setup:
         cyc, ghz = ctypes.c_double(0), ctypes.c_double(0)
         self._check(self._lib.kzg_microbench_valu_issue(self._h, waves_per_simd, iters, ctypes.byref(cyc), ctypes.byref(ghz)), "kzg_microbench_valu_issue")
         return cyc.value, ghz.value
+
+    def clock_probe_launch(self, duration_us: int):
+        """eight sleeping probe waves on the context's side stream compare the shader clock with real time for `duration_us`"""
+        self._check(self._lib.kzg_clock_probe_launch(self._h, duration_us), "kzg_clock_probe_launch")
+
+    def clock_probe_read(self):
+        """(mean, lowest, highest) XCD shader clock in GHz seen by the last probe"""
+        a, b, c = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_double(0)
+        self._check(self._lib.kzg_clock_probe_read(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)), "kzg_clock_probe_read")
+        return a.value, b.value, c.value
 
     def microbench_fp_mul(self, lanes: int, iters: int) -> float:
         ms = ctypes.c_float(0)
