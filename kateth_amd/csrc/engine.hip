@@ -59,7 +59,10 @@ static int32_t ws_grow(WsSlot& w, size_t bytes) {
   w.bytes = want;
   return 0;
 }
-int32_t ws_reserve(const kzg_ctx* ctx, size_t bytes) { return ws_grow(ctx->wss[ctx->ws_cur], bytes); }
+// Every slot grows together: the first large call pays for all of them, so that the SECOND call of a pair in flight does
+// not allocate (and synchronise the device: hipFree) in the middle of a pipeline -- seen as a 20-ms hole in the second step of a
+// traced run.  A slot that is in use is waited for on the host first; growth happens on the first call(s) of a size only.
+int32_t ws_reserve(const kzg_ctx* ctx, size_t bytes) { return ws_reserve_all(ctx, bytes); }
 int32_t ws_reserve_all(const kzg_ctx* ctx, size_t bytes) {
   for (WsSlot& w : ctx->wss) {
     int32_t rc = ws_grow(w, bytes);
@@ -718,6 +721,9 @@ int32_t ctx_create_single(const uint8_t* g1_lagrange, const uint8_t* g2_monomial
   // src/kzg/setup.rs:59-72 -- the context is usable after about as much work), build the chosen table beside the first calls
   if ((flags & KZG_CFG_BUILD_ASYNC) && !g_msm_override_hook && class_blocks(ladder[0].c) < 8u) {
     kzg_ctx* ctx = nullptr;
+    if (getenv("KATETH_AMD_TRACE"))
+      fprintf(stderr, "[kateth_amd trace] kzg_ctx_create device %d: first-use table class 8; class %u, %u plane groups follows in the background\n", device,
+              ladder[0].c, ladder[0].G);
     int32_t rc = ctx_create_with(g1_lagrange, g2_monomial, device, 8, 16, &ctx);
     if (rc) return rc;
     {
@@ -732,8 +738,15 @@ int32_t ctx_create_single(const uint8_t* g1_lagrange, const uint8_t* g2_monomial
     *out = ctx;
     return 0;
   }
+  const bool trace = getenv("KATETH_AMD_TRACE") != nullptr;
+  auto say = [&](const char* how, const TableChoice& ch) {  // the choice, once per context, for whoever asks (KATETH_AMD_TRACE=1)
+    if (trace)
+      fprintf(stderr, "[kateth_amd trace] kzg_ctx_create device %d: table class %u, %u plane groups (%s; %.1f GiB free, budget %s)\n", device, ch.c, ch.G, how,
+              (double)free_b / (double)GiB, budget == ~(size_t)0 ? "none" : (std::to_string((double)budget / (double)GiB) + " GiB").c_str());
+  };
   int32_t rc = fail(KZG_FAIL_HIP, "no table class fits");
   for (const TableChoice& ch : ladder) {
+    say(automatic ? "automatic" : "as configured", ch);
     rc = ctx_create_with(g1_lagrange, g2_monomial, device, ch.c, ch.G, out);
     if (!automatic || rc != KZG_FAIL_HIP) return rc;  // built, or rejected for a reason a smaller table would not cure (bad setup point, ...)
     (void)hipGetLastError();                          // an allocation failed: clear it and step down

@@ -40,6 +40,17 @@ int main(int argc, char** argv) {
     } catch (const kateth::Error& e) {
       if (e.kind != kateth::ErrorKind::BlobInvalidLen) return 4;
     }
+    // the same over a GROUP context (the device listed twice: two members on the card): every batch is sharded behind the same methods
+    auto group = kateth::Setup<4096, 65>::load_multi(g1.data(), g2.data(), {0, 0}, 8);
+    if (group.members() != 2 || setup.members() != 1) return 7;
+    std::vector<uint8_t> three(3 * kateth::Blob::BYTES), out3(3 * 48), ref3(3 * 48);
+    std::vector<int32_t> st3(3), st3r(3);
+    for (int k = 0; k < 3; k++) std::copy(rb.to_bytes().begin(), rb.to_bytes().end(), three.begin() + k * kateth::Blob::BYTES);
+    three[kateth::Blob::BYTES + 31] ^= 1;  // the middle blob differs
+    group.blob_to_commitment_batch(three.data(), 3, out3.data(), st3.data());
+    setup.blob_to_commitment_batch(three.data(), 3, ref3.data(), st3r.data());
+    if (out3 != ref3 || st3 != st3r || !std::equal(out3.begin(), out3.begin() + 48, rc.begin())) return 8;
+    if (!group.verify_blob_proof(rb.to_bytes().data(), kateth::Blob::BYTES, rc, rp)) return 9;
     return (ok && c[0] == 0x97 && p[0] == 0xc0) ? 0 : 2;
   } catch (const kateth::EngineFailure& e) {
     std::printf("engine failure %d: %s\n", e.code, e.what());

@@ -1,0 +1,236 @@
+"""Round-4 engine changes, through the C ABI on the GPU:
+  * batch verification with its phases interleaved (sorting beside the point decoder, infinity handled in the bucket chains,
+    statuses read after the bucket kernels are enqueued) -- src/kzg/setup.rs:115-161, 247-275;
+  * commitment / proof calls kept in flight on two streams (workspace slots) -- bit-exact against one call at a time;
+  * Polynomial::evaluate (src/kzg/poly.rs:10-33) for more pairs than one staging chunk;
+  * the spill-free point decoder at batch size against the oracle's decisions (src/bls.rs:505-531);
+  * the measurement aids bench.py prices its roofline with."""
+import json
+import os
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from conftest import GOLDEN, TRUSTED_SETUP  # noqa: E402
+
+R = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+INF48 = bytes([0xC0]) + bytes(47)
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch
+
+
+@pytest.fixture(scope="module")
+def engine():
+    import kateth_amd
+
+    s = kateth_amd.Setup.load_json(TRUSTED_SETUP, window_bits=8)
+    yield s
+    s.close()
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return json.load(open(os.path.join(GOLDEN, "kzg_vectors.json")))
+
+
+def _triples(engine, torch, n, seed):
+    d_blobs = torch.empty(n * 131072, dtype=torch.uint8, device="cuda")
+    engine.synth_blobs_dev(seed, 0, n, d_blobs.data_ptr())
+    d_c = torch.empty(n * 48, dtype=torch.uint8, device="cuda")
+    d_p = torch.empty(n * 48, dtype=torch.uint8, device="cuda")
+    d_st = torch.empty(n, dtype=torch.int32, device="cuda")
+    engine.blob_to_commitment_batch_dev(d_blobs.data_ptr(), n, d_c.data_ptr(), d_st.data_ptr())
+    torch.cuda.synchronize()
+    assert int(d_st.abs().sum()) == 0
+    engine.compute_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), n, d_p.data_ptr(), d_st.data_ptr())
+    torch.cuda.synchronize()
+    assert int(d_st.abs().sum()) == 0
+    return d_blobs, d_c, d_p
+
+
+@pytest.mark.parametrize("n", [33000, 700])
+def test_verify_with_infinity_and_repeated_points(n, engine, torch_cuda):
+    """the flat variable-base MSM (both lincombs from 32,768 terms on) and the classic one: a batch in which several blobs are
+    all-zero (commitment = proof = the point at infinity, src/bls.rs:505-531 decodes 0xc0..: the sorting kernels no longer see
+    the decoder's infinity flags, the bucket chains skip the zero entries), several triples are repeated (P + P in a bucket),
+    and one constant blob has an infinity PROOF with a finite commitment.  true; then one finite proof replaced by infinity ->
+    false; then a commitment that is not on the curve -> the reference's error although the bucket kernels had been enqueued."""
+    import kateth_amd
+
+    torch = torch_cuda
+    d_blobs, d_c, d_p = _triples(engine, torch, n, 0x1F1F + n)
+    zero_items = [0, 5, n // 2, n - 1]
+    for i in zero_items:
+        d_blobs[i * 131072:(i + 1) * 131072] = 0
+        d_c[i * 48:(i + 1) * 48] = torch.frombuffer(bytearray(INF48), dtype=torch.uint8).cuda()
+        d_p[i * 48:(i + 1) * 48] = torch.frombuffer(bytearray(INF48), dtype=torch.uint8).cuda()
+    # a constant polynomial: every element 7 -> commitment [7]G (finite), proof = infinity
+    const_blob = torch.frombuffer(bytearray((7).to_bytes(32, "big") * 4096), dtype=torch.uint8).cuda()
+    d_blobs[9 * 131072:10 * 131072] = const_blob
+    c9 = engine.blob_to_commitment(bytes(const_blob.cpu().numpy().tobytes()))
+    d_c[9 * 48:10 * 48] = torch.frombuffer(bytearray(c9), dtype=torch.uint8).cuda()
+    d_p[9 * 48:10 * 48] = torch.frombuffer(bytearray(INF48), dtype=torch.uint8).cuda()
+    # repeated triples: items 20..23 are copies of item 19
+    for i in range(20, 24):
+        d_blobs[i * 131072:(i + 1) * 131072] = d_blobs[19 * 131072:20 * 131072]
+        d_c[i * 48:(i + 1) * 48] = d_c[19 * 48:20 * 48]
+        d_p[i * 48:(i + 1) * 48] = d_p[19 * 48:20 * 48]
+    torch.cuda.synchronize()
+    args = (d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n)
+    assert engine.verify_blob_proof_batch_dev(*args) is True
+    # the sharded entry points (phase 1 complete, then phase 2) take the other order of the same pieces
+    sess, root, err6 = engine.verify_phase1_dev(*args)
+    assert err6[0] == err6[2] == err6[4] == -1
+    part = engine.verify_phase2_dev(sess, root, 0, n)
+    engine.verify_session_destroy(sess)
+    assert engine.verify_batch_finish(part) is True
+    keep = d_p[30 * 48:31 * 48].clone()
+    d_p[30 * 48:31 * 48] = torch.frombuffer(bytearray(INF48), dtype=torch.uint8).cuda()
+    assert engine.verify_blob_proof_batch_dev(*args) is False
+    d_p[30 * 48:31 * 48] = keep
+    assert engine.verify_blob_proof_batch_dev(*args) is True
+    # x = 5 is not on the curve / not in the group: whichever, it is commitment n - 3's error and it wins over nothing else
+    bad = bytes([0x80]) + bytes(46) + bytes([5])
+    d_c[(n - 3) * 48:(n - 2) * 48] = torch.frombuffer(bytearray(bad), dtype=torch.uint8).cuda()
+    with pytest.raises(kateth_amd.KzgError) as err:
+        engine.verify_blob_proof_batch_dev(*args)
+    want = engine.decompress_g1_batch(bad)[1][0]
+    assert want in (4, 5) and err.value.inner.inner.kind == {4: "NotOnCurve", 5: "NotInGroup"}[want]
+    sess, _, err6 = engine.verify_phase1_dev(*args)
+    engine.verify_session_destroy(sess)
+    assert err6[2] == n - 3 and err6[3] == want and err6[0] == -1 and err6[4] == -1
+    # the session pool is reusable after a rejected call
+    d_c[(n - 3) * 48:(n - 2) * 48] = d_c[19 * 48:20 * 48]
+    assert engine.verify_blob_proof_batch_dev(*args) is False  # wrong commitment, well-formed
+    del d_blobs, d_c, d_p
+    torch.cuda.empty_cache()
+
+
+def test_host_buffer_verify_takes_the_fused_path(engine, torch_cuda):
+    """kzg_verify_blob_proof_batch from host buffers (chunked staging, then the interleaved phases): same answers as the device
+    entry point, for a multi-chunk batch and for single items"""
+    torch = torch_cuda
+    n = 1300
+    d_blobs, d_c, d_p = _triples(engine, torch, n, 0xB0B)
+    hb, hc, hp = (t.cpu().numpy().tobytes() for t in (d_blobs, d_c, d_p))
+    assert engine.verify_blob_proof_batch_host(hb, hc, hp, n) is True
+    assert engine.verify_blob_proof_batch_host(hb, hc, hp[48:] + hp[:48], n) is False
+    assert engine.verify_blob_proof(hb[:131072], hc[:48], hp[:48]) is True
+    assert engine.verify_blob_proof(hb[:131072], hc[:48], hp[48:96]) is False
+    assert engine.verify_blob_proof(bytes(131072), INF48, INF48) is True
+
+
+def test_calls_in_flight_on_two_streams_are_bit_exact(engine, torch_cuda, golden):
+    """successive commitment / proof calls take the context's workspace slots in turn: calls enqueued on two streams (and on
+    one) with no synchronisation in between -- 12 of them, alternating sizes so that the slots are regrown under way -- return
+    what one call at a time returns"""
+    torch = torch_cuda
+    n = 600
+    d_blobs, d_c, d_p = _triples(engine, torch, n, golden["seed"])
+    hc, hp = d_c.cpu().numpy().tobytes(), d_p.cpu().numpy().tobytes()
+    for rec in golden["blobs"]:
+        assert hc[48 * rec["index"]:48 * rec["index"] + 48].hex() == rec["commitment"]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    sizes = [600, 37, 512, 600, 1, 300, 600, 64, 600, 129, 600, 600]
+    outs = []
+    for k, m in enumerate(sizes):
+        st = streams[k % 2] if k < 8 else streams[0]
+        o = torch.zeros(m * 48, dtype=torch.uint8, device="cuda")
+        s = torch.full((m,), -7, dtype=torch.int32, device="cuda")
+        with torch.cuda.stream(st):
+            if k % 3 == 2:
+                engine.blob_to_commitment_batch_dev(d_blobs.data_ptr(), m, o.data_ptr(), s.data_ptr(), st.cuda_stream)
+                outs.append((o, s, hc[: 48 * m], k))
+            else:
+                engine.compute_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), m, o.data_ptr(), s.data_ptr(), st.cuda_stream)
+                outs.append((o, s, hp[: 48 * m], k))
+    torch.cuda.synchronize()
+    for o, s, want, k in outs:
+        assert int(s.abs().sum()) == 0, k
+        assert o.cpu().numpy().tobytes() == want, k
+
+
+def test_evaluate_blobs_across_staging_chunks(engine, torch_cuda):
+    """kzg_evaluate_blobs streams the blobs through the staging arena in chunks of 2,048: 2,100 pairs, evaluated at each blob's
+    own Fiat-Shamir challenge, must equal the evaluations batch verification computed for the same blobs (session introspection),
+    and a rejected item beyond the first chunk keeps its place"""
+    torch = torch_cuda
+    n = 2100
+    d_blobs, d_c, d_p = _triples(engine, torch, n, 0xE7A2)
+    sess, _, err6 = engine.verify_phase1_dev(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n)
+    z, y = engine.verify_session_zy(sess, 0, n)
+    engine.verify_session_destroy(sess)
+    hb = d_blobs.cpu().numpy().tobytes()
+    ys, st = engine.evaluate_blobs(hb, z)
+    assert st == [0] * n and ys == y
+    bad = bytearray(hb[: 2060 * 131072])
+    bad[2055 * 131072 + 64:2055 * 131072 + 96] = R.to_bytes(32, "big")
+    ys2, st2 = engine.evaluate_blobs(bytes(bad), z[: 2060 * 32])
+    assert st2[2055] == 2 and sum(1 for v in st2 if v) == 1
+    assert ys2[: 2055 * 32] == y[: 2055 * 32] and ys2[2055 * 32:2056 * 32] == bytes(32) and ys2[2056 * 32:] == y[2056 * 32:2060 * 32]
+
+
+def test_point_decoder_at_batch_size_matches_the_oracle_decisions(engine):
+    """P1::decompress (src/bls.rs:505-531) for 4,096 encodings in one call -- valid points, x with no square root, on-curve points
+    outside the subgroup, x >= p, flag errors, infinity with stray bits: the engine's status equals the oracle's decision for
+    every one, and valid points round-trip through P1.compress"""
+    import random
+
+    import kateth_amd
+    from oracle.pyref import bls
+
+    rng = random.Random(0xDEC0DE)
+    raw = json.load(open(TRUSTED_SETUP))
+    valid = [bytes.fromhex(s[2:]) for s in raw["g1_lagrange"][:512]]
+    items, want = [], []
+    for k in range(4096):
+        kind = k % 8
+        if kind in (0, 1, 2):
+            enc = valid[rng.randrange(512)]
+        elif kind == 3:  # random x: about half have no square root, the rest are almost surely outside the subgroup
+            enc = bytearray(rng.randrange(bls.P).to_bytes(48, "big"))
+            enc[0] = (enc[0] & 0x1F) | 0x80 | (0x20 if rng.random() < 0.5 else 0)
+            enc = bytes(enc)
+        elif kind == 4:  # flip the sign flag of a valid point: still valid (the other root)
+            v = bytearray(valid[rng.randrange(512)])
+            v[0] ^= 0x20
+            enc = bytes(v)
+        elif kind == 5:  # x >= p (p's top byte is 0x1a)
+            enc = bytes([0x9F]) + bytes(rng.randrange(256) for _ in range(47)) if k % 16 else bytes([0x80 | (bls.P >> 376)]) + bls.P.to_bytes(48, "big")[1:]
+        elif kind == 6:  # compression flag clear
+            v = bytearray(valid[rng.randrange(512)])
+            v[0] &= 0x7F
+            enc = bytes(v)
+        else:  # infinity, sometimes with a stray bit
+            enc = bytes([0xC0]) + bytes(46) + bytes([1 if k % 16 == 15 else 0])
+        items.append(enc)
+        try:
+            bls.g1_decompress(enc)
+            want.append(0)
+        except bls.ECGroupError as err:
+            want.append({"InvalidEncoding": 3, "NotOnCurve": 4, "NotInGroup": 5}[err.kind])
+    pts, status = engine.decompress_g1_batch(items)
+    assert status == want
+    assert set(want) >= {0, 3, 4, 5}
+    for k in range(0, 4096, 97):
+        if want[k] == 0:
+            assert pts[k].compress() == items[k]
+    assert isinstance(pts[0], kateth_amd.P1)
+
+
+def test_measurement_aids(engine, torch_cuda):
+    """kzg_microbench_valu_issue and the clock probe return sane figures (bench.py prices SQ_INSTS_VALU with them)"""
+    cyc, ghz = engine.microbench_valu_issue(2, 4000)
+    assert 3.5 < cyc < 6.0 and 0.8 < ghz < 3.0, (cyc, ghz)
+    cyc1, _ = engine.microbench_valu_issue(1, 4000)
+    assert cyc1 > cyc  # a lone wave issues more slowly than two
+    engine.clock_probe_launch(20000)
+    mean, lo, hi = engine.clock_probe_read()
+    assert 0.5 < lo <= mean <= hi < 3.0, (mean, lo, hi)

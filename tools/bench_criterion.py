@@ -39,7 +39,7 @@ def timeit(fn, min_time=0.6, max_reps=200):
 def main():
     window_bits = int(sys.argv[1]) if len(sys.argv) > 1 else 14
     with_cpu = "--no-cpu" not in sys.argv
-    s = kateth_amd.Setup.load_json(SETUP, window_bits=window_bits)
+    s = kateth_amd.Setup.load_json(SETUP, window_bits=window_bits, table_max=True)
     n = SIZES[-1]
     d_blobs = torch.empty(n * 131072, dtype=torch.uint8, device="cuda")
     d_c = torch.empty(n * 48, dtype=torch.uint8, device="cuda")

@@ -1,0 +1,38 @@
+#!/bin/bash
+# Round-4 evidence: rocprofv3 passes over bench.py (one process, --gpus 1; the table bench.py times: window_bits = 0 +
+# KZG_CFG_TABLE_MAX).  Kernel trace + stats for the default run and for each workload alone, then PMC passes -- each in its
+# own run, never combined with tracing -- for the three workloads (SQ counters, FETCH_SIZE, WRITE_SIZE).  Summaries land in
+# gpurun_out/r04/prof/*.json|csv; tools/refresh_profiles_r04.py copies the ones to be judged into profiles/r04/.
+# TRACE_ONLY=1: the four traced runs only.   PMC_ONLY=1: the counter passes only.
+set -o pipefail
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/r04/prof
+mkdir -p $OUT
+run() {  # name, rocprof args..., -- bench args
+  local name=$1; shift
+  echo "[profile] $name" >&2
+  rocprofv3 "$@" > $OUT/$name.log 2>&1 || { tail -5 $OUT/$name.log; exit 1; }
+}
+B="--no-cpu-baseline --no-live-traffic --blocking-setup"
+if [ -z "$PMC_ONLY" ]; then
+run trace_default --kernel-trace --stats --output-format csv -d $OUT/trace_default -- python3 $R/bench.py --steps 10 --warmup 2 $B
+run trace_commit --kernel-trace --stats --output-format csv -d $OUT/trace_commit -- python3 $R/bench.py --steps 10 --warmup 2 --no-extra $B
+run trace_proof --kernel-trace --stats --output-format csv -d $OUT/trace_proof -- python3 $R/bench.py --workload proof --in-flight 1 --steps 5 --warmup 1 $B
+run trace_proof2 --kernel-trace --stats --output-format csv -d $OUT/trace_proof2 -- python3 $R/bench.py --workload proof --in-flight 2 --steps 6 --warmup 2 $B
+run trace_verify --kernel-trace --stats --output-format csv -d $OUT/trace_verify -- python3 $R/bench.py --workload verify --steps 5 --warmup 1 $B
+for w in proof2 verify; do
+  f=$(find $OUT/trace_$w -name "*kernel_trace.csv" | head -1)
+  python3 $R/tools/trace_timeline.py $f 70 > $OUT/timeline_$w.txt
+done
+fi
+[ -n "$TRACE_ONLY" ] && { python3 $R/tools/summarize_profiles.py $OUT; exit 0; }
+SQ="SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU"
+run pmc_verify_sq --pmc $SQ --output-format csv -d $OUT/pmc_verify_sq -- python3 $R/bench.py --workload verify --steps 3 --warmup 1 $B
+run pmc_verify_fetch --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_verify_fetch -- python3 $R/bench.py --workload verify --steps 3 --warmup 1 $B
+run pmc_verify_write --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_verify_write -- python3 $R/bench.py --workload verify --steps 3 --warmup 1 $B
+run pmc_commit_sq --pmc $SQ --output-format csv -d $OUT/pmc_commit_sq -- python3 $R/bench.py --steps 3 --warmup 1 --no-extra $B
+run pmc_commit_fetch --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_commit_fetch -- python3 $R/bench.py --steps 3 --warmup 1 --no-extra $B
+run pmc_commit_write --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_commit_write -- python3 $R/bench.py --steps 3 --warmup 1 --no-extra $B
+run pmc_proof_sq --pmc $SQ --output-format csv -d $OUT/pmc_proof_sq -- python3 $R/bench.py --workload proof --in-flight 1 --steps 3 --warmup 1 $B
+python3 $R/tools/summarize_profiles.py $OUT

@@ -13,7 +13,7 @@ import kateth_amd  # noqa: E402
 
 c = int(sys.argv[1]) if len(sys.argv) > 1 else 22
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-s = kateth_amd.Setup.load_json(os.path.join(ROOT, "tests", "golden", "trusted_setup_4096.json"), window_bits=c)
+s = kateth_amd.Setup.load_json(os.path.join(ROOT, "tests", "golden", "trusted_setup_4096.json"), window_bits=c, table_max=True)
 d_blob = torch.empty(131072, dtype=torch.uint8, device="cuda")
 d_c = torch.empty(48, dtype=torch.uint8, device="cuda")
 d_p = torch.empty(48, dtype=torch.uint8, device="cuda")
