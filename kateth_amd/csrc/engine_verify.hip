@@ -199,6 +199,7 @@ static MsmVarLayout msm_var_layout(const kzg_ctx* ctx, uint64_t nterms) {
 struct MsmVarJob {
   MsmVarLayout L{};
   uint64_t nterms = 0;
+  bool trace = false;  // KATETH_AMD_TRACE (read at context creation)
   VarGeom g{};
   uint32_t nout = 0;  // points read back: W window sums, or W*c bit sums on the flat path
   uint8_t* buf = nullptr;
@@ -219,6 +220,7 @@ static int32_t msm_var_sort(const kzg_ctx* ctx, MsmVarJob& job, const uint8_t* d
   job.active = false;
   job.st = st;
   job.nterms = nterms;
+  job.trace = ctx->knobs.trace;
   if (nterms == 0) return 0;
   job.L = msm_var_layout(ctx, nterms);
   const MsmVarLayout& L = job.L;
@@ -296,10 +298,13 @@ static int32_t msm_var_finish(MsmVarJob& job, g1_xyzz& result) {
   xyzz_set_inf(result);
   if (!job.active) return 0;
   int32_t rc = 0;
+  TraceTimer tt(job.trace, job.nterms & 1 ? "msm_var_finish (B)" : "msm_var_finish (A)");
   if (hipMemcpyAsync(job.win.data(), job.d_win, (size_t)job.nout * sizeof(g1_xyzz), hipMemcpyDeviceToHost, job.st) != hipSuccess ||
       hipStreamSynchronize(job.st) != hipSuccess)
     rc = fail(KZG_FAIL_HIP, "variable-base MSM read-back failed");
+  tt.mark("kernels done + read-back");
   if (rc == 0) host_horner(result, job.win, job.g);
+  tt.mark("horner");
   if (job.owns_buf) (void)hipFree(job.buf);
   job.buf = nullptr;
   job.active = false;
@@ -550,12 +555,13 @@ static int32_t p1_root(kzg_verify_session* s, uint8_t* out_root32) {
   sha256_bytes(out_root32, nb.data(), nb.size());
   return 0;
 }
-// (c) join of the decode stream, read-back of the statuses, first-error scan
+// (c) read-back of the statuses and first-error scan.  The copy rides on the DECODER's stream (right behind the decoder; the
+//     blob statuses were written by the evaluation kernel, which ended before the root was read), not on the caller's: there it
+//     would queue up behind the bucket kernels of phase 2 and the host would scan 3n statuses after them instead of beside them.
 static int32_t p1_status(kzg_verify_session* s, int32_t* err6) {
   const uint64_t n = s->n;
-  hipStream_t st = s->st;
-  if (hipStreamWaitEvent(st, s->ev_join, 0) != hipSuccess ||
-      hipMemcpyAsync(s->h_stat, s->stat, 3 * n * 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipEventRecord(s->ev_stat, st) != hipSuccess ||
+  if (hipStreamWaitEvent(s->side, s->ev_join, 0) != hipSuccess ||
+      hipMemcpyAsync(s->h_stat, s->stat, 3 * n * 4, hipMemcpyDeviceToHost, s->side) != hipSuccess || hipEventRecord(s->ev_stat, s->side) != hipSuccess ||
       hipEventSynchronize(s->ev_stat) != hipSuccess)
     return fail(KZG_FAIL_HIP, "verify phase 1 status readback failed");
   scan_first_error(s->h_stat, n, &err6[0], &err6[1]);
@@ -990,13 +996,56 @@ static int32_t p2_finish(kzg_verify_session* s, Phase2& p2, uint8_t* out192) {
     rca = msm_var_finish(p2.ja, Ax);
     rcb = msm_var_finish(p2.jb, Bx);
   }
+  TraceTimer tt(ctx->knobs.trace, "phase2 finish");
   (void)hipStreamSynchronize(s->st);
+  tt.mark("stream drained");
   if (rcb || rca) return rcb ? rcb : rca;
   host::g1_host_affine A, B;
   host_affine_from_xyzz(A, Ax);
   host_affine_from_xyzz(B, Bx);
   host_affine_to_be96(out192, A);
   host_affine_to_be96(out192 + 96, B);
+  tt.mark("two inversions + encoding");
+  return 0;
+}
+
+// (d') the single-context call's ending: each host thread takes ONE lincomb from the read-back to its Miller loop -- Horner over
+//      the bit sums, to affine, f_A = f_{|z|,[tau]_2}(-A) or f_B = f_{|z|,G2}(B) -- and the caller multiplies the two and runs the
+//      final exponentiation.  e(-A,[tau]_2) e(B,G2) = 1 exactly as verify_pairings_fixed checks it (the product of the two loops
+//      is the shared-squaring loop's value: (f_A^2 l_A)(f_B^2 l_B) = (f_A f_B)^2 l_A l_B), 0.13 ms sooner: the loops run side by side.
+static int32_t p2_finish_and_pair(kzg_verify_session* s, Phase2& p2, int32_t* ok) {
+  const kzg_ctx* ctx = s->ctx;
+  *ok = 0;
+  if (!(p2.ja.active && p2.jb.active && (p2.ja.nout + p2.jb.nout) >= 64)) {  // a handful of terms: the plain path
+    uint8_t partial[192];
+    int32_t rc = p2_finish(s, p2, partial);
+    return rc ? rc : kzg_verify_batch_finish(ctx, partial, 1, ok);
+  }
+  TraceTimer tt(ctx->knobs.trace, "phase2 finish + pairing");
+  host::fp12 fa = host::f12_one(), fb = host::f12_one();
+  int32_t rca = 0, rcb = 0;
+  const int device = ctx->device;
+  auto one = [&](MsmVarJob& job, const host::miller_lines& lines, bool negate, host::fp12& f) -> int32_t {
+    g1_xyzz sum;
+    int32_t rc = msm_var_finish(job, sum);
+    if (rc) return rc;
+    host::g1_host_affine p;
+    host_affine_from_xyzz(p, sum);
+    if (negate && !p.inf) fp_neg(p.y, p.y);
+    const host::miller_lines* ls[1] = {&lines};
+    f = host::multi_miller(&p, ls, 1);
+    return 0;
+  };
+  (void)run_on_helpers(2, [&](uint32_t k) -> int32_t {
+    if (k == 0) return rcb = one(p2.jb, ctx->pairing->lines_g2, false, fb);
+    (void)hipSetDevice(device);
+    return rca = one(p2.ja, ctx->pairing->lines_tau, true, fa);
+  });
+  (void)hipStreamSynchronize(s->st);
+  tt.mark("read-backs, horner, miller loops (two threads)");
+  if (rcb || rca) return rcb ? rcb : rca;
+  *ok = host::final_exp_is_one(host::f12_mul(fa, fb), ctx->pairing->fc) ? 1 : 0;
+  tt.mark("final exponentiation");
   return 0;
 }
 
@@ -1033,7 +1082,7 @@ extern "C" int32_t kzg_verify_phase2_dev(kzg_verify_session* s, const uint8_t* r
 static int32_t verify_fused(kzg_verify_session* s, const uint8_t* com, const uint8_t* prf, int32_t* ok, const uint8_t* root_done = nullptr) {
   const kzg_ctx* ctx = s->ctx;
   TraceTimer tt(ctx->knobs.trace, "verify (fused phases)");
-  uint8_t root[32], partial[192];
+  uint8_t root[32];
   int32_t err6[6];
   for (int k = 0; k < 6; k++) err6[k] = (k % 2 == 0) ? -1 : 0;
   Phase2 p2;
@@ -1052,8 +1101,8 @@ static int32_t verify_fused(kzg_verify_session* s, const uint8_t* com, const uin
   tt.mark("decoder done, statuses");
   int32_t code = 0;
   if (rc == 0) code = first_error_code(err6);
-  if (rc == 0 && code == 0) rc = p2_finish(s, p2, partial);
-  tt.mark("lincombs + host horner");
+  if (rc == 0 && code == 0) rc = p2_finish_and_pair(s, p2, ok);
+  tt.mark("lincombs + host horner + pairing");
   if (rc || code) {  // drain what is enqueued before the session goes back to the pool
     (void)hipStreamSynchronize(s->st);
     (void)hipStreamSynchronize(s->aux);
@@ -1061,7 +1110,7 @@ static int32_t verify_fused(kzg_verify_session* s, const uint8_t* com, const uin
     if (p2.jb.owns_buf && p2.jb.buf) (void)hipFree(p2.jb.buf);
     return rc ? rc : code;
   }
-  return kzg_verify_batch_finish(ctx, partial, 1, ok);
+  return 0;
 }
 
 // introspection: challenge z_i and evaluation y_i of items [first, first + count) of a session after phase 1
