@@ -113,18 +113,19 @@ def memory_plan(workload, n, window_bits, total_bytes, table_max=True):
     proof: + 128 KiB of quotient scalars per blob of a chunk; verify: a pooled session of ~800 B per item)"""
     cls, groups, table = table_plan(window_bits, total_bytes, table_max)
     chunk = min(n, 16384)
+    slots = 2  # KZG_WS_SLOTS: successive calls take two workspaces in turn (calls in flight on two streams), and they grow together
     msm_ws = chunk * (BYTES_PER_BLOB + 65 * 192 + 192)
     plan = {"table_class": cls, "plane_groups": groups, "table": table, "table_build_scratch_transient": 13 * GIB if cls == 22 else 1.7 * GIB,
             "blobs": n * BYTES_PER_BLOB, "results_and_status": n * (48 + 4)}
     if workload == "commit":
-        plan["workspace"] = msm_ws
+        plan["workspace"] = slots * msm_ws
     elif workload == "proof":
         plan["commitments"] = n * 48
-        plan["workspace"] = msm_ws + chunk * (BYTES_PER_BLOB + 512)
+        plan["workspace"] = slots * (msm_ws + 2 * chunk * (BYTES_PER_BLOB + 512))
     else:
         plan["commitments_and_proofs"] = n * 96
         plan["workspace"] = n * 800 + (1 << 20)
-        plan["setup_phase_peak"] = msm_ws + chunk * (BYTES_PER_BLOB + 512)  # the triples are produced by commit + prove first
+        plan["setup_phase_peak"] = slots * (msm_ws + 2 * chunk * (BYTES_PER_BLOB + 512))  # the triples are produced by commit + prove first
     resident = sum(v for k, v in plan.items() if k not in ("table_class", "plane_groups", "table_build_scratch_transient"))
     plan["resident_total"] = resident
     plan["peak_total"] = max(resident, plan["table"] + plan["table_build_scratch_transient"])

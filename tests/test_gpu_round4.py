@@ -142,9 +142,9 @@ def test_calls_in_flight_on_two_streams_are_bit_exact(engine, torch_cuda, golden
     outs = []
     for k, m in enumerate(sizes):
         st = streams[k % 2] if k < 8 else streams[0]
-        o = torch.zeros(m * 48, dtype=torch.uint8, device="cuda")
-        s = torch.full((m,), -7, dtype=torch.int32, device="cuda")
-        with torch.cuda.stream(st):
+        with torch.cuda.stream(st):  # the fills run on the call's own stream (torch's pool streams do not order against its default stream)
+            o = torch.zeros(m * 48, dtype=torch.uint8, device="cuda")
+            s = torch.full((m,), -7, dtype=torch.int32, device="cuda")
             if k % 3 == 2:
                 engine.blob_to_commitment_batch_dev(d_blobs.data_ptr(), m, o.data_ptr(), s.data_ptr(), st.cuda_stream)
                 outs.append((o, s, hc[: 48 * m], k))
