@@ -10,54 +10,20 @@
 // the partials and runs the single pairing check -- the same phase1 / roots / phase2 / finish protocol that
 // kateth_amd/dist.py drives across processes with RCCL, here inside one process.
 #include "engine_internal.hpp"
+#include "multi_split.hpp"
+
+using kzg::multi::Share;
+using kzg::multi::merged_first_error;
 
 namespace {
 
-struct Share {
-  uint32_t member;
-  uint64_t first, count;
-};
-
 inline const kzg_ctx* member_of(const kzg_ctx* ctx, uint32_t k) { return k == 0 ? ctx : ctx->peers[k - 1]; }
 
-// Contiguous ranges of ceil(n / members) items in member order -- kateth_amd/dist.py shard_range.  A call with fewer items than
-// members (the single-item methods of the reference's API, made from many host threads at once) starts at a rotating member,
-// one item each, so that concurrent small calls spread over the devices.
+// the shares of a call over this group's members (multi_split.hpp); calls smaller than the group start at a rotating member
 std::vector<Share> shares_of(const kzg_ctx* ctx, uint64_t n) {
   const uint32_t S = 1u + (uint32_t)ctx->peers.size();
-  std::vector<Share> out;
-  if (n == 0) return out;
-  if (n < S) {
-    const uint32_t start = ctx->rr.fetch_add((uint32_t)n, std::memory_order_relaxed);
-    for (uint64_t i = 0; i < n; i++) out.push_back(Share{(uint32_t)((start + i) % S), i, 1});
-    return out;
-  }
-  const uint64_t per = (n + S - 1) / S;
-  for (uint32_t k = 0; k < S && (uint64_t)k * per < n; k++) {
-    const uint64_t first = (uint64_t)k * per;
-    out.push_back(Share{k, first, n - first < per ? n - first : per});
-  }
-  return out;
-}
-
-// first-error-wins order of the reference (src/kzg/setup.rs:259-271: every blob is parsed before any commitment, every
-// commitment before any proof) from the members' records -- kateth_amd/dist.py merge_first_error
-int32_t merged_first_error(const std::vector<Share>& shares, const std::vector<int32_t>& err6) {
-  for (int kind = 0; kind < 6; kind += 2) {
-    int32_t code = 0;
-    uint64_t best = ~(uint64_t)0;
-    for (size_t j = 0; j < shares.size(); j++) {
-      const int32_t local = err6[6 * j + kind];
-      if (local < 0) continue;
-      const uint64_t g = shares[j].first + (uint64_t)local;
-      if (g < best) {
-        best = g;
-        code = err6[6 * j + kind + 1];
-      }
-    }
-    if (code) return code;
-  }
-  return 0;
+  const uint32_t rotate = (n && n < S) ? ctx->rr.fetch_add((uint32_t)n, std::memory_order_relaxed) : 0u;
+  return kzg::multi::shares_of(n, S, rotate);
 }
 
 }  // namespace
@@ -167,7 +133,7 @@ int32_t multi_verify_batch(const kzg_ctx* ctx, const uint8_t* blobs, const uint8
     error_publish(keep);
     return rc;
   }
-  const int32_t code = merged_first_error(shares, err6);
+  const int32_t code = merged_first_error(shares, err6.data());
   if (code) {
     release();
     return code;

@@ -12,6 +12,7 @@
 #include "../../kateth_amd/csrc/g1_decode28.cuh"
 #include "../../kateth_amd/csrc/modinv30.cuh"
 #include "../../kateth_amd/csrc/sha256.cuh"
+#include "../../kateth_amd/csrc/multi_split.hpp"
 
 using namespace kzg;
 
@@ -49,6 +50,20 @@ static void binop(int op, uint8_t* out, const uint8_t* a, const uint8_t* b) {
 }
 
 extern "C" {
+// group contexts: the split of a batch over the members and the merge of their first-error records (multi_split.hpp)
+// out = (member, first, count) triples; returns the number of shares
+int hm_multi_shares(uint64_t n, uint32_t members, uint32_t rotate, uint64_t* out, int cap) {
+  const std::vector<kzg::multi::Share> sh = kzg::multi::shares_of(n, members, rotate);
+  for (size_t j = 0; j < sh.size() && (int)j < cap; j++) {
+    out[3 * j] = sh[j].member;
+    out[3 * j + 1] = sh[j].first;
+    out[3 * j + 2] = sh[j].count;
+  }
+  return (int)sh.size();
+}
+int32_t hm_multi_first_error(uint64_t n, uint32_t members, uint32_t rotate, const int32_t* err6) {
+  return kzg::multi::merged_first_error(kzg::multi::shares_of(n, members, rotate), err6);
+}
 void hm_fp_op(int op, uint8_t* out48, const uint8_t* a48, const uint8_t* b48) {
   if (op == 5) {
     fp_t x, r;
