@@ -14,10 +14,12 @@
  * Plain C: pointers and sizes only.  Nothing unwinds across this boundary.
  * A kzg_ctx is immutable after creation and may be used from several host
  * threads at once, matching `&self` + `Arc<Setup>` in the reference
- * (src/kzg/setup.rs:323): commitment and proof calls serialise on an internal
- * lock around the shared GPU workspace; every verification call takes its own
- * pooled session (device scratch + stream) and runs beside the others; the
- * host-buffer verification calls additionally serialise on the staging arena.
+ * (src/kzg/setup.rs:323): commitment and proof calls hold an internal lock only
+ * while they enqueue and take the context's two GPU workspaces in turn, so calls
+ * enqueued on two streams run side by side; every verification call takes its
+ * own pooled session (device scratch + streams) and runs beside the others; the
+ * host-buffer calls additionally serialise on the staging arena.  A context
+ * created with kzg_config.devices / ndev spans several GPUs (below).
  *
  * Return value of every call: 0 on success, a positive KZG_ERR_* code when an
  * input is rejected the way the reference returns Err, a negative KZG_FAIL_*
