@@ -594,6 +594,7 @@ static int32_t ctx_create_with(const uint8_t* g1_lagrange, const uint8_t* g2_mon
   if (rc != 0) {
     const ErrorSnapshot keep = error_snapshot();
     kzg_ctx_destroy(ctx);
+    (void)hipGetLastError();  // a failed allocation leaves its code behind: the NEXT call's launch check must not trip over it
     error_publish(keep);
     return rc;
   }
@@ -625,6 +626,7 @@ static void build_thread_main(kzg_ctx* ctx, std::vector<TableChoice> ladder, boo
     }
   }
   if (st) (void)hipStreamDestroy(st);
+  if (rc) (void)hipGetLastError();  // (the last-error slot is per host thread; cleared all the same)
   {
     std::lock_guard<std::mutex> guard(ctx->build_mu);
     ctx->build_rc = rc;

@@ -421,3 +421,51 @@ def test_background_table_build_swaps_without_changing_results(triples, golden):
     s = kateth_amd.Setup.load_json(TRUSTED_SETUP, window_bits=8, build_async=True)
     assert s.ready and s.window_bits == 8
     s.close()
+
+
+def test_background_build_failure_leaves_a_working_context(triples, torch_cuda):
+    """an explicit class-22 table that cannot be allocated (the card is filled up to ~30 GiB free): with KZG_CFG_BUILD_ASYNC
+    creation still succeeds on the first-use table, kzg_ctx_wait_ready reports the failure, and the context keeps answering
+    correctly on the table it has; without the flag the same request fails at creation"""
+    import kateth_amd
+
+    torch = torch_cuda
+    hb, hc, hp, n = triples
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free = torch.cuda.mem_get_info()[0]
+    if free < 40 << 30:
+        pytest.skip("needs a mostly empty card")
+    ballast = torch.empty(free - (30 << 30), dtype=torch.uint8, device="cuda")
+    try:
+        with pytest.raises(kateth_amd.kzg.EngineError):
+            kateth_amd.Setup.load_json(TRUSTED_SETUP, window_bits=22, plane_groups=4)
+        s = kateth_amd.Setup.load_json(TRUSTED_SETUP, window_bits=22, plane_groups=4, build_async=True)
+        try:
+            assert s.blob_to_commitment_batch(hb[: 4 * 131072]) == (hc[: 4 * 48], [0] * 4)
+            with pytest.raises(kateth_amd.kzg.EngineError):
+                s.wait_ready()
+            assert s.ready and s.window_bits == 8
+            assert s.compute_blob_proof_batch(hb[: 4 * 131072], hc[: 4 * 48]) == (hp[: 4 * 48], [0] * 4)
+        finally:
+            s.close()
+    finally:
+        del ballast
+        torch.cuda.empty_cache()
+
+
+def test_group_with_background_build(triples):
+    """both flags together: a group whose members come up on their first-use tables and swap to class 16 behind the calls"""
+    import kateth_amd
+
+    hb, hc, hp, n = triples
+    g = kateth_amd.Setup.load_json(TRUSTED_SETUP, window_bits=16, devices=[0, 0], build_async=True)
+    try:
+        assert g.members == 2
+        assert g.blob_to_commitment_batch(hb) == (hc, [0] * n)
+        g.wait_ready()
+        assert g.ready and g.window_bits == 16 and g.member(1).window_bits == 16
+        assert g.compute_blob_proof_batch(hb, hc) == (hp, [0] * n)
+        assert g.verify_blob_proof_batch_host(hb, hc, hp, n) is True
+    finally:
+        g.close()
