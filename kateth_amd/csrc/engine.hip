@@ -25,6 +25,9 @@ extern "C" int32_t kzg_last_error_code(void) { return g_last_detail; }
 int32_t fail(int32_t code, const std::string& msg) {
   g_last_error = msg;
   g_last_detail = 0;
+  // the runtime keeps the code of a failed call (an out-of-memory allocation, say) until somebody asks for it: reported here, it
+  // must not be found again by the launch check of this thread's NEXT, unrelated call
+  if (code == KZG_FAIL_HIP) (void)hipGetLastError();
   return code;
 }
 // a failure caused by a rejected input: `detail` is the KZG_ERR_* code of that input

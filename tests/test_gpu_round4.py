@@ -234,3 +234,44 @@ def test_measurement_aids(engine, torch_cuda):
     engine.clock_probe_launch(20000)
     mean, lo, hi = engine.clock_probe_read()
     assert 0.5 < lo <= mean <= hi < 3.0, (mean, lo, hi)
+
+
+def test_out_of_memory_at_call_time_is_reported_and_recoverable(torch_cuda, golden):
+    """a call whose workspace cannot be allocated (the card is filled up first) fails with KZG_FAIL_HIP -- and the failure does not
+    leak into the next call: a small call on the same thread, with the card still full, succeeds (the runtime's last-error slot is
+    cleared when a failure is reported), and once memory is back the large call does too"""
+    import kateth_amd
+
+    torch = torch_cuda
+    s = kateth_amd.Setup.load_json(TRUSTED_SETUP, window_bits=8)  # a context of its own: its workspace has not grown yet
+    try:
+        n = 8192
+        d_blobs = torch.empty(n * 131072, dtype=torch.uint8, device="cuda")
+        s.synth_blobs_dev(golden["seed"], 0, n, d_blobs.data_ptr())
+        d_c = torch.zeros(n * 48, dtype=torch.uint8, device="cuda")
+        d_st = torch.zeros(n, dtype=torch.int32, device="cuda")
+        s.blob_to_commitment_batch_dev(d_blobs.data_ptr(), 2, d_c.data_ptr(), d_st.data_ptr())  # the workspace of a 2-blob call exists now
+        torch.cuda.synchronize()
+        small = d_c[:96].cpu().numpy().tobytes()
+        assert small[:48].hex() == golden["blobs"][0]["commitment"]
+        torch.cuda.empty_cache()
+        free = torch.cuda.mem_get_info()[0]
+        ballast = torch.empty(free - (600 << 20), dtype=torch.uint8, device="cuda")  # 0.6 GiB left: two 1.1-GiB workspaces cannot grow
+        try:
+            with pytest.raises(kateth_amd.kzg.EngineError, match="out of memory|hipMalloc|HIP"):
+                s.blob_to_commitment_batch_dev(d_blobs.data_ptr(), n, d_c.data_ptr(), d_st.data_ptr())
+            d_c[:96] = 0
+            s.blob_to_commitment_batch_dev(d_blobs.data_ptr(), 2, d_c.data_ptr(), d_st.data_ptr())
+            torch.cuda.synchronize()
+            assert d_c[:96].cpu().numpy().tobytes() == small and int(d_st[:2].abs().sum()) == 0
+        finally:
+            del ballast
+            torch.cuda.empty_cache()
+        s.blob_to_commitment_batch_dev(d_blobs.data_ptr(), n, d_c.data_ptr(), d_st.data_ptr())
+        torch.cuda.synchronize()
+        assert int(d_st.abs().sum()) == 0 and d_c[:96].cpu().numpy().tobytes() == small
+        for rec in golden["blobs"]:
+            assert d_c[48 * rec["index"]:48 * rec["index"] + 48].cpu().numpy().tobytes().hex() == rec["commitment"]
+    finally:
+        s.close()
+        torch.cuda.empty_cache()
