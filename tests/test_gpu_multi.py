@@ -267,6 +267,17 @@ def test_group_creation_errors():
 
     with pytest.raises(kateth_amd.kzg.EngineError, match="out of range"):
         kateth_amd.Setup.load_json(TRUSTED_SETUP, window_bits=8, devices=[0, 99])
+    # malformed configuration structs are refused, not guessed at: an unknown flag bit, a reserved field in use, a device list
+    # announced but not given
+    lib = kzg.load_library()
+    raw0 = json.load(open(TRUSTED_SETUP))
+    g1b = b"".join(bytes.fromhex(x[2:]) for x in raw0["g1_lagrange"])
+    g2b = b"".join(bytes.fromhex(x[2:]) for x in raw0["g2_monomial"])
+    for cfg, what in ((kzg._Config(0, 8, 0x40, 0, 0, None, 0, 0), b"flags"), (kzg._Config(0, 8, 0, 0, 0, None, 0, 7), b"reserved"),
+                      (kzg._Config(0, 8, 0, 0, 0, None, 2, 0), b"devices"), (kzg._Config(0, 8, 0, 3, 0, None, 0, 0), b"plane groups")):
+        out = ctypes.c_void_p()
+        assert lib.kzg_ctx_create(g1b, g2b, ctypes.byref(cfg), ctypes.byref(out)) == -1 and not out.value  # KZG_FAIL_ARGUMENT
+        assert what in lib.kzg_last_error()
     # a rejected setup point is reported like the single-device creation reports it (LoadSetupError::Bls, src/kzg/setup.rs:59-64)
     raw = json.load(open(TRUSTED_SETUP))
     g1 = [bytes.fromhex(s[2:]) for s in raw["g1_lagrange"]]
