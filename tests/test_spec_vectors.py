@@ -145,6 +145,17 @@ def gpu_engine():
     s.close()
 
 
+@pytest.fixture(scope="module")
+def gpu_group():
+    """what the Rust shim's load_json creates on a node with several GPUs: a GROUP context -- here
+    two members on the one card -- on a first-use table with the configured one built in the background"""
+    import kateth_amd
+
+    s = kateth_amd.Setup.load_json(TRUSTED_SETUP, window_bits=16, devices=[0, 0], build_async=True)
+    yield s
+    s.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("handler", HANDLERS)
 @pytest.mark.parametrize("which", ["official", "generated"])
@@ -152,6 +163,17 @@ def test_spec_vectors_gpu(handler, which, gpu_engine):
     if not cases(handler, which):
         pytest.skip("consensus-spec-tests vectors not present; set KZG_SPEC_TESTS")
     assert _check(gpu_engine, handler, which) >= 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("handler", HANDLERS)
+@pytest.mark.parametrize("which", ["official", "generated"])
+def test_spec_vectors_gpu_group_context(handler, which, gpu_group):
+    """the same vectors through the drop-in's context shape: every batch sharded over the members, single items on a rotating
+    member, the tables swapped under way"""
+    if not cases(handler, which):
+        pytest.skip("consensus-spec-tests vectors not present; set KZG_SPEC_TESTS")
+    assert _check(gpu_group, handler, which) >= 1
 
 
 def test_generated_set_covers_every_handler_and_null_convention():
