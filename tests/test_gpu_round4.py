@@ -255,8 +255,20 @@ def test_out_of_memory_at_call_time_is_reported_and_recoverable(torch_cuda, gold
         small = d_c[:96].cpu().numpy().tobytes()
         assert small[:48].hex() == golden["blobs"][0]["commitment"]
         torch.cuda.empty_cache()
-        free = torch.cuda.mem_get_info()[0]
-        ballast = torch.empty(free - (600 << 20), dtype=torch.uint8, device="cuda")  # 0.6 GiB left: two 1.1-GiB workspaces cannot grow
+        # the ballast comes straight from hipMalloc: torch's caching allocator would serve part of it from segments it already
+        # holds (in a long test process it does) and leave the DEVICE with more free memory than asked for
+        import ctypes
+
+        hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+        ballast = []
+        for _ in range(8):  # until 0.6 GiB are left (the runtime's "free" figure moves by more than one allocation's size): two 1.1-GiB workspaces cannot grow
+            free = torch.cuda.mem_get_info()[0]
+            if free < 700 << 20:
+                break
+            p = ctypes.c_void_p()
+            assert hip.hipMalloc(ctypes.byref(p), ctypes.c_size_t(free - (600 << 20))) == 0
+            ballast.append(p)
+        assert torch.cuda.mem_get_info()[0] < 700 << 20
         try:
             with pytest.raises(kateth_amd.kzg.EngineError, match="out of memory|hipMalloc|HIP"):
                 s.blob_to_commitment_batch_dev(d_blobs.data_ptr(), n, d_c.data_ptr(), d_st.data_ptr())
@@ -265,8 +277,8 @@ def test_out_of_memory_at_call_time_is_reported_and_recoverable(torch_cuda, gold
             torch.cuda.synchronize()
             assert d_c[:96].cpu().numpy().tobytes() == small and int(d_st[:2].abs().sum()) == 0
         finally:
-            del ballast
-            torch.cuda.empty_cache()
+            for p in ballast:
+                assert hip.hipFree(p) == 0
         s.blob_to_commitment_batch_dev(d_blobs.data_ptr(), n, d_c.data_ptr(), d_st.data_ptr())
         torch.cuda.synchronize()
         assert int(d_st.abs().sum()) == 0 and d_c[:96].cpu().numpy().tobytes() == small
