@@ -238,6 +238,7 @@ EnvKnobs read_env_knobs() {
     if (const char* e = getenv("KATETH_AMD_EVAL_GROUP")) k.eval_group = atoi(e);
     k.verify_serial = getenv("KATETH_AMD_VERIFY_SERIAL") != nullptr;
     if (const char* e = getenv("KATETH_AMD_VAR_MSM")) k.var_msm_classic = std::string(e) == "classic";
+    if (const char* e = getenv("KATETH_AMD_VERIFY_STREAMS")) k.verify_streams = (uint32_t)atoi(e) <= (uint32_t)KZG_STAGE_STREAMS ? (uint32_t)atoi(e) : 0u;
     if (const char* e = getenv("KATETH_AMD_VERIFY_CHUNK")) k.verify_chunk = (uint64_t)atoll(e) > 0 ? (uint64_t)atoll(e) : 0;
     k.comb_full_wave = getenv("KATETH_AMD_COMB_FULL_WAVE") != nullptr;
     if (const char* e = getenv("KATETH_AMD_LAT_TABLE")) k.lat_table = atoi(e) != 0;

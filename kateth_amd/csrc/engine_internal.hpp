@@ -86,6 +86,7 @@ struct EnvKnobs {
   bool verify_serial = false;    // KATETH_AMD_VERIFY_SERIAL
   bool var_msm_classic = false;  // KATETH_AMD_VAR_MSM=classic: c = 8 with per-bucket partials for every batch size (cross-check of the flat path)
   uint64_t verify_chunk = 0;     // KATETH_AMD_VERIFY_CHUNK: blobs per host-buffer staging chunk (0 = default)
+  uint32_t verify_streams = 0;   // KATETH_AMD_VERIFY_STREAMS: compute streams the host-buffer verification rotates its chunks over (1..4; 0 = default)
   uint32_t comb_fair = 20;       // KATETH_AMD_COMB_FAIR=s: the MSM waves of a SIMD trade issue priority every 2^s cycles; 0 = hardware default (measurement aid)
   bool lat_table = true;         // KATETH_AMD_LAT_TABLE=0: no latency comb beside a class-22 table (measurement aid)
   bool comb_full_wave = false;   // KATETH_AMD_COMB_FULL_WAVE: never use the comb's two-blobs-per-wave mode (measurement aid)

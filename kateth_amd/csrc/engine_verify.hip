@@ -702,6 +702,12 @@ int32_t verify_phase1_host(const kzg_ctx* ctx, const uint8_t* blobs, const uint8
   }
   const uint64_t nchunks = (n + chunk - 1) / chunk;
   const uint64_t slots = nchunks < KZG_STAGE_SLOTS ? nchunks : KZG_STAGE_SLOTS;
+  // Compute streams the chunks rotate over: TWO.  With a hardware queue per stream (GPU_MAX_HW_QUEUES = 8) four independent
+  // chunk streams put four chunks' hash and evaluation kernels on the chip at once and the LAST chunk's latency-bound hash --
+  // the call's critical path: it cannot start before its copy ends -- shares SIMDs with its predecessors' waves: 16.5 instead of
+  // 15.0 ms per 4,096 triples (two or three streams: 15.0; one: 18.9; at 16,384 triples all the same, 44.2).  Round 3's four
+  // streams only did well because the runtime's default of four hardware queues folded them onto fewer.
+  const uint64_t nstreams = ctx->knobs.verify_streams ? ctx->knobs.verify_streams : 2;
   const size_t slot_bytes = (size_t)chunk * KZG_BYTES_PER_BLOB;
   do {
     rc = stage_reserve(ctx, slots * slot_bytes, 0);
@@ -731,12 +737,12 @@ int32_t verify_phase1_host(const kzg_ctx* ctx, const uint8_t* blobs, const uint8
                            s->inf);
       }
       (void)hipEventRecord(s->ev_join, s->side);
-      for (int r = 0; r < KZG_STAGE_STREAMS; r++) (void)hipStreamWaitEvent(ctx->stage_streams[r], s->ev_fork, 0);  // session initialised, points resident
+      for (int r = 0; r < KZG_STAGE_STREAMS; r++) (void)hipStreamWaitEvent(ctx->stage_streams[r], s->ev_fork, 0);  // session initialised, points resident (all of them: the join below is over all)
       for (uint64_t k = 0; k < nchunks && rc == 0; k++) {
         const uint64_t slot = k % slots;
         const uint64_t base = k * chunk;
         const uint64_t m = (n - base < chunk) ? (n - base) : chunk;
-        hipStream_t comp = ctx->stage_streams[k % KZG_STAGE_STREAMS];
+        hipStream_t comp = ctx->stage_streams[k % nstreams];
         uint8_t* d_chunk = ctx->stage + slot * slot_bytes;
         if (k >= slots) (void)hipStreamWaitEvent(ctx->stage_copy_stream, ctx->stage_done[slot], 0);  // the chunk that used this slot has been consumed
         if (hipMemcpyAsync(d_chunk, blobs + base * (size_t)KZG_BYTES_PER_BLOB, m * (size_t)KZG_BYTES_PER_BLOB, hipMemcpyHostToDevice,
