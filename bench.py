@@ -68,8 +68,8 @@ def parse():
                          "16 -> 12.9 GB, 65,536 additions; 8 -> 100 MB, 131,072 additions")
     ap.add_argument("--default-budget", action="store_true", help="do NOT pass KZG_CFG_TABLE_MAX: the library's default budget (100 GiB -> the 96-GiB table, G = 4) "
                     "instead of the largest table the device has room for (192 GiB, G = 8)")
-    ap.add_argument("--in-flight", type=int, default=0, help="calls kept in flight: step i is enqueued on stream i mod F with result buffers of its own (0 = default: 2 for "
-                    "--workload proof -- one call's hash + quotient kernels run in the shadow of the other's MSM --, 1 otherwise; the timed region is still K steps "
+    ap.add_argument("--in-flight", type=int, default=0, help="calls kept in flight: step i is enqueued on stream i mod F with result buffers of its own (0 = default: 3 for "
+                    "--workload proof -- a call's hash + quotient kernels run in the shadow of the others' MSMs; the context has three workspaces --, 1 otherwise; the timed region is still K steps "
                     "between two full synchronisations)")
     ap.add_argument("--blocking-setup", action="store_true", help="create the context without KZG_CFG_BUILD_ASYNC (kzg_ctx_create returns when the full table stands)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL, the measured path) or gloo (rehearsal: ranks may share one card, gathers go through the host)")
@@ -113,7 +113,7 @@ def memory_plan(workload, n, window_bits, total_bytes, table_max=True):
     proof: + 128 KiB of quotient scalars per blob of a chunk; verify: a pooled session of ~800 B per item)"""
     cls, groups, table = table_plan(window_bits, total_bytes, table_max)
     chunk = min(n, 16384)
-    slots = 2  # KZG_WS_SLOTS: successive calls take two workspaces in turn (calls in flight on two streams), and they grow together
+    slots = 3  # KZG_WS_SLOTS: successive calls take three workspaces in turn (calls in flight on several streams), and they grow together
     msm_ws = chunk * (BYTES_PER_BLOB + 65 * 192 + 192)
     plan = {"table_class": cls, "plane_groups": groups, "table": table, "table_build_scratch_transient": 13 * GIB if cls == 22 else 1.7 * GIB,
             "blobs": n * BYTES_PER_BLOB, "results_and_status": n * (48 + 4)}
@@ -611,10 +611,11 @@ class Rank:
             elapsed = float(t.item())
         return elapsed, prof
 
-    def measure(self, fn, reps):
-        """secondary workloads: (seconds per call, profile) over `reps` calls after two warm-up calls (the second one timed, for the
-        clock probe's duration)"""
-        fn()
+    def measure(self, fn, reps, warm=2):
+        """secondary workloads: (seconds per call, profile) over `reps` calls after `warm` warm-up calls (every lane of a
+        calls-in-flight measurement gets its first call here; the last warm-up call is timed, for the clock probe's duration)"""
+        for _ in range(max(1, warm) - 1):
+            fn()
         self.torch.cuda.synchronize()
         t0 = time.perf_counter()
         fn()
@@ -664,7 +665,7 @@ def extra_workloads(R, d_blobs, d_com, n):
         with torch.cuda.stream(st):
             R.commit(d_blobs, n, o, stt, raw)
 
-    dtc, _ = R.measure(two_commits, 8)
+    dtc, _ = R.measure(two_commits, 8, warm=4)
     for _, _, o, stt in lanes_c:
         assert int(stt.abs().sum()) == 0 and torch.equal(o, d_com), "two calls in flight must not change a byte"
     out["blob_to_kzg_commitment_two_calls_in_flight"] = {"blobs_per_s": n / dtc, "ms_per_batch": 1e3 * dtc}
@@ -676,22 +677,23 @@ def extra_workloads(R, d_blobs, d_com, n):
     dt, prof = R.measure(lambda: R.prove(d_blobs, d_com, n, d_prf, d_st), 3)
     out["compute_blob_kzg_proof"] = {"workload": "batch=%d blobs resident in HBM (BASELINE configs[2])" % n, "blobs_per_s": n / dt, "ms_per_batch": 1e3 * dt,
                                      "algorithmic_GBps": n * ALG_BYTES["proof"] / dt / 1e9, "roofline": roofline_object("proof", n, prof, setup.window_bits)}
-    # the same with TWO calls in flight (two streams, result buffers of their own): a call starts with ~5 ms in which the chip is
-    # nearly idle -- one SHA-256 stream per blob, then the quotients -- and no stream can order a call's hash before its own
-    # inputs; a caller that keeps two batches in flight has the second call's preparation run in the shadow of the first one's MSM
-    lanes = R.lanes(2, n)
+    # the same with THREE calls in flight (three streams, result buffers of their own; the context has three workspaces): a call
+    # starts with ~5 ms in which the chip is nearly idle -- one SHA-256 stream per blob, then the quotients -- and no stream can order
+    # a call's hash before its own inputs; a caller that keeps batches in flight has the next calls' preparation run in the shadow of
+    # the current call's MSM
+    lanes = R.lanes(3, n)
     tick = [0]
 
-    def two():
-        st, raw, o, stt = lanes[tick[0] % 2]
+    def in_flight():
+        st, raw, o, stt = lanes[tick[0] % 3]
         tick[0] += 1
         with torch.cuda.stream(st):
             R.prove(d_blobs, d_com, n, o, stt, raw)
 
-    dt2, _ = R.measure(two, 6)
+    dt2, _ = R.measure(in_flight, 21, warm=6)
     for _, _, o, stt in lanes:
-        assert int(stt.abs().sum()) == 0 and torch.equal(o, d_prf), "two calls in flight must not change a byte"
-    out["compute_blob_kzg_proof"].update({"blobs_per_s_two_calls_in_flight": n / dt2, "ms_per_batch_two_calls_in_flight": 1e3 * dt2})
+        assert int(stt.abs().sum()) == 0 and torch.equal(o, d_prf), "calls in flight must not change a byte"
+    out["compute_blob_kzg_proof"].update({"blobs_per_s_three_calls_in_flight": n / dt2, "ms_per_batch_three_calls_in_flight": 1e3 * dt2})
     del lanes
     # ---- verify: 65,536 distinct triples
     nv = 65536
@@ -717,12 +719,12 @@ def extra_workloads(R, d_blobs, d_com, n):
         return R.verify(vb, vc, vp, nv, 0, nv, vstreams[k % 2].cuda_stream)
 
     with concurrent.futures.ThreadPoolExecutor(max_workers=2) as pool:
-        assert all(pool.map(one_verify, range(2)))  # warm-up: the second pooled session
+        assert all(pool.map(one_verify, range(4)))  # warm-up: the second pooled session, both streams
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        oks = list(pool.map(one_verify, range(6)))
+        oks = list(pool.map(one_verify, range(10)))
         torch.cuda.synchronize()
-        dt2 = (time.perf_counter() - t0) / 6
+        dt2 = (time.perf_counter() - t0) / 10
     assert all(v is True for v in oks)
     rec.update({"blobs_per_s_two_calls_in_flight": nv / dt2, "ms_per_batch_two_calls_in_flight": 1e3 * dt2})
     rec["cpu_baseline"] = verify_cpu_baseline(R, vb, vc, vp, nv)
@@ -760,7 +762,7 @@ def run_rank(args, rank, local_rank, world):
     gathered = torch.empty(world * n * 48, dtype=torch.uint8, device=R.dev) if R.use_dist else None
     verdicts = []
 
-    flight = args.in_flight or (2 if wl == "proof" else 1)
+    flight = args.in_flight or (3 if wl == "proof" else 1)
     lanes = R.lanes(flight, n) if wl != "verify" else []
     tick = [0]
 
@@ -905,15 +907,15 @@ def run_rank(args, rank, local_rank, world):
                 result["metric"] = "blobs/sec for blob_to_kzg_commitment and verify_blob_kzg_proof_batch (n=4096)"
                 result["values"] = {"blob_to_kzg_commitment": result["value"], "verify_blob_kzg_proof_batch": v["blobs_per_s"], "compute_blob_kzg_proof": p["blobs_per_s"],
                                     "blob_to_kzg_commitment_two_calls_in_flight": result["extra"].get("blob_to_kzg_commitment_two_calls_in_flight", {}).get("blobs_per_s"),
-                                    "compute_blob_kzg_proof_two_calls_in_flight": p.get("blobs_per_s_two_calls_in_flight"),
+                                    "compute_blob_kzg_proof_three_calls_in_flight": p.get("blobs_per_s_three_calls_in_flight"),
                                     "verify_blob_kzg_proof_batch_two_calls_in_flight": v.get("blobs_per_s_two_calls_in_flight"), "unit": "blobs/s", "note": "`value` = blob_to_kzg_commitment at batch 4,096 (configs[1]); verify at batch 65,536 (configs[3]); proof at 4,096 (configs[2])"}
                 result["secondary_metrics"] = [
                     {"metric": METRIC["verify"], "value": v["blobs_per_s"], "unit": "blobs/s", "ms_per_step": v["ms_per_batch"], "workload": v["workload"],
                      "roofline_frac": v["roofline"]["frac"] if v.get("roofline") else None, "result": v["result"],
                      "value_two_calls_in_flight": v.get("blobs_per_s_two_calls_in_flight"), "ms_per_step_two_calls_in_flight": v.get("ms_per_batch_two_calls_in_flight")},
                     {"metric": METRIC["proof"], "value": p["blobs_per_s"], "unit": "blobs/s", "ms_per_step": p["ms_per_batch"], "workload": p["workload"],
-                     "roofline_frac": p["roofline"]["frac"] if p.get("roofline") else None, "value_two_calls_in_flight": p.get("blobs_per_s_two_calls_in_flight"),
-                     "ms_per_step_two_calls_in_flight": p.get("ms_per_batch_two_calls_in_flight")}]
+                     "roofline_frac": p["roofline"]["frac"] if p.get("roofline") else None, "value_three_calls_in_flight": p.get("blobs_per_s_three_calls_in_flight"),
+                     "ms_per_step_three_calls_in_flight": p.get("ms_per_batch_three_calls_in_flight")}]
             except Exception as err:  # secondary numbers never hide the headline
                 result["extra"] = {"error": repr(err)}
         if not args.no_cpu_baseline and world == 1:

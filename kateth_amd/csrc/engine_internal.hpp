@@ -120,7 +120,7 @@ struct ProfEvent {
 
 struct kzg_verify_session;
 struct kzg_ctx;
-constexpr int KZG_WS_SLOTS = 2;
+constexpr int KZG_WS_SLOTS = 3;
 struct WsSlot {
   void* p = nullptr;
   size_t bytes = 0;
@@ -198,7 +198,7 @@ struct kzg_ctx {
   // workspace (grown on demand, guarded by lock)
   mutable std::mutex lock;
   // KZG_WS_SLOTS workspaces taken in turn by successive commitment / proof calls: a call's stream waits for the previous
-  // user of ITS slot only, so two calls enqueued on two streams run side by side (one call's hash and quotient kernels in
+  // user of ITS slot only, so calls enqueued on several streams run side by side (one call's hash and quotient kernels in
   // the shadow of the other's MSM) instead of queueing behind one shared buffer
   mutable WsSlot wss[KZG_WS_SLOTS];
   mutable uint32_t ws_next = 0;  // slot of the next call

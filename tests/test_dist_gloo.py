@@ -129,7 +129,7 @@ def test_bench_dry_run_prints_every_ranks_memory_plan():
     assert [r["first_blob"] for r in rec["ranks"]] == [131072 * k for k in range(8)]
     r0 = rec["ranks"][0]
     assert r0["fits"] and (r0["table_class"], r0["plane_groups"]) == (22, 8)
-    assert r0["blobs"] == 16 << 30 and r0["table"] >= 192 * (1 << 30) and 4 << 30 <= r0["workspace"] < 5 << 30  # two workspace slots of 2.2 GiB
+    assert r0["blobs"] == 16 << 30 and r0["table"] >= 192 * (1 << 30) and 6 << 30 <= r0["workspace"] < 7 << 30  # three workspace slots of 2.2 GiB
     assert r0["resident_total"] <= r0["hbm_total"] - (2 << 30)
     assert rec["exchange_bytes_per_step_per_rank"] == 131072 * 48
     # a part with 160 GiB of HBM steps down to 4 plane groups; a batch that cannot fit is refused with exit code 3

@@ -127,21 +127,21 @@ def test_host_buffer_verify_takes_the_fused_path(engine, torch_cuda):
     assert engine.verify_blob_proof(bytes(131072), INF48, INF48) is True
 
 
-def test_calls_in_flight_on_two_streams_are_bit_exact(engine, torch_cuda, golden):
-    """successive commitment / proof calls take the context's workspace slots in turn: calls enqueued on two streams (and on
-    one) with no synchronisation in between -- 12 of them, alternating sizes so that the slots are regrown under way -- return
-    what one call at a time returns"""
+def test_calls_in_flight_on_several_streams_are_bit_exact(engine, torch_cuda, golden):
+    """successive commitment / proof calls take the context's workspace slots (three) in turn: calls enqueued on two, then four
+    streams (one more than there are slots: a call waits for the slot's previous user) and on one, with no synchronisation in
+    between -- 20 of them, alternating sizes so that the slots are regrown under way -- return what one call at a time returns"""
     torch = torch_cuda
     n = 600
     d_blobs, d_c, d_p = _triples(engine, torch, n, golden["seed"])
     hc, hp = d_c.cpu().numpy().tobytes(), d_p.cpu().numpy().tobytes()
     for rec in golden["blobs"]:
         assert hc[48 * rec["index"]:48 * rec["index"] + 48].hex() == rec["commitment"]
-    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
-    sizes = [600, 37, 512, 600, 1, 300, 600, 64, 600, 129, 600, 600]
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    sizes = [600, 37, 512, 600, 1, 300, 600, 64, 600, 129, 600, 600, 600, 600, 450, 600, 2, 600, 600, 77]
     outs = []
     for k, m in enumerate(sizes):
-        st = streams[k % 2] if k < 8 else streams[0]
+        st = streams[k % 2] if k < 8 else streams[0] if k < 12 else streams[k % 4]
         with torch.cuda.stream(st):  # the fills run on the call's own stream (torch's pool streams do not order against its default stream)
             o = torch.zeros(m * 48, dtype=torch.uint8, device="cuda")
             s = torch.full((m,), -7, dtype=torch.int32, device="cuda")

@@ -10,7 +10,8 @@ cd $R
 python tools/gpu_hostapi_bench.py 4096 0 > $O/hostapi_n4096.json 2> $O/evidence.err
 python tools/gpu_hostapi_bench.py 16384 0 > $O/hostapi_n16384.json 2>> $O/evidence.err
 python bench.py --default-budget --no-extra --steps 10 --warmup 3 --no-cpu-baseline --no-live-traffic > $O/bench_commit_default_budget.json 2>> $O/evidence.err
-python bench.py --workload proof --steps 20 --warmup 5 --no-cpu-baseline --no-live-traffic > $O/bench_proof_two_in_flight.json 2>> $O/evidence.err
+python bench.py --workload proof --in-flight 2 --steps 20 --warmup 5 --no-cpu-baseline --no-live-traffic > $O/bench_proof_two_in_flight.json 2>> $O/evidence.err
+python bench.py --workload proof --in-flight 3 --steps 21 --warmup 6 --no-cpu-baseline --no-live-traffic > $O/bench_proof_three_in_flight.json 2>> $O/evidence.err
 python bench.py --workload proof --in-flight 1 --steps 20 --warmup 5 --no-cpu-baseline --no-live-traffic > $O/bench_proof_one_in_flight.json 2>> $O/evidence.err
 python tools/bench_criterion.py 0 --no-cpu > $O/criterion_equivalent.json 2>> $O/evidence.err
 cd /tmp && export TMPDIR=/tmp

@@ -18,10 +18,11 @@ B="--no-cpu-baseline --no-live-traffic --blocking-setup"
 if [ -z "$PMC_ONLY" ]; then
 run trace_default --kernel-trace --stats --output-format csv -d $OUT/trace_default -- python3 $R/bench.py --steps 10 --warmup 2 $B
 run trace_commit --kernel-trace --stats --output-format csv -d $OUT/trace_commit -- python3 $R/bench.py --steps 10 --warmup 2 --no-extra $B
-run trace_proof --kernel-trace --stats --output-format csv -d $OUT/trace_proof -- python3 $R/bench.py --workload proof --in-flight 1 --steps 5 --warmup 1 $B
-run trace_proof2 --kernel-trace --stats --output-format csv -d $OUT/trace_proof2 -- python3 $R/bench.py --workload proof --in-flight 2 --steps 6 --warmup 2 $B
+run trace_proof --kernel-trace --stats --output-format csv -d $OUT/trace_proof -- python3 $R/bench.py --workload proof --in-flight 1 --steps 5 --warmup 3 $B
+run trace_proof2 --kernel-trace --stats --output-format csv -d $OUT/trace_proof2 -- python3 $R/bench.py --workload proof --in-flight 2 --steps 6 --warmup 3 $B
+run trace_proof3 --kernel-trace --stats --output-format csv -d $OUT/trace_proof3 -- python3 $R/bench.py --workload proof --in-flight 3 --steps 9 --warmup 3 $B
 run trace_verify --kernel-trace --stats --output-format csv -d $OUT/trace_verify -- python3 $R/bench.py --workload verify --steps 5 --warmup 1 $B
-for w in proof2 verify; do
+for w in proof2 proof3 verify; do
   f=$(find $OUT/trace_$w -name "*kernel_trace.csv" | head -1)
   python3 $R/tools/trace_timeline.py $f 70 > $OUT/timeline_$w.txt
 done

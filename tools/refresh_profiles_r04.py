@@ -49,14 +49,16 @@ out["verify_n65536_c22"] = {"kernel": "k_challenge", "algorithmic_bytes_per_laun
 json.dump(out, open(D + "pmc_traffic.json", "w"), indent=1)
 shutil.copy(P + "summary_pmc.json", D + "pmc_counters_per_kernel.json")
 for a, b in (("default", "bench_default_kernel_stats.csv"), ("commit", "trace_commit_kernel_stats.csv"), ("proof", "trace_proof4096_kernel_stats.csv"),
-             ("proof2", "trace_proof4096_two_calls_in_flight_kernel_stats.csv"), ("verify", "trace_verify65536_kernel_stats.csv")):
+             ("proof2", "trace_proof4096_two_calls_in_flight_kernel_stats.csv"), ("proof3", "trace_proof4096_three_calls_in_flight_kernel_stats.csv"),
+             ("verify", "trace_verify65536_kernel_stats.csv")):
     if os.path.exists(P + "summary_trace_%s_kernel_stats.csv" % a):
         shutil.copy(P + "summary_trace_%s_kernel_stats.csv" % a, D + b)
 for src, dst in ((P + "timeline_verify.txt", "verify65536_kernel_timeline.txt"), (P + "timeline_proof2.txt", "proof4096_two_calls_in_flight_kernel_timeline.txt"),
+                 (P + "timeline_proof3.txt", "proof4096_three_calls_in_flight_kernel_timeline.txt"),
                  (R + "gpurun_out/bench_default.json", "bench_default.json")):
     if os.path.exists(src):
         shutil.copy(src, D + dst)
-for w in ("default", "commit", "proof", "proof2", "verify"):
+for w in ("default", "commit", "proof", "proof2", "proof3", "verify"):
     try:
         line = [l for l in open(P + "trace_%s.log" % w) if l.startswith('{"metric"')][0]
     except (OSError, IndexError):
@@ -67,7 +69,7 @@ for w in ("default", "commit", "proof", "proof2", "verify"):
 if os.path.exists(D + "bench_default.json"):
     d = json.loads([l for l in open(D + "bench_default.json") if l.startswith("{")][-1])
     print("default:", round(d["value"]), round(d["ms_per_step"], 3), "frac", d["roofline"]["frac"], "valu_issue", (d["roofline"].get("valu_issue") or {}).get("frac"),
-          [(round(m["value"]), m.get("valu_issue_frac"), m.get("value_two_calls_in_flight")) for m in d["secondary_metrics"]], d["extra"]["single_blob_latency_ms"])
+          [(round(m["value"]), m.get("valu_issue_frac"), m.get("value_two_calls_in_flight") or m.get("value_three_calls_in_flight")) for m in d["secondary_metrics"]], d["extra"]["single_blob_latency_ms"])
 print("decoder WRITE_SIZE per launch (bytes):", dc["WRITE_SIZE_bytes"], " verify call HBM / algorithmic:", out["verify_n65536_c22"]["call_over_algorithmic"])
 print("commit traffic / algorithmic:", out["commit_n4096_c22"]["over_algorithmic"])
 for run, kern in (("pmc_commit_sq", "k_msm_comb28"), ("pmc_verify_sq", "k_challenge"), ("pmc_verify_sq", "k_eval_frac"), ("pmc_verify_sq", "k_g1_decompress_range")):

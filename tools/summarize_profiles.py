@@ -18,7 +18,7 @@ def short(name):
 
 
 def main(out):
-    for name in ("trace_default", "trace_commit", "trace_proof", "trace_proof2", "trace_verify"):
+    for name in ("trace_default", "trace_commit", "trace_proof", "trace_proof2", "trace_proof3", "trace_verify"):
         for f in glob.glob(os.path.join(out, name, "**", "*kernel_stats.csv"), recursive=True):
             shutil.copy(f, os.path.join(out, "summary_%s_kernel_stats.csv" % name))
     summary = {}
