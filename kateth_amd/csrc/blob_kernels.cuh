@@ -203,6 +203,8 @@ static __global__ __launch_bounds__(64) void k_challenge(const uint8_t* __restri
 
 // the PRODUCER wave of the two latency kernels: message schedule (W + K) of block k into wk[k & 1], one block ahead of the
 // consumer(s); one workgroup barrier per block
+// QUADS: the schedule in the layout of the lane-pair rounds (sha256_expand_to_lds_quads)
+template <bool QUADS>
 __device__ __forceinline__ void challenge_producer(uint32_t (*wk)[64 * 64], int lane, const uint8_t* __restrict__ blob, const uint8_t* __restrict__ com) {
   constexpr uint32_t NBLK = 2050;
   uint32_t w[16], nxt[16];
@@ -224,7 +226,10 @@ __device__ __forceinline__ void challenge_producer(uint32_t (*wk)[64 * 64], int 
   load_be_words16(nxt + 12, blob + 80);
 #pragma unroll 1
   for (uint32_t k = 0; k < NBLK; k++) {
-    sha256_expand_to_lds(wk[k & 1], lane, w);
+    if (QUADS)
+      sha256_expand_to_lds_quads(wk[k & 1], lane, w);
+    else
+      sha256_expand_to_lds(wk[k & 1], lane, w);
 #pragma unroll
     for (int q = 0; q < 16; q++) w[q] = nxt[q];
     const uint32_t k2 = k + 2;  // the block after next
@@ -266,7 +271,7 @@ __device__ __forceinline__ void challenge_split_workgroup(uint32_t (*wk)[64 * 64
   const uint8_t* com = commitments48 + b * 48;
   constexpr uint32_t NBLK = 2050;
   if (producer) {
-    challenge_producer(wk, lane, blob, com);
+    challenge_producer<false>(wk, lane, blob, com);
   } else {
     sha256_state s;
     sha256_init(s);
@@ -291,32 +296,36 @@ static __global__ __launch_bounds__(128) void k_challenge_split(const uint8_t* _
   challenge_split_workgroup(wk, blockIdx.x, blobs, commitments48, n, z_plain);
 }
 // Batches small enough for THREE waves per 64 blobs to have a SIMD each (n <= 16,384 on 256 CUs; single items): the rounds
-// run on lane pairs (sha256_rounds_pair: 11 instead of 14 instructions per round on the critical chain), so 64 blobs
+// run on lane pairs (sha256_rounds_pair: 10 instead of 14 instructions per round on the critical chain), so 64 blobs
 // take two consumer waves + the producer wave.  Y lanes read their W + K from an all-zero LDS region.
 __device__ __forceinline__ void challenge_pair_workgroup(uint32_t (*wk)[64 * 64], uint32_t* zeros, uint64_t wg, const uint8_t* __restrict__ blobs,
                                                          const uint8_t* __restrict__ commitments48, uint64_t n, fr_t* __restrict__ z_plain) {
   issue_priority_latency();  // a latency-bound stream: never behind an MSM wave of another stream (issue_fair.cuh)
   const int tid = threadIdx.x;  // 192 threads: [0, 128) consumer lane pairs, [128, 192) producer
   const bool producer = tid >= 128;
-  const int p = producer ? tid - 128 : tid >> 1;  // blob within the workgroup
+  const int p = producer ? tid - 128 : sha_pair_slot(tid);  // blob within the workgroup
   uint64_t b = wg * 64 + p;
   const bool live = b < n;
   if (!live) b = n - 1;  // idle lanes shadow the last blob: every wave must reach every barrier
   for (int i = tid; i < 64 * 64; i += 192) zeros[i] = 0;
   __syncthreads();
   if (producer) {
-    challenge_producer(wk, p, blobs + b * 131072ull, commitments48 + b * 48);
+    challenge_producer<true>(wk, p, blobs + b * 131072ull, commitments48 + b * 48);
   } else {
-    const bool is_y = (tid & 1) != 0;
+    const bool is_y = sha_pair_is_y(tid);
     sha256_state init;
     sha256_init(init);
     sha256_half st;
 #pragma unroll
     for (int q = 0; q < 4; q++) st.s[q] = is_y ? init.h[q] : init.h[4 + q];
+    // the lane's slot in the schedule buffer of even and of odd blocks (Y: the zero region both times), toggled by a subtraction
+    const uint32_t even = sha_lds_address((is_y ? zeros : wk[0]) + 4 * p), both = even + sha_lds_address((is_y ? zeros : wk[1]) + 4 * p);
+    uint32_t quads = even;
 #pragma unroll 1
     for (uint32_t k = 0; k < 2050; k++) {
       __syncthreads();
-      sha256_rounds_pair(st, is_y ? zeros + p : wk[k & 1] + p, is_y);
+      sha256_rounds_pair(st, quads, is_y);
+      quads = both - quads;
     }
     uint32_t other[4];
 #pragma unroll
@@ -335,8 +344,8 @@ __device__ __forceinline__ void challenge_pair_workgroup(uint32_t (*wk)[64 * 64]
 }
 static __global__ __launch_bounds__(192) void k_challenge_pair(const uint8_t* __restrict__ blobs, const uint8_t* __restrict__ commitments48, uint64_t n,
                                                                fr_t* __restrict__ z_plain) {
-  __shared__ uint32_t wk[2][64 * 64];
-  __shared__ uint32_t zeros[64 * 64];
+  __shared__ alignas(16) uint32_t wk[2][64 * 64];
+  __shared__ alignas(16) uint32_t zeros[64 * 64];
   // Claim more than half of a SIMD's register file (nothing is stored there): a second workgroup then cannot put a wave next
   // to one of this kernel's on the same SIMD, so the dispatcher has to give every workgroup a CU of its own (256 workgroups
   // = 16,384 blobs on 256 CUs).  Left to itself it paired workgroups on some CUs and the hash took 4.7 instead of 3.7 ms.
@@ -348,8 +357,8 @@ static __global__ __launch_bounds__(192) void k_challenge_pair_and_decode(const 
                                                                           const uint8_t* __restrict__ in_a, uint64_t n_a, int32_t* __restrict__ status_a,
                                                                           const uint8_t* __restrict__ in_b, uint64_t n_b, int32_t* __restrict__ status_b,
                                                                           uint4* __restrict__ affine, uint8_t* __restrict__ inf) {
-  __shared__ uint32_t wk[2][64 * 64];
-  __shared__ uint32_t zeros[64 * 64];
+  __shared__ alignas(16) uint32_t wk[2][64 * 64];
+  __shared__ alignas(16) uint32_t zeros[64 * 64];
   if (blockIdx.x < sha_wgs) {
     challenge_pair_workgroup(wk, zeros, blockIdx.x, blobs, commitments48, n, z_plain);
   } else {

@@ -879,8 +879,12 @@ int32_t commit_host(const kzg_ctx* ctx, const uint8_t* blobs, uint64_t n, uint8_
   if (rc) return rc;
   uint8_t* d_res = ctx->hostio;
   int32_t* d_status = reinterpret_cast<int32_t*>(ctx->hostio + out_bytes);
-  hipStream_t copy_st = ctx->stage_copy_stream;
+  // A call of ONE chunk (single blobs -- the drop-in's common case -- up to a few thousand) rides on one stream, copy included:
+  // every event between two streams is a packet on one hardware queue waiting for a signal from another (~0.1 ms each with a
+  // queue per stream), and there is nothing to overlap.
+  const bool one_chunk = plan.size() == 1;
   hipStream_t comp[2] = {ctx->stage_streams[0], ctx->stage_streams[1]};
+  hipStream_t copy_st = one_chunk ? comp[0] : ctx->stage_copy_stream;
   std::lock_guard<std::mutex> guard(ctx->lock);  // the workspace: per slot the lane sums, the sums and the bit-plane masks of a chunk
   uint64_t max_units = 1;  // launch shapes follow the table in use, which only changes under this lock
   for (uint64_t m : plan) {
@@ -894,11 +898,11 @@ int32_t commit_host(const kzg_ctx* ctx, const uint8_t* blobs, uint64_t n, uint8_
     const size_t scratch_bytes = align_up(msm_scratch_bytes(ctx, max_chunk), 256);
     const size_t per_slot = partial_bytes + sums_bytes + scratch_bytes;
     rc = ws_begin(ctx, comp[0]);
-    if (rc == 0) rc = ws_wait(ctx, comp[1]);
+    if (rc == 0 && !one_chunk) rc = ws_wait(ctx, comp[1]);
     if (rc == 0) rc = ws_reserve(ctx, nslots * per_slot);
     if (rc) break;
-    if (hipMemsetAsync(d_status, 0, n * sizeof(int32_t), comp[0]) != hipSuccess || hipEventRecord(ctx->stage_join[0], comp[0]) != hipSuccess ||
-        hipStreamWaitEvent(comp[1], ctx->stage_join[0], 0) != hipSuccess) {
+    if (hipMemsetAsync(d_status, 0, n * sizeof(int32_t), comp[0]) != hipSuccess ||
+        (!one_chunk && (hipEventRecord(ctx->stage_join[0], comp[0]) != hipSuccess || hipStreamWaitEvent(comp[1], ctx->stage_join[0], 0) != hipSuccess))) {
       rc = fail(KZG_FAIL_HIP, "memset failed");
       break;
     }
@@ -918,7 +922,8 @@ int32_t commit_host(const kzg_ctx* ctx, const uint8_t* blobs, uint64_t n, uint8_
       }
       if (hipMemcpyAsync(ctx->stage + (size_t)slot * slot_bytes, blobs + base * (size_t)KZG_BYTES_PER_BLOB, m * (size_t)KZG_BYTES_PER_BLOB,
                          hipMemcpyHostToDevice, copy_st) != hipSuccess ||
-          hipEventRecord(ctx->stage_copied[slot], copy_st) != hipSuccess || hipStreamWaitEvent(comp[slot], ctx->stage_copied[slot], 0) != hipSuccess) {
+          (!one_chunk && (hipEventRecord(ctx->stage_copied[slot], copy_st) != hipSuccess ||
+                          hipStreamWaitEvent(comp[slot], ctx->stage_copied[slot], 0) != hipSuccess))) {
         rc = fail(KZG_FAIL_HIP, "host-to-device copy failed");
         break;
       }
@@ -929,7 +934,7 @@ int32_t commit_host(const kzg_ctx* ctx, const uint8_t* blobs, uint64_t n, uint8_
                         comp[slot]);
     }
     if (rc) break;
-    if (hipEventRecord(ctx->stage_join[1], comp[1]) != hipSuccess || hipStreamWaitEvent(comp[0], ctx->stage_join[1], 0) != hipSuccess) {
+    if (!one_chunk && (hipEventRecord(ctx->stage_join[1], comp[1]) != hipSuccess || hipStreamWaitEvent(comp[0], ctx->stage_join[1], 0) != hipSuccess)) {
       rc = fail(KZG_FAIL_HIP, "stream join failed");
       break;
     }

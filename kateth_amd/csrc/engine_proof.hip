@@ -207,8 +207,9 @@ int32_t proof_host(const kzg_ctx* ctx, const uint8_t* blobs, const uint8_t* side
   uint8_t* d_aff = out_affine96 ? ctx->hostio + o_aff : nullptr;
   uint8_t* d_y = ctx->hostio + o_y;
   int32_t* d_status = reinterpret_cast<int32_t*>(ctx->hostio + o_st);
-  hipStream_t copy_st = ctx->stage_copy_stream;
   hipStream_t st = ctx->stage_streams[0];  // an idle non-blocking stream (the null stream would serialise against every blocking stream of the process)
+  const bool one_pass = plan.size() == 1;  // nothing to overlap: the copy rides on the compute stream, no event between hardware queues
+  hipStream_t copy_st = one_pass ? st : ctx->stage_copy_stream;
   std::lock_guard<std::mutex> guard(ctx->lock);
   do {
     if (hipMemcpyAsync(d_side, side, n * side_bytes, hipMemcpyHostToDevice, st) != hipSuccess) {
@@ -230,7 +231,7 @@ int32_t proof_host(const kzg_ctx* ctx, const uint8_t* blobs, const uint8_t* side
         break;
       }
       if (hipMemcpyAsync(d_blobs, blobs + base * (size_t)KZG_BYTES_PER_BLOB, m * (size_t)KZG_BYTES_PER_BLOB, hipMemcpyHostToDevice, copy_st) != hipSuccess ||
-          hipEventRecord(ctx->stage_copied[slot], copy_st) != hipSuccess || hipStreamWaitEvent(st, ctx->stage_copied[slot], 0) != hipSuccess) {
+          (!one_pass && (hipEventRecord(ctx->stage_copied[slot], copy_st) != hipSuccess || hipStreamWaitEvent(st, ctx->stage_copied[slot], 0) != hipSuccess))) {
         rc = fail(KZG_FAIL_HIP, "host-to-device copy failed");
         break;
       }

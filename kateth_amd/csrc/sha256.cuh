@@ -2,6 +2,7 @@
 // One hash state per lane; the 64-word schedule lives in 16 rotating VGPRs.
 #pragma once
 #include "field.cuh"
+#include "sha_pair_asm.cuh"
 
 namespace kzg {
 
@@ -137,6 +138,34 @@ __device__ __forceinline__ void sha256_expand_to_lds(uint32_t* __restrict__ wk /
     wk[i * 64 + lane] = wi + sha256_k(i);
   }
 }
+// the same schedule in the layout of the lane-pair rounds: wk as [16 groups][64 slots] uint4, group t / 4 holds W[t] + K[t] of
+// four consecutive rounds (one ds_write_b128 per group here, one ds_read_b128 per group in sha256_rounds_pair_asm)
+__device__ __forceinline__ void sha256_expand_to_lds_quads(uint32_t* __restrict__ wk /* [16][64][4] */, int slot, const uint32_t* win /* 16 words */) {
+  uint32_t w[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) w[i] = win[i];
+  uint4* out = reinterpret_cast<uint4*>(wk) + slot;
+#pragma unroll
+  for (int g = 0; g < 16; g++) {
+    uint32_t q[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int i = 4 * g + j;
+      uint32_t wi;
+      if (i < 16) {
+        wi = w[i];
+      } else {
+        const uint32_t w15 = w[(i - 15) & 15], w2 = w[(i - 2) & 15];
+        const uint32_t s0 = xor3(rotr32(w15, 7), rotr32(w15, 18), w15 >> 3);
+        const uint32_t s1 = xor3(rotr32(w2, 17), rotr32(w2, 19), w2 >> 10);
+        wi = w[i & 15] + s0 + w[(i - 7) & 15] + s1;
+        w[i & 15] = wi;
+      }
+      q[j] = wi + sha256_k(i);
+    }
+    out[g * 64] = make_uint4(q[0], q[1], q[2], q[3]);
+  }
+}
 __device__ __forceinline__ void sha256_rounds_from_lds(sha256_state& s, const uint32_t* __restrict__ wk, int lane) {
   uint32_t a = s.h[0], b = s.h[1], c = s.h[2], d = s.h[3];
   uint32_t e = s.h[4], f = s.h[5], g = s.h[6], h = s.h[7];
@@ -168,40 +197,37 @@ __device__ __forceinline__ void sha256_rounds_from_lds(sha256_state& s, const ui
 // ---- the 64 rounds on a PAIR of lanes -------------------------------------------------------------------------------
 // Latency path, one step further: the consumer's 14 instructions per round are two almost independent halves,
 //   T1 = h + Sigma1(e) + Ch(e, f, g) + (W + K)      and      T2 = Sigma0(a) + Maj(a, b, c),
-// joined only by e' = d + T1, a' = T1 + T2.  An even lane X keeps (e, f, g, h), its odd neighbour Y keeps (a, b, c, d), and
-// both run the SAME instructions: rotations by per-lane amounts (v_alignbit_b32 takes the shift from a VGPR),
-// Maj(a, b, c) = Ch(~(a ^ b), b, c) so one Ch serves both (the selector is a0 for X and ~(a0 ^ a1) for Y: one
-// v_bitop3_b32 with the lane's role mask as third operand), W + K read from LDS by X and from an all-zero region by Y,
-// h added under the X mask; then X sends T1 and Y sends d to the neighbour (DPP quad_perm, folded into the add):
-// 11 instructions per round instead of 14 on the chain that bounds a single hash.
+// joined only by e' = d + T1, a' = T1 + T2.  A lane X keeps (e, f, g, h), its partner Y keeps (a, b, c, d), and both run the
+// SAME instructions: rotations by per-lane amounts (v_alignbit_b32 takes the shift from a VGPR), Maj(a, b, c) =
+// Ch(~(a ^ b), b, c) so one Ch serves both (the selector is a0 for X and ~(a0 ^ a1) for Y: one v_bitop3_b32 with the lane's
+// role mask as third operand), W + K read from LDS by X and from an all-zero region by Y.
+// Partners are the lanes j and 7 - j of every group of eight (DPP row_half_mirror), so that X lanes fill DPP banks 0 and 2 and
+// Y lanes banks 1 and 3: what only one role does is ONE instruction with a bank mask instead of a select and the operation --
+//   hw = (W + K) + h         X banks only (Y keeps its zero)
+//   t  = Sigma + Ch + hw     X: T1     Y: T2
+//   n  = mirror(a3) + t      X banks only: e' = d + T1 (d is Y's a3)
+//   n  = mirror(t) + t       Y banks only: a' = T1 + T2
+// 10 instructions per round on the chain that bounds a single hash (14 on one lane; 11 with selects on quad_perm pairs, the
+// form of rounds 2-3).  The rounds themselves are generated assembly (sha_pair_asm.cuh, tools/gen_sha_pair_asm.py): a lone
+// wave pays an issue slot for every s_nop the compiler puts around a DPP hazard it cannot schedule away.
 struct sha256_half {
   uint32_t s[4];  // X: e, f, g, h      Y: a, b, c, d
 };
+// role and blob slot of consumer thread `tid` (eight consecutive threads cover four blobs)
+__device__ __forceinline__ bool sha_pair_is_y(int tid) { return (tid & 4) != 0; }
+__device__ __forceinline__ int sha_pair_slot(int tid) { return (tid >> 3) * 4 + ((tid & 4) ? 7 - (tid & 7) : (tid & 7)); }
 __device__ __forceinline__ uint32_t sha_pair_swap(uint32_t v) {
-  return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141 /* row_half_mirror */, 0xF, 0xF, true);
 }
-// wk: this lane's base into the [t][blob] schedule (X) or into the zero region (Y); element t at wk[t * 64]
-__device__ __forceinline__ void sha256_rounds_pair(sha256_half& st, const uint32_t* __restrict__ wk, bool is_y) {
+__device__ __forceinline__ uint32_t sha_lds_address(const void* p) {
+  return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
+}
+// one block; quads_lds: sha_lds_address of this lane's slot in the block's [16][64] uint4 schedule (X) or in the zero region of the
+// same shape (Y)
+__device__ __forceinline__ void sha256_rounds_pair(sha256_half& st, uint32_t quads_lds, bool is_y) {
   const uint32_t k1 = is_y ? 2u : 6u, k2 = is_y ? 13u : 11u, k3 = is_y ? 22u : 25u;
-  const uint32_t ymask = is_y ? 0xffffffffu : 0u, xmask = ~ymask;
-  uint32_t a0 = st.s[0], a1 = st.s[1], a2 = st.s[2], a3 = st.s[3];
-#pragma unroll
-  for (int i = 0; i < 64; i++) {
-    const uint32_t sig = xor3(__builtin_amdgcn_alignbit(a0, a0, k1), __builtin_amdgcn_alignbit(a0, a0, k2), __builtin_amdgcn_alignbit(a0, a0, k3));
-    const uint32_t sel = __builtin_amdgcn_bitop3_b32(a0, a1, ymask, 0xD2);  // X: a0      Y: ~(a0 ^ a1)
-    const uint32_t ch = sha_ch(sel, a1, a2);                                // X: Ch(e, f, g)   Y: Maj(a, b, c)
-    const uint32_t t = sig + ch + wk[i * 64] + (a3 & xmask);                // X: T1      Y: T2
-    const uint32_t send = is_y ? a3 : t;                                    // X sends T1, Y sends d
-    const uint32_t n0 = t + sha_pair_swap(send);                            // X: e' = T1 + d      Y: a' = T2 + T1
-    a3 = a2;
-    a2 = a1;
-    a1 = a0;
-    a0 = n0;
-  }
-  st.s[0] += a0;
-  st.s[1] += a1;
-  st.s[2] += a2;
-  st.s[3] += a3;
+  const uint32_t ymask = is_y ? 0xffffffffu : 0u;
+  sha256_rounds_pair_asm(st.s[0], st.s[1], st.s[2], st.s[3], quads_lds, k1, k2, k3, ymask);
 }
 #endif
 

@@ -1,10 +1,17 @@
-"""The lane-pair SHA-256 rounds (kateth_amd/csrc/sha256.cuh, sha256_rounds_pair) rest on three identities; the kernel itself is
-device-only (DPP lane exchange) and is covered by the GPU parity tests, the identities are checked here on the CPU:
+"""The lane-pair SHA-256 rounds (kateth_amd/csrc/sha256.cuh, sha256_rounds_pair; the rounds themselves are generated assembly:
+kateth_amd/csrc/sha_pair_asm.cuh, tools/gen_sha_pair_asm.py) are device-only (DPP lane exchange) and are covered end to end by the
+GPU parity tests.  Here, on the CPU:
   * Maj(a, b, c) = Ch(~(a ^ b), b, c);
   * the selector v_bitop3_b32(a0, a1, role, 0xD2) is a0 for role = 0 and ~(a0 ^ a1) for role = all-ones;
-  * one round computed as (X: T1 + h-half, Y: T2-half) with the two exchanges gives the FIPS 180-4 round, so 64 of them give
-    the reference compression function."""
+  * the GENERATED INSTRUCTION STREAM itself is interpreted on a group of eight lanes (four X / Y pairs: DPP row_half_mirror and
+    the identity permutation with their bank masks, the LDS quads, the lgkmcnt waits) and must give the FIPS 180-4 compression
+    function for four independent messages at once; the interpreter also checks the two hazards the stream covers by instruction
+    order alone -- a DPP read at least two instructions after the VALU write of its source, no W + K register read before the
+    wait that covers its load;
+  * the thread -> (role, blob slot) map of the consumer waves is a bijection onto 64 slots x two roles with partners j <-> 7 - j."""
 import hashlib
+import os
+import re
 import random
 import struct
 
@@ -56,37 +63,161 @@ def test_selector_truth_table_0xD2():
     assert bitop3(0xF0F0F0F0, 0xCCCCCCCC, 0xAAAAAAAA, 0xCA) == ch(0xF0F0F0F0, 0xCCCCCCCC, 0xAAAAAAAA)  # the Ch table the kernel uses
 
 
-def pair_compress(state, w64):
-    """the kernel's data flow: X = (e, f, g, h), Y = (a, b, c, d); same operations on both with role-dependent constants"""
-    X = [state[4], state[5], state[6], state[7]]
-    Y = [state[0], state[1], state[2], state[3]]
-    for i in range(64):
-        out = {}
-        for role, s, rots, wk in (("X", X, (6, 11, 25), (w64[i] + K[i]) & M), ("Y", Y, (2, 13, 22), 0)):
-            ymask = M if role == "Y" else 0
-            sig = rotr(s[0], rots[0]) ^ rotr(s[0], rots[1]) ^ rotr(s[0], rots[2])
-            sel = bitop3(s[0], s[1], ymask, 0xD2)
-            c = bitop3(sel, s[1], s[2], 0xCA)
-            t = (sig + c + wk + (s[3] & (~ymask & M))) & M
-            out[role] = (t, s[3] if role == "Y" else t)  # (own t, what this lane sends)
-        n0x = (out["X"][0] + out["Y"][1]) & M  # e' = T1 + d
-        n0y = (out["Y"][0] + out["X"][1]) & M  # a' = T2 + T1
-        X = [n0x, X[0], X[1], X[2]]
-        Y = [n0y, Y[0], Y[1], Y[2]]
-    return [(state[k] + Y[k]) & M for k in range(4)] + [(state[4 + k] + X[k]) & M for k in range(4)]
+def schedule(block16):
+    w = list(block16)
+    for i in range(16, 64):
+        s0 = rotr(w[i - 15], 7) ^ rotr(w[i - 15], 18) ^ (w[i - 15] >> 3)
+        s1 = rotr(w[i - 2], 17) ^ rotr(w[i - 2], 19) ^ (w[i - 2] >> 10)
+        w.append((w[i - 16] + s0 + w[i - 7] + s1) & M)
+    return w
 
 
-def test_pair_rounds_equal_sha256():
+ASM = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "kateth_amd", "csrc", "sha_pair_asm.cuh")
+LANES = 8  # one half row: lanes 0-3 are DPP bank 0 (X), lanes 4-7 bank 1 (Y); lane j's partner is 7 - j
+
+
+def asm_lines():
+    return [m.group(1) for m in re.finditer(r'^\s*"([^"]+?)\\n\\t"', open(ASM).read(), re.M)]
+
+
+class Wave:
+    """registers as per-lane lists; interprets exactly the opcodes the generator emits"""
+
+    def __init__(self, operands):
+        self.reg = dict(operands)
+        self.written_at = {}  # register -> index of the instruction slot (VALU or s_nop wait states) that wrote it
+        self.slot = 0
+        self.loads = []  # destination register quads in issue order
+        self.complete = 0  # loads [0, complete) have returned
+
+    def get(self, name):
+        if name not in self.reg:
+            raise AssertionError("read of unwritten register " + name)
+        return self.reg[name]
+
+    def dpp(self, src, ctrl):
+        v = self.get(src)
+        assert self.slot - self.written_at.get(src, -10) >= 3, "DPP read of %s too close to its write" % src
+        if ctrl == "row_half_mirror":
+            return [v[7 - j] for j in range(LANES)]
+        assert ctrl == "quad_perm:[0,1,2,3]"
+        return list(v)
+
+    def put(self, name, values, banks=0xF):
+        old = self.reg.get(name, [None] * LANES)
+        self.reg[name] = [values[j] if (banks >> (j // 4)) & 1 else old[j] for j in range(LANES)]
+        self.written_at[name] = self.slot
+
+    def check_loaded(self, name):
+        for k, quad in enumerate(self.loads):
+            if name in quad:
+                assert k < self.complete, "%s read before the wait that covers its load" % name
+
+    def run(self, lines, lds):
+        for line in lines:
+            op, rest = line.split(None, 1)
+            if op == "ds_read_b128":
+                m = re.match(r"v\[(\d+):(\d+)\], (\S+) offset:(\d+)", rest)
+                lo, hi, addr, off = int(m.group(1)), int(m.group(2)), m.group(3), int(m.group(4))
+                assert hi == lo + 3
+                base = self.get(addr)
+                for q in range(4):
+                    self.reg["v%d" % (lo + q)] = [lds[(base[j] + off) // 4 + q] for j in range(LANES)]
+                self.loads.append(["v%d" % (lo + q) for q in range(4)])
+                continue
+            if op == "s_waitcnt":
+                n = int(re.match(r"lgkmcnt\((\d+)\)", rest).group(1))
+                self.complete = max(self.complete, len(self.loads) - n)
+                continue
+            if op == "s_nop":
+                self.slot += int(rest) + 1
+                continue
+            args = [x.strip() for x in rest.split(",")]
+            if op == "v_add_u32_dpp":
+                dst, src0 = args[0], args[1]
+                src1, ctrl, rm, bm = args[2].split(None, 1)[0], None, None, None
+                tail = args[2].split(None, 1)[1] + ("," + ",".join(args[3:]) if len(args) > 3 else "")
+                ctrl = "row_half_mirror" if "row_half_mirror" in tail else re.search(r"quad_perm:\[[\d,]+\]", tail).group(0)
+                assert "row_mask:0xf" in tail
+                banks = int(re.search(r"bank_mask:0x([0-9a-f])", tail).group(1), 16)
+                a, b = self.dpp(src0, ctrl), self.get(src1)
+                for r in (src0, src1):
+                    self.check_loaded(r)
+                self.put(dst, [(a[j] + b[j]) & M if a[j] is not None and b[j] is not None else None for j in range(LANES)], banks)
+            elif op == "v_alignbit_b32":
+                d, x, y, k = args
+                assert x == y
+                xs, ks = self.get(x), self.get(k)
+                self.put(d, [rotr(xs[j], ks[j]) for j in range(LANES)])
+            elif op == "v_bitop3_b32":
+                d, x, y = args[0], args[1], args[2]
+                z, table = args[3].split()[0], int(args[3].split("bitop3:")[1], 16)
+                xs, ys, zs = self.get(x), self.get(y), self.get(z)
+                self.put(d, [bitop3(xs[j], ys[j], zs[j], table) for j in range(LANES)])
+            elif op == "v_add3_u32":
+                d, x, y, z = args
+                self.check_loaded(z)
+                xs, ys, zs = self.get(x), self.get(y), self.get(z)
+                self.put(d, [(xs[j] + ys[j] + zs[j]) & M for j in range(LANES)])
+            elif op == "v_add_u32_e32":
+                d, x, y = args
+                xs, ys = self.get(x), self.get(y)
+                self.put(d, [(xs[j] + ys[j]) & M for j in range(LANES)])
+            else:
+                raise AssertionError("opcode the interpreter does not know: " + op)
+            self.slot += 1
+
+
+def test_generated_rounds_equal_sha256_on_four_lane_pairs():
+    lines = asm_lines()
+    assert len(lines) > 600 and lines[0].startswith("ds_read_b128")
     rnd = random.Random(3)
-    for n in (0, 1, 55, 56, 64, 131):
-        msg = bytes(rnd.getrandbits(8) for _ in range(n))
-        padded = msg + b"\x80" + b"\x00" * ((55 - n) % 64) + struct.pack(">Q", 8 * n)
-        st = list(H0)
-        for off in range(0, len(padded), 64):
-            w = list(struct.unpack(">16I", padded[off:off + 64]))
-            for i in range(16, 64):
-                s0 = rotr(w[i - 15], 7) ^ rotr(w[i - 15], 18) ^ (w[i - 15] >> 3)
-                s1 = rotr(w[i - 2], 17) ^ rotr(w[i - 2], 19) ^ (w[i - 2] >> 10)
-                w.append((w[i - 16] + s0 + w[i - 7] + s1) & M)
-            st = pair_compress(st, w)
-        assert struct.pack(">8I", *st) == hashlib.sha256(msg).digest(), n
+    msgs = [bytes(rnd.getrandbits(8) for _ in range(n)) for n in (0, 55, 64, 131)]
+    padded = [m + b"\x80" + b"\x00" * ((55 - len(m)) % 64) + struct.pack(">Q", 8 * len(m)) for m in msgs]
+    nblocks = max(len(p) for p in padded) // 64
+    # lane roles as the kernel sets them: X lanes 0..3 hold (e, f, g, h) of message j, Y lane 7 - j holds (a, b, c, d)
+    is_y = [j >= 4 for j in range(LANES)]
+    slot = [7 - j if is_y[j] else j for j in range(LANES)]
+    state = [list(H0) for _ in msgs]
+    live = [True] * 4
+    for blk in range(nblocks):
+        # LDS: words [0, 16 * 64 * 4) the schedule as [group][slot][4], then a zero region of the same shape
+        lds = [0] * (2 * 16 * 64 * 4)
+        for s_, p in enumerate(padded):
+            if 64 * blk < len(p):
+                w = schedule(struct.unpack(">16I", p[64 * blk:64 * blk + 64]))
+                for t in range(64):
+                    lds[((t // 4) * 64 + s_) * 4 + (t % 4)] = (w[t] + K[t]) & M
+            else:
+                live[s_] = False
+        ops = {"%%%d" % q: [state[slot[j]][q] if is_y[j] else state[slot[j]][4 + q] for j in range(LANES)] for q in range(4)}
+        ops["%4"] = [(16 * 64 * 16 if is_y[j] else 0) + 16 * slot[j] for j in range(LANES)]
+        for name, x, y in (("%5", 6, 2), ("%6", 11, 13), ("%7", 25, 22)):
+            ops[name] = [y if is_y[j] else x for j in range(LANES)]
+        ops["%8"] = [M if is_y[j] else 0 for j in range(LANES)]
+        wave = Wave(ops)
+        wave.written_at = {}
+        wave.run(lines, lds)
+        for j in range(LANES):
+            if live[slot[j]]:
+                for q in range(4):
+                    state[slot[j]][q if is_y[j] else 4 + q] = wave.reg["%%%d" % q][j]
+        for s_, p in enumerate(padded):
+            if 64 * (blk + 1) == len(p):
+                assert struct.pack(">8I", *state[s_]) == hashlib.sha256(msgs[s_]).digest(), len(msgs[s_])
+
+
+def test_consumer_thread_map():
+    """sha_pair_is_y / sha_pair_slot (sha256.cuh): 128 consumer threads -> 64 blob slots x {X, Y}; partners are the lanes j and
+    7 - j of a group of eight; X lanes sit in DPP banks 0 and 2, Y lanes in banks 1 and 3"""
+    seen = set()
+    for tid in range(128):
+        is_y = (tid & 4) != 0
+        slot = (tid >> 3) * 4 + (7 - (tid & 7) if is_y else (tid & 7))
+        partner = (tid & ~7) | (7 - (tid & 7))
+        p_is_y = (partner & 4) != 0
+        p_slot = (partner >> 3) * 4 + (7 - (partner & 7) if p_is_y else (partner & 7))
+        assert p_is_y != is_y and p_slot == slot
+        assert ((tid % 16) // 4) % 2 == (1 if is_y else 0)
+        seen.add((slot, is_y))
+    assert seen == {(s_, y) for s_ in range(64) for y in (False, True)}

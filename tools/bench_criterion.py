@@ -37,7 +37,7 @@ def timeit(fn, min_time=0.6, max_reps=200):
 
 
 def main():
-    window_bits = int(sys.argv[1]) if len(sys.argv) > 1 else 14
+    window_bits = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 0  # 0: the automatic choice (class 22 on an idle part)
     with_cpu = "--no-cpu" not in sys.argv
     s = kateth_amd.Setup.load_json(SETUP, window_bits=window_bits, table_max=True)
     n = SIZES[-1]
