@@ -34,7 +34,7 @@ import os
 # Several HIP streams are live in a run (the engine's copy / side / session streams, the lanes of calls kept in flight) and
 # the runtime multiplexes them onto GPU_MAX_HW_QUEUES hardware queues -- 4 by default: two streams that land on one queue run
 # strictly one after the other (seen: both lanes of `--in-flight 2` on one queue, profiles/r04).  Set before HIP initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 import subprocess
 import sys
 import time

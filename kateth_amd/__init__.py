@@ -12,7 +12,7 @@ import os as _os
 # compute, calls kept in flight by the caller); the runtime multiplexes ALL streams of the process onto GPU_MAX_HW_QUEUES
 # hardware queues -- 4 by default -- and two streams that share a queue run strictly one after the other.  Takes effect when
 # set before HIP initialises (the library's own load-time constructor does the same for non-Python callers).
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 from .kzg import (  # noqa: F401,E402
     BYTES_PER_BLOB,

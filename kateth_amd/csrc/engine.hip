@@ -11,8 +11,10 @@
 // The engine overlaps kernels on several HIP streams; the runtime multiplexes all streams of a process onto
 // GPU_MAX_HW_QUEUES hardware queues (4 by default) and streams that share a queue run one after the other.  The flag is read
 // when HIP initialises (the first API call), so a load-time default is in time for every caller that has not touched HIP yet;
-// an explicit setting in the environment is left alone.
-__attribute__((constructor)) static void kzg_default_hw_queues() { (void)setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+// an explicit setting in the environment is left alone.  16: a process that keeps three calls in flight has the caller's three
+// streams beside a dozen of the engine's own (copy, staging, session streams); with 8 queues two of the three lanes shared a
+// queue in bench.py's default run (+5 % instead of +11 % over one call at a time), with 12, 16 and 24 none did.
+__attribute__((constructor)) static void kzg_default_hw_queues() { (void)setenv("GPU_MAX_HW_QUEUES", "16", 0); }
 
 // ---------------------------------------------------------------------------
 // error plumbing

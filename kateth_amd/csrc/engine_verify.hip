@@ -702,7 +702,7 @@ int32_t verify_phase1_host(const kzg_ctx* ctx, const uint8_t* blobs, const uint8
   }
   const uint64_t nchunks = (n + chunk - 1) / chunk;
   const uint64_t slots = nchunks < KZG_STAGE_SLOTS ? nchunks : KZG_STAGE_SLOTS;
-  // Compute streams the chunks rotate over: TWO.  With a hardware queue per stream (GPU_MAX_HW_QUEUES = 8) four independent
+  // Compute streams the chunks rotate over: TWO.  With a hardware queue per stream (GPU_MAX_HW_QUEUES >= 8) four independent
   // chunk streams put four chunks' hash and evaluation kernels on the chip at once and the LAST chunk's latency-bound hash --
   // the call's critical path: it cannot start before its copy ends -- shares SIMDs with its predecessors' waves: 16.5 instead of
   // 15.0 ms per 4,096 triples (two or three streams: 15.0; one: 18.9; at 16,384 triples all the same, 44.2).  Round 3's four

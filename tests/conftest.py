@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # as kateth_amd/__init__.py: before anything initialises HIP
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # as kateth_amd/__init__.py: before anything initialises HIP
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 TRUSTED_SETUP = os.path.join(GOLDEN, "trusted_setup_4096.json")
