@@ -1022,9 +1022,12 @@ extern "C" int32_t kzg_microbench_fp_mul(const kzg_ctx* ctx, uint64_t lanes, uin
 
 // ISSUE interval of the instruction the hot loops are made of (v_mad_u64_u32: 76-80 % of the MSM, evaluation and decoding
 // streams) with `w` waves per SIMD on the whole chip, and the shader clock that load sustains: 8 INDEPENDENT chains per
-// wave, so no dependent-latency effect is measured.  Occupancy is forced with LDS (a 256-thread workgroup = one wave per
-// SIMD takes 160 KiB / w).  bench.py prices SQ_INSTS_VALU with these two numbers (roofline.valu_issue).
-__global__ __launch_bounds__(256) void k_microbench_valu_issue(uint32_t* out, unsigned long long* ticks, uint32_t iters, uint32_t seed) {
+// wave, so no dependent-latency effect is measured.  Occupancy by construction: ONE workgroup of 4 w waves per CU (it takes nearly
+// all of the CU's LDS, so no second one joins it) -- the waves of a workgroup are resident together, w per SIMD, wherever the
+// dispatcher puts the workgroup.  (Two 256-thread workgroups per CU, as this was first written, are co-resident only if the
+// dispatcher pairs them: in a process with many queues it sometimes ran them one after the other and the figure halved.)
+// bench.py prices SQ_INSTS_VALU with these two numbers (roofline.valu_issue).
+__global__ __launch_bounds__(1024) void k_microbench_valu_issue(uint32_t* out, unsigned long long* ticks, uint32_t iters, uint32_t seed) {
   extern __shared__ uint32_t issue_lds[];
   uint64_t x[8];
   for (int c = 0; c < 8; c++) x[c] = ((uint64_t)(seed + threadIdx.x * 7 + c * 0x9e3779b9u) << 20) | 0x3ff0000000000001ull;
@@ -1045,26 +1048,27 @@ __global__ __launch_bounds__(256) void k_microbench_valu_issue(uint32_t* out, un
   const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
   uint64_t r = 0;
   for (int c = 0; c < 8; c++) r ^= x[c];
-  out[blockIdx.x * 256 + threadIdx.x] = (uint32_t)r ^ (uint32_t)(r >> 32);
+  out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)r ^ (uint32_t)(r >> 32);
   if ((threadIdx.x & 63) == 0) {
-    ticks[2 * (blockIdx.x * 4 + (threadIdx.x >> 6))] = t1 - t0;
-    ticks[2 * (blockIdx.x * 4 + (threadIdx.x >> 6)) + 1] = r1 - r0;
+    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    ticks[2 * wave] = t1 - t0;
+    ticks[2 * wave + 1] = r1 - r0;
   }
 }
 
 extern "C" int32_t kzg_microbench_valu_issue(const kzg_ctx* ctx, uint32_t waves_per_simd, uint32_t iters, double* cycles_per_inst, double* clock_ghz) {
   if (!ctx || !cycles_per_inst || !clock_ghz || waves_per_simd < 1 || waves_per_simd > 4 || iters == 0) return fail(KZG_FAIL_ARGUMENT, "bad argument");
   HIP_TRY(hipSetDevice(ctx->device));
-  const uint32_t blocks = ctx->num_cus * waves_per_simd;
-  const size_t lds = (size_t)(160 * 1024) / waves_per_simd - 1024;  // at most `waves_per_simd` workgroups per CU
+  const uint32_t blocks = ctx->num_cus, threads = 256 * waves_per_simd;
+  const size_t lds = (size_t)(160 * 1024) - 1024;  // one workgroup per CU
   HIP_TRY(hipFuncSetAttribute((const void*)k_microbench_valu_issue, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   uint32_t* d_out = nullptr;
   unsigned long long* d_ticks = nullptr;
-  HIP_TRY(hipMalloc(&d_out, (size_t)blocks * 256 * 4));
-  HIP_TRY(hipMalloc(&d_ticks, (size_t)blocks * 4 * 2 * 8));
-  hipLaunchKernelGGL(k_microbench_valu_issue, dim3(blocks), dim3(256), lds, nullptr, d_out, d_ticks, 64u, 1u);  // warm-up: clocks ramp
-  hipLaunchKernelGGL(k_microbench_valu_issue, dim3(blocks), dim3(256), lds, nullptr, d_out, d_ticks, iters, 1u);
-  std::vector<unsigned long long> t((size_t)blocks * 4 * 2);
+  HIP_TRY(hipMalloc(&d_out, (size_t)blocks * threads * 4));
+  HIP_TRY(hipMalloc(&d_ticks, (size_t)blocks * (threads / 64) * 2 * 8));
+  hipLaunchKernelGGL(k_microbench_valu_issue, dim3(blocks), dim3(threads), lds, nullptr, d_out, d_ticks, 64u, 1u);  // warm-up: clocks ramp
+  hipLaunchKernelGGL(k_microbench_valu_issue, dim3(blocks), dim3(threads), lds, nullptr, d_out, d_ticks, iters, 1u);
+  std::vector<unsigned long long> t((size_t)blocks * (threads / 64) * 2);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipMemcpy(t.data(), d_ticks, t.size() * 8, hipMemcpyDeviceToHost);
   (void)hipFree(d_out);

@@ -228,9 +228,9 @@ def test_point_decoder_at_batch_size_matches_the_oracle_decisions(engine):
 def test_measurement_aids(engine, torch_cuda):
     """kzg_microbench_valu_issue and the clock probe return sane figures (bench.py prices SQ_INSTS_VALU with them)"""
     torch_cuda.cuda.synchronize()  # nothing of an earlier test may share the SIMDs with the timed waves
-    cyc, ghz = min(engine.microbench_valu_issue(2, 4000) for _ in range(3))
+    cyc, ghz = engine.microbench_valu_issue(2, 4000)
     assert 3.5 < cyc < 6.0 and 0.8 < ghz < 3.0, (cyc, ghz)
-    cyc1, _ = min(engine.microbench_valu_issue(1, 4000) for _ in range(3))
+    cyc1, _ = engine.microbench_valu_issue(1, 4000)
     assert cyc1 > cyc - 0.1, (cyc1, cyc)  # a lone wave does not issue faster than two (4.22 against 4.13 cycles measured)
     engine.clock_probe_launch(20000)
     mean, lo, hi = engine.clock_probe_read()
