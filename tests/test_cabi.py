@@ -215,3 +215,21 @@ def test_product_sources_have_one_msm_path():
             assert "KZG_TEST_WINDOW_MSM" not in text and "k_msm_fixed28" not in text, name
     syms = subprocess.check_output(["strings", kzg.library_path()], text=True)
     assert "k_msm_comb28" in syms and "k_msm_fixed" not in syms and "kzg_test_read_wave_times" not in syms
+
+
+def test_library_load_defaults_the_hardware_queue_count(lib):
+    """the load-time constructor (engine.hip, kzg_default_hw_queues) sets GPU_MAX_HW_QUEUES=16 before HIP can initialise, and
+    leaves an explicit setting alone"""
+    import sys
+
+    from kateth_amd import kzg
+
+    LIB = kzg.library_path()
+    # the library binds to the HIP runtime already in the process (no DT_NEEDED): load one first, as a C host program's link line does
+    prog = ("import ctypes, os, sys; ctypes.CDLL('/opt/rocm/lib/libamdhip64.so', mode=ctypes.RTLD_GLOBAL); ctypes.CDLL(sys.argv[1]); "
+            "libc = ctypes.CDLL(None); libc.getenv.restype = ctypes.c_char_p; print((libc.getenv(b'GPU_MAX_HW_QUEUES') or b'').decode())")
+    base = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    got = subprocess.run([sys.executable, "-c", prog, LIB], env=base, capture_output=True, text=True, timeout=120)
+    assert got.returncode == 0 and got.stdout.strip() == "16", (got.stdout, got.stderr[-300:])
+    got = subprocess.run([sys.executable, "-c", prog, LIB], env=dict(base, GPU_MAX_HW_QUEUES="4"), capture_output=True, text=True, timeout=120)
+    assert got.returncode == 0 and got.stdout.strip() == "4", (got.stdout, got.stderr[-300:])
