@@ -203,8 +203,6 @@ static __global__ __launch_bounds__(64) void k_challenge(const uint8_t* __restri
 
 // the PRODUCER wave of the two latency kernels: message schedule (W + K) of block k into wk[k & 1], one block ahead of the
 // consumer(s); one workgroup barrier per block
-// QUADS: the schedule in the layout of the lane-pair rounds (sha256_expand_to_lds_quads)
-template <bool QUADS>
 __device__ __forceinline__ void challenge_producer(uint32_t (*wk)[64 * 64], int lane, const uint8_t* __restrict__ blob, const uint8_t* __restrict__ com) {
   constexpr uint32_t NBLK = 2050;
   uint32_t w[16], nxt[16];
@@ -226,10 +224,7 @@ __device__ __forceinline__ void challenge_producer(uint32_t (*wk)[64 * 64], int 
   load_be_words16(nxt + 12, blob + 80);
 #pragma unroll 1
   for (uint32_t k = 0; k < NBLK; k++) {
-    if (QUADS)
-      sha256_expand_to_lds_quads(wk[k & 1], lane, w);
-    else
-      sha256_expand_to_lds(wk[k & 1], lane, w);
+    sha256_expand_to_lds(wk[k & 1], lane, w);
 #pragma unroll
     for (int q = 0; q < 16; q++) w[q] = nxt[q];
     const uint32_t k2 = k + 2;  // the block after next
@@ -271,7 +266,7 @@ __device__ __forceinline__ void challenge_split_workgroup(uint32_t (*wk)[64 * 64
   const uint8_t* com = commitments48 + b * 48;
   constexpr uint32_t NBLK = 2050;
   if (producer) {
-    challenge_producer<false>(wk, lane, blob, com);
+    challenge_producer(wk, lane, blob, com);
   } else {
     sha256_state s;
     sha256_init(s);
@@ -295,22 +290,86 @@ static __global__ __launch_bounds__(128) void k_challenge_split(const uint8_t* _
   asm volatile("" ::: "v255", "a8");  // one wave per SIMD, whatever the dispatcher would like to pack (see k_challenge_pair)
   challenge_split_workgroup(wk, blockIdx.x, blobs, commitments48, n, z_plain);
 }
-// Batches small enough for THREE waves per 64 blobs to have a SIMD each (n <= 16,384 on 256 CUs; single items): the rounds
-// run on lane pairs (sha256_rounds_pair: 10 instead of 14 instructions per round on the critical chain), so 64 blobs
-// take two consumer waves + the producer wave.  Y lanes read their W + K from an all-zero LDS region.
-__device__ __forceinline__ void challenge_pair_workgroup(uint32_t (*wk)[64 * 64], uint32_t* zeros, uint64_t wg, const uint8_t* __restrict__ blobs,
+// Batches small enough for FOUR waves per 64 blobs to have a SIMD each (n <= 16,384 on 256 CUs; single items): the rounds
+// run on lane pairs (sha256.cuh, sha_pair_asm.cuh: 10 instead of 14 instructions per round on the critical chain), so 64 blobs
+// take two consumer waves + two producer waves.
+// FOUR blocks per workgroup barrier (round 4): the producer expands the schedules of blocks 4s .. 4s+3 into one of two buffer
+// sets while the consumers run the four blocks of the other set as ONE generated statement (sha256_blocks_pair_asm4), which
+// reads every block's W + K from LDS during the block before it.  With a barrier per block the LDS latency of a block's first
+// reads and the barrier itself were exposed 2,050 times per hash (~300 of 3,070 cycles per block); now 513 times.
+constexpr uint32_t SHA_PAIR_STEP = 4;                                  // blocks per barrier
+constexpr uint32_t SHA_PAIR_BLOCK_QUADS = 16 * SHA_PAIR_ROW_QUADS;     // [16 rows][64 slots + the Y lanes' zero quad]
+constexpr uint32_t SHA_PAIR_LDS_BYTES = 2 * SHA_PAIR_STEP * SHA_PAIR_BLOCK_QUADS * 16;  // 133,120: dynamic (launch + hipFuncSetAttribute)
+constexpr uint32_t SHA_PAIR_STEPS = 2050 / SHA_PAIR_STEP;              // 512 full steps, then blocks 2048 and 2049
+
+// message words of the TWO blocks producer j (0 / 1) expands in step s -- blocks 4s + 2j and 4s + 2j + 1; in the last step
+// (s = 512) block 2048 + j alone -- of one blob's challenge message
+//   "FSBLOBVERIFY_V1_" || u128_be(4096) || blob || commitment48 || padding:   block k >= 1 covers blob bytes [64k - 32, 64k + 32)
+__device__ __forceinline__ void challenge_step_words(uint32_t* w /* 32 */, uint32_t s, uint32_t j, const uint8_t* __restrict__ blob,
+                                                     const uint8_t* __restrict__ com) {
+  if (s == 0 && j == 0) {
+    w[0] = 0x4653424cu;  // "FSBL"
+    w[1] = 0x4f425645u;  // "OBVE"
+    w[2] = 0x52494659u;  // "RIFY"
+    w[3] = 0x5f56315fu;  // "_V1_"
+    w[4] = 0;
+    w[5] = 0;
+    w[6] = 0;
+    w[7] = 4096;
+#pragma unroll
+    for (int q = 0; q < 6; q++) load_be_words16(w + 8 + 4 * q, blob + 16 * q);
+  } else if (s < SHA_PAIR_STEPS) {
+    const uint8_t* src = blob + 256ull * s - 32 + 128 * j;
+#pragma unroll
+    for (int q = 0; q < 8; q++) load_be_words16(w + 4 * q, src + 16 * q);
+  } else if (j == 0) {  // block 2048: last 32 blob bytes || first 32 commitment bytes
+    load_be_words16(w, blob + 131040);
+    load_be_words16(w + 4, blob + 131056);
+    load_be_words16(w + 8, com);
+    load_be_words16(w + 12, com + 16);
+  } else {  // block 2049: last 16 commitment bytes, padding, bit length of 131,152 bytes
+    load_be_words16(w, com + 32);
+    w[4] = 0x80000000u;
+#pragma unroll
+    for (int q = 5; q < 15; q++) w[q] = 0;
+    w[15] = 131152u * 8u;
+  }
+}
+
+__device__ __forceinline__ void challenge_pair_workgroup(uint4* sched, uint64_t wg, const uint8_t* __restrict__ blobs,
                                                          const uint8_t* __restrict__ commitments48, uint64_t n, fr_t* __restrict__ z_plain) {
   issue_priority_latency();  // a latency-bound stream: never behind an MSM wave of another stream (issue_fair.cuh)
-  const int tid = threadIdx.x;  // 192 threads: [0, 128) consumer lane pairs, [128, 192) producer
+  // 256 threads, a wave per SIMD: [0, 128) consumer lane pairs, [128, 192) producer 0, [192, 256) producer 1 -- each producer
+  // expands two of a step's four blocks for the 64 blobs (one producer wave needs as many issue slots per block as the rounds do,
+  // plus its global loads and LDS writes: alone it was what the consumers waited for)
+  const int tid = threadIdx.x;
   const bool producer = tid >= 128;
-  const int p = producer ? tid - 128 : sha_pair_slot(tid);  // blob within the workgroup
+  const uint32_t pj = producer ? (uint32_t)(tid - 128) >> 6 : 0u;
+  const int p = producer ? (tid & 63) : sha_pair_slot(tid);  // blob within the workgroup
   uint64_t b = wg * 64 + p;
   const bool live = b < n;
   if (!live) b = n - 1;  // idle lanes shadow the last blob: every wave must reach every barrier
-  for (int i = tid; i < 64 * 64; i += 192) zeros[i] = 0;
+  if (tid < (int)(2 * SHA_PAIR_STEP * 16)) sched[tid * SHA_PAIR_ROW_QUADS + 64] = make_uint4(0, 0, 0, 0);  // the Y lanes' quad of every row
   __syncthreads();
   if (producer) {
-    challenge_producer<true>(wk, p, blobs + b * 131072ull, commitments48 + b * 48);
+    const uint8_t* blob = blobs + b * 131072ull;
+    const uint8_t* com = commitments48 + b * 48;
+    uint32_t cur[32], nxt[32];
+    challenge_step_words(nxt, 0, pj, blob, com);
+#pragma unroll 1
+    for (uint32_t s = 0; s <= SHA_PAIR_STEPS; s++) {
+#pragma unroll
+      for (int q = 0; q < 32; q++) cur[q] = nxt[q];
+      if (s < SHA_PAIR_STEPS) challenge_step_words(nxt, s + 1, pj, blob, com);  // fetched while this step is expanded
+      uint4* set = sched + (s & 1u) * SHA_PAIR_STEP * SHA_PAIR_BLOCK_QUADS;
+      if (s < SHA_PAIR_STEPS) {
+        sha256_expand_to_lds_quads(set + (2 * pj) * SHA_PAIR_BLOCK_QUADS, p, cur);
+        sha256_expand_to_lds_quads(set + (2 * pj + 1) * SHA_PAIR_BLOCK_QUADS, p, cur + 16);
+      } else {
+        sha256_expand_to_lds_quads(set + pj * SHA_PAIR_BLOCK_QUADS, p, cur);
+      }
+      __syncthreads();
+    }
   } else {
     const bool is_y = sha_pair_is_y(tid);
     sha256_state init;
@@ -318,15 +377,19 @@ __device__ __forceinline__ void challenge_pair_workgroup(uint32_t (*wk)[64 * 64]
     sha256_half st;
 #pragma unroll
     for (int q = 0; q < 4; q++) st.s[q] = is_y ? init.h[q] : init.h[4 + q];
-    // the lane's slot in the schedule buffer of even and of odd blocks (Y: the zero region both times), toggled by a subtraction
-    const uint32_t even = sha_lds_address((is_y ? zeros : wk[0]) + 4 * p), both = even + sha_lds_address((is_y ? zeros : wk[1]) + 4 * p);
-    uint32_t quads = even;
+    const uint32_t k1 = is_y ? 2u : 6u, k2 = is_y ? 13u : 11u, k3 = is_y ? 22u : 25u, ymask = is_y ? 0xffffffffu : 0u;
+    // the lane's quad in row 0 of block 0 of the even / odd set (Y: the zero quad), toggled by a subtraction
+    constexpr uint32_t BLK = SHA_PAIR_BLOCK_QUADS * 16;
+    const uint32_t even = sha_lds_address(sched + (is_y ? 64 : p)), both = 2u * even + SHA_PAIR_STEP * BLK;
+    uint32_t q0 = even;
 #pragma unroll 1
-    for (uint32_t k = 0; k < 2050; k++) {
+    for (uint32_t s = 0; s < SHA_PAIR_STEPS; s++) {
       __syncthreads();
-      sha256_rounds_pair(st, quads, is_y);
-      quads = both - quads;
+      sha256_blocks_pair_asm4(st.s[0], st.s[1], st.s[2], st.s[3], q0, q0 + BLK, q0 + 2 * BLK, q0 + 3 * BLK, k1, k2, k3, ymask);
+      q0 = both - q0;
     }
+    __syncthreads();
+    sha256_blocks_pair_asm2(st.s[0], st.s[1], st.s[2], st.s[3], q0, q0 + BLK, k1, k2, k3, ymask);
     uint32_t other[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) other[q] = sha_pair_swap(st.s[q]);
@@ -342,27 +405,25 @@ __device__ __forceinline__ void challenge_pair_workgroup(uint32_t (*wk)[64 * 64]
     }
   }
 }
-static __global__ __launch_bounds__(192) void k_challenge_pair(const uint8_t* __restrict__ blobs, const uint8_t* __restrict__ commitments48, uint64_t n,
+extern __shared__ uint4 sha_pair_lds[];  // SHA_PAIR_LDS_BYTES (dynamic: above the 64-KiB static limit)
+static __global__ __launch_bounds__(256) void k_challenge_pair(const uint8_t* __restrict__ blobs, const uint8_t* __restrict__ commitments48, uint64_t n,
                                                                fr_t* __restrict__ z_plain) {
-  __shared__ alignas(16) uint32_t wk[2][64 * 64];
-  __shared__ alignas(16) uint32_t zeros[64 * 64];
   // Claim more than half of a SIMD's register file (nothing is stored there): a second workgroup then cannot put a wave next
   // to one of this kernel's on the same SIMD, so the dispatcher has to give every workgroup a CU of its own (256 workgroups
-  // = 16,384 blobs on 256 CUs).  Left to itself it paired workgroups on some CUs and the hash took 4.7 instead of 3.7 ms.
+  // = 16,384 blobs on 256 CUs; the 130 KiB of LDS say the same).  Left to itself it paired workgroups on some CUs and the hash
+  // took 4.7 instead of 3.7 ms.
   asm volatile("" ::: "v255", "a8");
-  challenge_pair_workgroup(wk, zeros, blockIdx.x, blobs, commitments48, n, z_plain);
+  challenge_pair_workgroup(sha_pair_lds, blockIdx.x, blobs, commitments48, n, z_plain);
 }
-static __global__ __launch_bounds__(192) void k_challenge_pair_and_decode(const uint8_t* __restrict__ blobs, const uint8_t* __restrict__ commitments48,
+static __global__ __launch_bounds__(256) void k_challenge_pair_and_decode(const uint8_t* __restrict__ blobs, const uint8_t* __restrict__ commitments48,
                                                                           uint64_t n, fr_t* __restrict__ z_plain, uint32_t sha_wgs,
                                                                           const uint8_t* __restrict__ in_a, uint64_t n_a, int32_t* __restrict__ status_a,
                                                                           const uint8_t* __restrict__ in_b, uint64_t n_b, int32_t* __restrict__ status_b,
                                                                           uint4* __restrict__ affine, uint8_t* __restrict__ inf) {
-  __shared__ alignas(16) uint32_t wk[2][64 * 64];
-  __shared__ alignas(16) uint32_t zeros[64 * 64];
   if (blockIdx.x < sha_wgs) {
-    challenge_pair_workgroup(wk, zeros, blockIdx.x, blobs, commitments48, n, z_plain);
+    challenge_pair_workgroup(sha_pair_lds, blockIdx.x, blobs, commitments48, n, z_plain);
   } else {
-    const uint64_t t = (uint64_t)(blockIdx.x - sha_wgs) * 192 + threadIdx.x;
+    const uint64_t t = (uint64_t)(blockIdx.x - sha_wgs) * 256 + threadIdx.x;
     g1_decompress_item(t, in_a, n_a, status_a, in_b, n_b, status_b, affine, inf);
   }
 }

@@ -287,7 +287,10 @@ static inline void launch_challenge(const kzg_ctx* ctx, hipStream_t st, const ui
   uint64_t split_max = (uint64_t)ctx->num_cus * 4 * 64 / 2;  // 2 waves per 64 blobs, one wave per SIMD: 32,768 on 256 CUs
   if (ctx->knobs.challenge_split_max) split_max = ctx->knobs.challenge_split_max;
   if ((uint64_t)blocks_for(n, 64) <= (uint64_t)ctx->num_cus && !ctx->knobs.challenge_split_max)  // one workgroup per CU
-    hipLaunchKernelGGL(k_challenge_pair, dim3(blocks_for(n, 64)), dim3(192), 0, st, blobs, commitments48, n, z);  // three waves per 64 blobs, a SIMD each
+  {  // four waves per 64 blobs, a SIMD each; 130 KiB of dynamic LDS (two sets of four block schedules)
+    (void)hipFuncSetAttribute((const void*)k_challenge_pair, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SHA_PAIR_LDS_BYTES);
+    hipLaunchKernelGGL(k_challenge_pair, dim3(blocks_for(n, 64)), dim3(256), SHA_PAIR_LDS_BYTES, st, blobs, commitments48, n, z);
+  }
   else if (n <= split_max)
     hipLaunchKernelGGL(k_challenge_split, dim3(blocks_for(n, 64)), dim3(128), 0, st, blobs, commitments48, n, z);
   else
@@ -301,18 +304,19 @@ constexpr uint64_t KZG_FUSED_PREP_MAX = 16384;  // the two-wave kernel's limit: 
 // runs alone -- still on lane pairs up to one workgroup per CU = 16,384 blobs -- and the points are decoded beside the evaluation.
 static inline bool fused_prep_fits(const kzg_ctx* ctx, uint64_t n_blobs, uint64_t n_points) {
   if (ctx->knobs.challenge_split_max) return n_blobs <= KZG_FUSED_PREP_MAX;  // tests force the two-wave / one-lane kernels
-  return (uint64_t)blocks_for(n_blobs, 64) + blocks_for(n_points, 192) <= (uint64_t)ctx->num_cus;
+  return (uint64_t)blocks_for(n_blobs, 64) + blocks_for(n_points, 256) <= (uint64_t)ctx->num_cus;
 }
 static inline void launch_challenge_and_decode(const kzg_ctx* ctx, hipStream_t st, const uint8_t* blobs, const uint8_t* commitments48, uint64_t n, fr_t* z,
                                                const uint8_t* in_a, uint64_t n_a, int32_t* status_a, const uint8_t* in_b, uint64_t n_b,
                                                int32_t* status_b, uint4* affine, uint8_t* inf) {
   ProfScope ps(ctx, PROF_CHALLENGE, st);
   const uint32_t sha_wgs = (uint32_t)blocks_for(n, 64);
-  if ((uint64_t)sha_wgs + blocks_for(n_a + n_b, 192) <= (uint64_t)ctx->num_cus && !ctx->knobs.challenge_split_max) {
-    // every wave still gets a SIMD of its own with three hash waves per 64 blobs: the rounds run on lane pairs
-    const uint32_t dec_wgs = (uint32_t)blocks_for(n_a + n_b, 192);
-    hipLaunchKernelGGL(k_challenge_pair_and_decode, dim3(sha_wgs + dec_wgs), dim3(192), 0, st, blobs, commitments48, n, z, sha_wgs, in_a, n_a, status_a,
-                       in_b, n_b, status_b, affine, inf);
+  if ((uint64_t)sha_wgs + blocks_for(n_a + n_b, 256) <= (uint64_t)ctx->num_cus && !ctx->knobs.challenge_split_max) {
+    // every wave still gets a SIMD of its own with four hash waves per 64 blobs: the rounds run on lane pairs
+    const uint32_t dec_wgs = (uint32_t)blocks_for(n_a + n_b, 256);
+    (void)hipFuncSetAttribute((const void*)k_challenge_pair_and_decode, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SHA_PAIR_LDS_BYTES);
+    hipLaunchKernelGGL(k_challenge_pair_and_decode, dim3(sha_wgs + dec_wgs), dim3(256), SHA_PAIR_LDS_BYTES, st, blobs, commitments48, n, z, sha_wgs, in_a,
+                       n_a, status_a, in_b, n_b, status_b, affine, inf);
     return;
   }
   const uint32_t dec_wgs = (uint32_t)blocks_for(n_a + n_b, 128);

@@ -138,13 +138,14 @@ __device__ __forceinline__ void sha256_expand_to_lds(uint32_t* __restrict__ wk /
     wk[i * 64 + lane] = wi + sha256_k(i);
   }
 }
-// the same schedule in the layout of the lane-pair rounds: wk as [16 groups][64 slots] uint4, group t / 4 holds W[t] + K[t] of
-// four consecutive rounds (one ds_write_b128 per group here, one ds_read_b128 per group in sha256_rounds_pair_asm)
-__device__ __forceinline__ void sha256_expand_to_lds_quads(uint32_t* __restrict__ wk /* [16][64][4] */, int slot, const uint32_t* win /* 16 words */) {
+// the same schedule in the layout of the lane-pair rounds: wk as [16 rows][SHA_PAIR_ROW_QUADS] uint4, row t / 4 holds
+// W[t] + K[t] of four consecutive rounds for 64 slots (one ds_write_b128 per row here, one ds_read_b128 per row in
+// sha_pair_asm.cuh); the row's last quad stays zero (the Y lanes read it)
+__device__ __forceinline__ void sha256_expand_to_lds_quads(uint4* __restrict__ wk, int slot, const uint32_t* win /* 16 words */) {
   uint32_t w[16];
 #pragma unroll
   for (int i = 0; i < 16; i++) w[i] = win[i];
-  uint4* out = reinterpret_cast<uint4*>(wk) + slot;
+  uint4* out = wk + slot;
 #pragma unroll
   for (int g = 0; g < 16; g++) {
     uint32_t q[4];
@@ -163,7 +164,7 @@ __device__ __forceinline__ void sha256_expand_to_lds_quads(uint32_t* __restrict_
       }
       q[j] = wi + sha256_k(i);
     }
-    out[g * 64] = make_uint4(q[0], q[1], q[2], q[3]);
+    out[g * SHA_PAIR_ROW_QUADS] = make_uint4(q[0], q[1], q[2], q[3]);
   }
 }
 __device__ __forceinline__ void sha256_rounds_from_lds(sha256_state& s, const uint32_t* __restrict__ wk, int lane) {
@@ -208,8 +209,9 @@ __device__ __forceinline__ void sha256_rounds_from_lds(sha256_state& s, const ui
 //   n  = mirror(a3) + t      X banks only: e' = d + T1 (d is Y's a3)
 //   n  = mirror(t) + t       Y banks only: a' = T1 + T2
 // 10 instructions per round on the chain that bounds a single hash (14 on one lane; 11 with selects on quad_perm pairs, the
-// form of rounds 2-3).  The rounds themselves are generated assembly (sha_pair_asm.cuh, tools/gen_sha_pair_asm.py): a lone
-// wave pays an issue slot for every s_nop the compiler puts around a DPP hazard it cannot schedule away.
+// form of rounds 2-3).  The rounds themselves are generated assembly (sha_pair_asm.cuh, tools/gen_sha_pair_asm.py:
+// sha256_blocks_pair_asm1 / 2 / 4 for one, two and four consecutive blocks): a lone wave pays an issue slot for every s_nop the
+// compiler puts around a DPP hazard it cannot schedule away.
 struct sha256_half {
   uint32_t s[4];  // X: e, f, g, h      Y: a, b, c, d
 };
@@ -221,13 +223,6 @@ __device__ __forceinline__ uint32_t sha_pair_swap(uint32_t v) {
 }
 __device__ __forceinline__ uint32_t sha_lds_address(const void* p) {
   return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
-}
-// one block; quads_lds: sha_lds_address of this lane's slot in the block's [16][64] uint4 schedule (X) or in the zero region of the
-// same shape (Y)
-__device__ __forceinline__ void sha256_rounds_pair(sha256_half& st, uint32_t quads_lds, bool is_y) {
-  const uint32_t k1 = is_y ? 2u : 6u, k2 = is_y ? 13u : 11u, k3 = is_y ? 22u : 25u;
-  const uint32_t ymask = is_y ? 0xffffffffu : 0u;
-  sha256_rounds_pair_asm(st.s[0], st.s[1], st.s[2], st.s[3], quads_lds, k1, k2, k3, ymask);
 }
 #endif
 

@@ -1,4 +1,4 @@
-"""The lane-pair SHA-256 rounds (kateth_amd/csrc/sha256.cuh, sha256_rounds_pair; the rounds themselves are generated assembly:
+"""The lane-pair SHA-256 rounds (kateth_amd/csrc/sha256.cuh, "the 64 rounds on a PAIR of lanes"; the rounds themselves are generated assembly:
 kateth_amd/csrc/sha_pair_asm.cuh, tools/gen_sha_pair_asm.py) are device-only (DPP lane exchange) and are covered end to end by the
 GPU parity tests.  Here, on the CPU:
   * Maj(a, b, c) = Ch(~(a ^ b), b, c);
@@ -14,6 +14,8 @@ import os
 import re
 import random
 import struct
+
+import pytest
 
 M = 0xFFFFFFFF
 K = [
@@ -74,10 +76,16 @@ def schedule(block16):
 
 ASM = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "kateth_amd", "csrc", "sha_pair_asm.cuh")
 LANES = 8  # one half row: lanes 0-3 are DPP bank 0 (X), lanes 4-7 bank 1 (Y); lane j's partner is 7 - j
+ROW_QUADS = 65  # a schedule row: 64 slots + the zero quad of the Y lanes
+BLOCK_WORDS = 16 * ROW_QUADS * 4
 
 
-def asm_lines():
-    return [m.group(1) for m in re.finditer(r'^\s*"([^"]+?)\\n\\t"', open(ASM).read(), re.M)]
+def asm_lines(nb):
+    """the instruction lines of sha256_blocks_pair_asm<nb>"""
+    text = open(ASM).read()
+    start = text.index("void sha256_blocks_pair_asm%d(" % nb)
+    body = text[start:text.index('      : "+v"(a0)', start)]
+    return [m.group(1) for m in re.finditer(r'^\s*"([^"]+?)\\n\\t"', body, re.M)]
 
 
 class Wave:
@@ -168,43 +176,45 @@ class Wave:
             self.slot += 1
 
 
-def test_generated_rounds_equal_sha256_on_four_lane_pairs():
-    lines = asm_lines()
-    assert len(lines) > 600 and lines[0].startswith("ds_read_b128")
-    rnd = random.Random(3)
-    msgs = [bytes(rnd.getrandbits(8) for _ in range(n)) for n in (0, 55, 64, 131)]
-    padded = [m + b"\x80" + b"\x00" * ((55 - len(m)) % 64) + struct.pack(">Q", 8 * len(m)) for m in msgs]
-    nblocks = max(len(p) for p in padded) // 64
-    # lane roles as the kernel sets them: X lanes 0..3 hold (e, f, g, h) of message j, Y lane 7 - j holds (a, b, c, d)
+def run_statement(nb, state, blocks_per_slot):
+    """one generated statement over nb blocks: state[slot] = 8 chaining words, blocks_per_slot[slot] = nb lists of 16 message words"""
+    lines = asm_lines(nb)
+    assert lines[0].startswith("ds_read_b128") and len(lines) > 600 * nb
     is_y = [j >= 4 for j in range(LANES)]
     slot = [7 - j if is_y[j] else j for j in range(LANES)]
+    lds = [0] * (nb * BLOCK_WORDS)
+    for s_ in range(4):
+        for blk in range(nb):
+            w = schedule(blocks_per_slot[s_][blk])
+            for t in range(64):
+                lds[blk * BLOCK_WORDS + ((t // 4) * ROW_QUADS + s_) * 4 + (t % 4)] = (w[t] + K[t]) & M
+    ops = {"%%%d" % q: [state[slot[j]][q] if is_y[j] else state[slot[j]][4 + q] for j in range(LANES)] for q in range(4)}
+    for blk in range(nb):
+        ops["%%%d" % (4 + blk)] = [4 * (blk * BLOCK_WORDS + 4 * (64 if is_y[j] else slot[j])) for j in range(LANES)]
+    for q, (x, y) in enumerate(((6, 2), (11, 13), (25, 22))):
+        ops["%%%d" % (4 + nb + q)] = [y if is_y[j] else x for j in range(LANES)]
+    ops["%%%d" % (7 + nb)] = [M if is_y[j] else 0 for j in range(LANES)]
+    wave = Wave(ops)
+    wave.run(lines, lds)
+    assert wave.complete == len(wave.loads), "reads still outstanding at the end of the statement"
+    for j in range(LANES):
+        for q in range(4):
+            state[slot[j]][q if is_y[j] else 4 + q] = wave.reg["%%%d" % q][j]
+
+
+@pytest.mark.parametrize("nb", [1, 2, 4])
+def test_generated_blocks_equal_sha256_on_four_lane_pairs(nb):
+    rnd = random.Random(3 + nb)
+    # four messages of 8 blocks after padding (448 + 55 bytes and shorter ones padded with whole zero blocks is not SHA: so four
+    # messages of the SAME padded length, different content)
+    msgs = [bytes(rnd.getrandbits(8) for _ in range(64 * 8 - 9 - k)) for k in range(4)]
+    padded = [m + b"\x80" + b"\x00" * ((55 - len(m)) % 64) + struct.pack(">Q", 8 * len(m)) for m in msgs]
+    assert all(len(p) == 64 * 8 for p in padded)
     state = [list(H0) for _ in msgs]
-    live = [True] * 4
-    for blk in range(nblocks):
-        # LDS: words [0, 16 * 64 * 4) the schedule as [group][slot][4], then a zero region of the same shape
-        lds = [0] * (2 * 16 * 64 * 4)
-        for s_, p in enumerate(padded):
-            if 64 * blk < len(p):
-                w = schedule(struct.unpack(">16I", p[64 * blk:64 * blk + 64]))
-                for t in range(64):
-                    lds[((t // 4) * 64 + s_) * 4 + (t % 4)] = (w[t] + K[t]) & M
-            else:
-                live[s_] = False
-        ops = {"%%%d" % q: [state[slot[j]][q] if is_y[j] else state[slot[j]][4 + q] for j in range(LANES)] for q in range(4)}
-        ops["%4"] = [(16 * 64 * 16 if is_y[j] else 0) + 16 * slot[j] for j in range(LANES)]
-        for name, x, y in (("%5", 6, 2), ("%6", 11, 13), ("%7", 25, 22)):
-            ops[name] = [y if is_y[j] else x for j in range(LANES)]
-        ops["%8"] = [M if is_y[j] else 0 for j in range(LANES)]
-        wave = Wave(ops)
-        wave.written_at = {}
-        wave.run(lines, lds)
-        for j in range(LANES):
-            if live[slot[j]]:
-                for q in range(4):
-                    state[slot[j]][q if is_y[j] else 4 + q] = wave.reg["%%%d" % q][j]
-        for s_, p in enumerate(padded):
-            if 64 * (blk + 1) == len(p):
-                assert struct.pack(">8I", *state[s_]) == hashlib.sha256(msgs[s_]).digest(), len(msgs[s_])
+    for first in range(0, 8, nb):
+        run_statement(nb, state, [[struct.unpack(">16I", p[64 * (first + k):64 * (first + k) + 64]) for k in range(nb)] for p in padded])
+    for s_, m in enumerate(msgs):
+        assert struct.pack(">8I", *state[s_]) == hashlib.sha256(m).digest()
 
 
 def test_consumer_thread_map():
