@@ -299,8 +299,8 @@ static inline void launch_challenge(const kzg_ctx* ctx, hipStream_t st, const ui
 
 // Small batches: challenges of n blobs and decoding of n_a + n_b points in one launch (k_challenge_and_decode).
 constexpr uint64_t KZG_FUSED_PREP_MAX = 16384;  // the two-wave kernel's limit: 512 hash waves + 512 decode waves (verify), one wave per SIMD on 256 CUs
-// Hash and decode in one launch only while every workgroup gets a CU of its own (the lane-pair kernel's three-wave workgroups
-// share SIMDs as soon as two land on one CU: measured 4.5 ms instead of 3.7 ms per hash at 12,288 blobs); beyond that the hash
+// Hash and decode in one launch only while every workgroup gets a CU of its own (the lane-pair kernel's workgroups take a CU
+// each -- four waves, 130 KiB of LDS; in round 3's three-wave form two on one CU shared SIMDs: 4.5 ms instead of 3.7 ms per hash at 12,288 blobs); beyond that the hash
 // runs alone -- still on lane pairs up to one workgroup per CU = 16,384 blobs -- and the points are decoded beside the evaluation.
 static inline bool fused_prep_fits(const kzg_ctx* ctx, uint64_t n_blobs, uint64_t n_points) {
   if (ctx->knobs.challenge_split_max) return n_blobs <= KZG_FUSED_PREP_MAX;  // tests force the two-wave / one-lane kernels

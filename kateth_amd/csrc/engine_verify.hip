@@ -489,8 +489,8 @@ static int32_t phase1_items(kzg_verify_session* s, const uint8_t* blobs, const u
     // 19.2-20.5 instead of 18.1 ms per 65,536 triples, profiles/r03/verify_cohash_traded_priority_rejected.json.)
     const uint64_t hash_wgs = blocks_for(m, 64);
     const uint64_t split_max = ctx->knobs.challenge_split_max ? ctx->knobs.challenge_split_max : (uint64_t)ctx->num_cus * 128;
-    // lane-pair kernel (three waves per 64 blobs), producer/consumer pairs (two), one lane per blob (one wave, 292 VGPRs)
-    const uint64_t hash_waves = hash_wgs <= ctx->num_cus ? 3 * hash_wgs : (m <= split_max ? 2 * hash_wgs : hash_wgs);
+    // lane-pair kernel (four waves per 64 blobs), producer/consumer pairs (two), one lane per blob (one wave, 292 VGPRs)
+    const uint64_t hash_waves = hash_wgs <= ctx->num_cus ? 4 * hash_wgs : (m <= split_max ? 2 * hash_wgs : hash_wgs);
     const uint64_t simds = (uint64_t)ctx->num_cus * 4;
     uint64_t beside = 0;  // points decoded beside the hash
     if (decode_here && !ctx->knobs.verify_serial && !ctx->knobs.challenge_split_max && hash_waves + 64 <= simds)
