@@ -420,6 +420,9 @@ static __global__ __launch_bounds__(256) void k_challenge_pair_and_decode(const 
                                                                           const uint8_t* __restrict__ in_a, uint64_t n_a, int32_t* __restrict__ status_a,
                                                                           const uint8_t* __restrict__ in_b, uint64_t n_b, int32_t* __restrict__ status_b,
                                                                           uint4* __restrict__ affine, uint8_t* __restrict__ inf) {
+  // as in k_challenge_pair: more than half of a SIMD's registers, so that the four waves of a workgroup land on four SIMDs (at 225
+  // VGPRs two of them fit on one); the decoding workgroups lose nothing, a CU holds one workgroup of this launch anyway (LDS)
+  asm volatile("" ::: "v255", "a8");
   if (blockIdx.x < sha_wgs) {
     challenge_pair_workgroup(sha_pair_lds, blockIdx.x, blobs, commitments48, n, z_plain);
   } else {

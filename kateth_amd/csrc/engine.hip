@@ -1066,7 +1066,9 @@ extern "C" int32_t kzg_microbench_valu_issue(const kzg_ctx* ctx, uint32_t waves_
   unsigned long long* d_ticks = nullptr;
   HIP_TRY(hipMalloc(&d_out, (size_t)blocks * threads * 4));
   HIP_TRY(hipMalloc(&d_ticks, (size_t)blocks * (threads / 64) * 2 * 8));
-  hipLaunchKernelGGL(k_microbench_valu_issue, dim3(blocks), dim3(threads), lds, nullptr, d_out, d_ticks, 64u, 1u);  // warm-up: clocks ramp
+  // warm-up: ~20 ms of the same load, so that the timed launch does not run while the clocks come up from an idle chip (readings
+  // taken right after a long idle stretch were off by factors: tests/test_gpu_round4.py::test_measurement_aids)
+  hipLaunchKernelGGL(k_microbench_valu_issue, dim3(blocks), dim3(threads), lds, nullptr, d_out, d_ticks, iters > 20000u ? iters : 20000u, 1u);
   hipLaunchKernelGGL(k_microbench_valu_issue, dim3(blocks), dim3(threads), lds, nullptr, d_out, d_ticks, iters, 1u);
   std::vector<unsigned long long> t((size_t)blocks * (threads / 64) * 2);
   hipError_t e = hipGetLastError();
