@@ -23,6 +23,13 @@ __global__ __launch_bounds__(64) void k(uint32_t* out, unsigned long long* ticks
       if (P == 5) asm volatile("v_alignbit_b32 %0, %0, %0, %1\n\tv_alignbit_b32 %0, %0, %0, %1" : "+v"(x) : "v"(y));
       if (P == 6) asm volatile("v_add3_u32 %0, %0, %3, %4\n\tv_bitop3_b32 %1, %1, %3, %4 bitop3:0x96\n\tv_bitop3_b32 %2, %2, %3, %4 bitop3:0x96" : "+v"(x), "+v"(w), "+v"(v) : "v"(y), "v"(z));
       if (P == 7) asm volatile("v_bitop3_b32 %0, %0, %3, %4 bitop3:0x96\n\tv_bitop3_b32 %1, %1, %3, %4 bitop3:0x96\n\tv_bitop3_b32 %2, %2, %3, %4 bitop3:0x96" : "+v"(x), "+v"(w), "+v"(v) : "v"(y), "v"(z));
+      // explicit registers: do three VGPR sources from ONE register bank (index mod 4) cost more than three from different banks?
+      if (P == 9) asm volatile("v_bitop3_b32 v40, v40, v44, v48 bitop3:0x96\n\tv_bitop3_b32 v40, v40, v44, v48 bitop3:0x96\n\tv_bitop3_b32 v40, v40, v44, v48 bitop3:0x96" ::: "v40", "v44", "v48");
+      if (P == 10) asm volatile("v_bitop3_b32 v40, v40, v45, v50 bitop3:0x96\n\tv_bitop3_b32 v40, v40, v45, v50 bitop3:0x96\n\tv_bitop3_b32 v40, v40, v45, v50 bitop3:0x96" ::: "v40", "v45", "v50");
+      if (P == 11) asm volatile("v_add3_u32 v40, v40, v44, v48\n\tv_add3_u32 v40, v40, v44, v48\n\tv_add3_u32 v40, v40, v44, v48" ::: "v40", "v44", "v48");
+      if (P == 12) asm volatile("v_add3_u32 v40, v40, v45, v50\n\tv_add3_u32 v40, v40, v45, v50\n\tv_add3_u32 v40, v40, v45, v50" ::: "v40", "v45", "v50");
+      if (P == 13) asm volatile("v_alignbit_b32 v40, v44, v44, v48\n\tv_alignbit_b32 v41, v44, v44, v48\n\tv_alignbit_b32 v42, v44, v44, v48" ::: "v40", "v41", "v42", "v44", "v48");
+      if (P == 14) asm volatile("v_alignbit_b32 v40, v44, v44, v49\n\tv_alignbit_b32 v41, v44, v44, v49\n\tv_alignbit_b32 v42, v44, v44, v49" ::: "v40", "v41", "v42", "v44", "v49");
       if (P == 8) asm volatile("v_add_u32_e32 %0, %0, %3\n\tv_add_u32_e32 %0, %0, %4\n\tv_bitop3_b32 %1, %1, %3, %4 bitop3:0x96" : "+v"(x), "+v"(w), "+v"(v) : "v"(y), "v"(z));
     }
   }
@@ -62,6 +69,12 @@ int main(int argc, char** argv) {
   run<3>("add -> add (dependent)", 2, out, d_ticks, js, first);
   run<4>("add_dpp row_half_mirror a ; bitop3 b ; bitop3 c", 3, out, d_ticks, js, first);
   run<5>("alignbit -> alignbit (dependent)", 2, out, d_ticks, js, first);
+  run<9>("bitop3 x3, sources v40 v44 v48 (one bank)", 3, out, d_ticks, js, first);
+  run<10>("bitop3 x3, sources v40 v45 v50 (three banks)", 3, out, d_ticks, js, first);
+  run<11>("add3 x3, sources v40 v44 v48 (one bank)", 3, out, d_ticks, js, first);
+  run<12>("add3 x3, sources v40 v45 v50 (three banks)", 3, out, d_ticks, js, first);
+  run<13>("alignbit x3, sources v44 v44 v48 (one bank)", 3, out, d_ticks, js, first);
+  run<14>("alignbit x3, sources v44 v44 v49 (two banks)", 3, out, d_ticks, js, first);
   fprintf(js, "\n]}\n");
   fclose(js);
   return 0;
