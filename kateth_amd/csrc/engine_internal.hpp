@@ -84,6 +84,7 @@ struct EnvKnobs {
   int proof_overlap = -1;        // KATETH_AMD_PROOF_OVERLAP (-1 = default)
   int eval_group = 0;            // KATETH_AMD_EVAL_GROUP: 16 | 64 (0 = automatic)
   bool verify_serial = false;    // KATETH_AMD_VERIFY_SERIAL
+  bool single_via_batch = false; // KATETH_AMD_SINGLE_VIA_BATCH: a single-item verification takes the batch machinery (the cross-check of the host lincomb)
   bool var_msm_classic = false;  // KATETH_AMD_VAR_MSM=classic: c = 8 with per-bucket partials for every batch size (cross-check of the flat path)
   uint64_t verify_chunk = 0;     // KATETH_AMD_VERIFY_CHUNK: blobs per host-buffer staging chunk (0 = default)
   uint32_t verify_streams = 0;   // KATETH_AMD_VERIFY_STREAMS: compute streams the host-buffer verification rotates its chunks over (1..4; 0 = default)

@@ -9,6 +9,7 @@
 
 #include <thread>
 #include "verify_kernels.cuh"
+#include "host_lincomb.hpp"
 // A verification session: device scratch for n items, a second stream (point decoding beside the evaluation kernel,
 // lincomb A beside lincomb B) and its fork/join events.  Sessions are POOLED in the context (kzg_ctx::session_pool): a
 // call takes one (growing its buffer if the batch is larger than any before), and kzg_verify_session_destroy hands it
@@ -915,6 +916,52 @@ int32_t evaluate_blobs_single(const kzg_ctx* ctx, const uint8_t* blobs, const ui
   return rc;
 }
 
+// ---- ONE item: the lincombs on the host ---------------------------------------------------------------------------------
+// verify_blob_proof / verify_proof (src/kzg/setup.rs:96-113, 208-221) are the batch check with n = 1, where r^0 = 1:
+//     e(proof, [tau]_2) == e(commitment - [y]G + [z]proof, G2).
+// Through the batch machinery that is a transcript, seven sorting / bucket / window kernels per lincomb for one and three
+// terms, two read-backs and two Horner loops: 0.6 ms on a chip with nothing to do (profiles/r04/single_verify_kernel_timeline.txt).
+// Here the two decoded points, z and y come back in one copy and the host -- which already runs the Horner loops and the pairing
+// -- takes S = [z]proof - [y]G as ONE double-scalar multiplication (4-bit windows, shared doublings: 14 + 252 + <= 128 point
+// operations, ~0.2 ms), B = S + commitment and its Miller loop on one thread while a second thread runs the proof's Miller loop.
+// The point decoding itself (square root, subgroup check: the reference's P1::decompress decisions) stays on the device.
+namespace {
+using host::host_point_from_r392;
+using host::host_double_scalar_mul;
+
+// proof / commitment: 24 limbs each as the decoder left them (x || y, 2^392 domain); z, y plain
+int32_t verify_one_on_host(const kzg_ctx* ctx, const uint32_t* prf24, bool prf_inf, const uint32_t* com24, bool com_inf, const fr_t& z, const fr_t& y,
+                           int32_t* ok) {
+  TraceTimer tt(ctx->knobs.trace, "one item: host lincomb + pairing");
+  host::g1_host_affine P, C;
+  host_point_from_r392(P, prf24, prf_inf);
+  host_point_from_r392(C, com24, com_inf);
+  host::fp12 fa = host::f12_one(), fb = host::f12_one();
+  (void)run_on_helpers(2, [&](uint32_t k) -> int32_t {
+    if (k == 1) {  // f_{|z|,[tau]_2}(-proof)
+      host::g1_host_affine np = P;
+      if (!np.inf) fp_neg(np.y, np.y);
+      const host::miller_lines* ls[1] = {&ctx->pairing->lines_tau};
+      fa = host::multi_miller(&np, ls, 1);
+      return 0;
+    }
+    g1_xyzz S;
+    host_double_scalar_mul(S, z, P, y);  // [z]proof - [y]G
+    if (!C.inf) xyzz_madd(S, C.x, C.y);
+    host::g1_host_affine B;
+    host_affine_from_xyzz(B, S);
+    const host::miller_lines* ls[1] = {&ctx->pairing->lines_g2};
+    fb = host::multi_miller(&B, ls, 1);
+    return 0;
+  });
+  tt.mark("double-scalar multiplication, two miller loops (two threads)");
+  *ok = host::final_exp_is_one(host::f12_mul(fa, fb), ctx->pairing->fc) ? 1 : 0;
+  tt.mark("final exponentiation");
+  return 0;
+}
+
+}  // namespace
+
 static int32_t first_error_code(const int32_t* err6);
 // ---- phase 2 in four pieces ---------------------------------------------------------------------------------------------
 struct Phase2 {
@@ -1079,6 +1126,28 @@ extern "C" int32_t kzg_verify_phase2_dev(kzg_verify_session* s, const uint8_t* r
   return rc;
 }
 
+// one item of a single-context call after phase 1: read back the two decoded points, z, y and the three statuses; the rest on the host
+static int32_t verify_one_tail(kzg_verify_session* s, int32_t* ok) {
+  *ok = 0;
+  struct {
+    uint32_t aff[48];  // proof, commitment: x || y each
+    fr_t z, y;
+    int32_t stat[3];   // blob, commitment, proof
+    uint8_t inf[2];
+  } h;
+  hipStream_t st = s->st;
+  if (hipStreamWaitEvent(st, s->ev_join, 0) != hipSuccess ||  // the decoder (its own stream when the launch was not the fused one)
+      hipMemcpyAsync(h.aff, s->aff, sizeof(h.aff), hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipMemcpyAsync(&h.z, s->z, sizeof(fr_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipMemcpyAsync(&h.y, s->y, sizeof(fr_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipMemcpyAsync(h.stat, s->stat, sizeof(h.stat), hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipMemcpyAsync(h.inf, s->inf, sizeof(h.inf), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+    return fail(KZG_FAIL_HIP, "single-item read-back failed");
+  for (int k = 0; k < 3; k++)  // first-error-wins: blob, commitment, proof (src/kzg/setup.rs:259-271)
+    if (h.stat[k]) return h.stat[k];
+  return verify_one_on_host(s->ctx, h.aff, h.inf[0] != 0, h.aff + 24, h.inf[1] != 0, h.z, h.y, ok);
+}
+
 // The single-context call, phases interleaved: everything that does not need the decoded POINTS -- transcript, root, r, the
 // scalars, and the digit / histogram / scan / scatter halves of both lincombs -- is enqueued while the point decoder still runs
 // on the session's side stream (its 2 x 224-VGPR waves leave every SIMD 64 registers, and each of those kernels fits in 64),
@@ -1087,6 +1156,7 @@ extern "C" int32_t kzg_verify_phase2_dev(kzg_verify_session* s, const uint8_t* r
 // the bucket kernels are enqueued; a rejected input still wins (its code is returned, the sums are discarded).
 static int32_t verify_fused(kzg_verify_session* s, const uint8_t* com, const uint8_t* prf, int32_t* ok, const uint8_t* root_done = nullptr) {
   const kzg_ctx* ctx = s->ctx;
+  if (s->n == 1 && !ctx->knobs.single_via_batch) return verify_one_tail(s, ok);
   TraceTimer tt(ctx->knobs.trace, "verify (fused phases)");
   uint8_t root[32];
   int32_t err6[6];
@@ -1236,8 +1306,10 @@ int32_t verify_proof_single(const kzg_ctx* ctx, const uint8_t* proof48, const ui
   }
   int32_t rc = 0;
   int32_t h_stat[2] = {0, 0};
+  uint32_t h_aff[48];  // proof, commitment as decoded
+  uint8_t h_inf[2] = {0, 0};
+  fr_t zy[2];
   do {
-    fr_t zy[2];
     fr_from_be_bytes_plain(zy[0], z32);
     fr_from_be_bytes_plain(zy[1], y32);
     uint8_t in[96];
@@ -1246,16 +1318,23 @@ int32_t verify_proof_single(const kzg_ctx* ctx, const uint8_t* proof48, const ui
     if (hipMemcpyAsync(s->pts48, in, 96, hipMemcpyHostToDevice, st) != hipSuccess) { rc = fail(KZG_FAIL_HIP, "copy"); break; }
     hipLaunchKernelGGL(k_g1_decompress, dim3(1), dim3(64), 0, st, s->pts48, (uint64_t)1, s->stat + 2, s->pts48 + 48, (uint64_t)1, s->stat + 1, s->aff,
                        s->inf);
-    if (hipMemcpyAsync(h_stat, s->stat + 1, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+    if (hipMemcpyAsync(h_stat, s->stat + 1, 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(h_aff, s->aff, sizeof(h_aff), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(h_inf, s->inf, sizeof(h_inf), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
       rc = fail(KZG_FAIL_HIP, "copy");
       break;
     }
     if (h_stat[1]) { rc = h_stat[1]; break; }  // proof first (src/kzg/setup.rs:103)
     if (h_stat[0]) { rc = h_stat[0]; break; }
     if (!fr_is_canonical(zy[0]) || !fr_is_canonical(zy[1])) { rc = KZG_ERR_FF_NOT_IN_FIELD; break; }
+    if (!ctx->knobs.single_via_batch) break;  // the lincomb and the pairing on the host (verify_one_on_host)
     if (hipMemcpyAsync(s->z, &zy[0], 32, hipMemcpyHostToDevice, st) != hipSuccess ||
         hipMemcpyAsync(s->y, &zy[1], 32, hipMemcpyHostToDevice, st) != hipSuccess) { rc = fail(KZG_FAIL_HIP, "copy"); break; }
   } while (0);
+  if (rc == 0 && !ctx->knobs.single_via_batch) {
+    kzg_verify_session_destroy(s);
+    return verify_one_on_host(ctx, h_aff, h_inf[0] != 0, h_aff + 24, h_inf[1] != 0, zy[0], zy[1], ok);
+  }
   uint8_t partial[192];
   if (rc == 0) {
     const uint8_t root[32] = {0};

@@ -446,3 +446,33 @@ extern "C" void hm_modinv30(int which, uint8_t* out, const uint8_t* a) {
     store_le(out, r);
   }
 }
+
+// ---- single-item verification's host lincomb (kateth_amd/csrc/host_lincomb.hpp) ---------------------------------------------
+#include "../../kateth_amd/csrc/host_lincomb.hpp"
+// out48 = compress([k1] P - [k2] G + C) with P, C given compressed and passed through the decoder's r392 output format
+// (g1_decompress28(..., r392_out = true)) and host_point_from_r392, as verify_one_on_host does; k1, k2: 32 bytes big-endian
+extern "C" int32_t hm_single_item_lincomb(uint8_t* out48, const uint8_t* k1_be, const uint8_t* p48, const uint8_t* k2_be, const uint8_t* c48) {
+  kzg::host::g1_host_affine pts[2];
+  const uint8_t* enc[2] = {p48, c48};
+  for (int j = 0; j < 2; j++) {
+    fp_t x, y;
+    bool inf = false;
+    if (g1_decompress28(x, y, inf, enc[j], true) != 0) return -1;
+    uint32_t xy[24];
+    for (int q = 0; q < 12; q++) {
+      xy[q] = x.v[q];
+      xy[12 + q] = y.v[q];
+    }
+    kzg::host::host_point_from_r392(pts[j], xy, inf);
+  }
+  fr_t k1, k2;
+  for (int q = 0; q < 8; q++) {
+    k1.v[7 - q] = ((uint32_t)k1_be[4 * q] << 24) | ((uint32_t)k1_be[4 * q + 1] << 16) | ((uint32_t)k1_be[4 * q + 2] << 8) | k1_be[4 * q + 3];
+    k2.v[7 - q] = ((uint32_t)k2_be[4 * q] << 24) | ((uint32_t)k2_be[4 * q + 1] << 16) | ((uint32_t)k2_be[4 * q + 2] << 8) | k2_be[4 * q + 3];
+  }
+  g1_xyzz s;
+  kzg::host::host_double_scalar_mul(s, k1, pts[0], k2);
+  if (!pts[1].inf) xyzz_madd(s, pts[1].x, pts[1].y);
+  g1_compress_xyzz(out48, s);
+  return 0;
+}

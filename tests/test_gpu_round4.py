@@ -298,3 +298,52 @@ def test_out_of_memory_at_call_time_is_reported_and_recoverable(torch_cuda, gold
     finally:
         s.close()
         torch.cuda.empty_cache()
+
+
+def test_single_item_verification_host_lincomb_agrees_with_the_batch_machinery(engine, torch_cuda, golden, monkeypatch):
+    """n = 1 (verify_blob_proof, verify_proof -- src/kzg/setup.rs:96-113, 208-221) ends on the host: commitment - [y]G + [z]proof as
+    one double-scalar multiplication, then the pairing.  KATETH_AMD_SINGLE_VIA_BATCH sends the same calls through the batch
+    machinery (transcript, two variable-base MSMs): same booleans and same errors on valid triples, a wrong proof, a wrong y, a
+    constant blob (proof = infinity), the zero blob (commitment = proof = infinity) and rejected encodings."""
+    import kateth_amd
+
+    torch = torch_cuda
+    monkeypatch.setenv("KATETH_AMD_SINGLE_VIA_BATCH", "1")
+    batch = kateth_amd.Setup.load_json(TRUSTED_SETUP, window_bits=8)
+    monkeypatch.delenv("KATETH_AMD_SINGLE_VIA_BATCH")
+    try:
+        n = 3
+        d_blobs, d_c, d_p = _triples(engine, torch, n, golden["seed"])
+        hb, hc, hp = (t.cpu().numpy().tobytes() for t in (d_blobs, d_c, d_p))
+        blobs = [hb[i * 131072:(i + 1) * 131072] for i in range(n)]
+        cs = [hc[i * 48:(i + 1) * 48] for i in range(n)]
+        ps = [hp[i * 48:(i + 1) * 48] for i in range(n)]
+        const_blob = (7).to_bytes(32, "big") * 4096
+        c7 = engine.blob_to_commitment(const_blob)
+        cases = [(blobs[0], cs[0], ps[0], True), (blobs[1], cs[1], ps[1], True), (blobs[0], cs[0], ps[1], False), (blobs[0], cs[1], ps[0], False),
+                 (const_blob, c7, INF48, True), (const_blob, c7, ps[0], False), (bytes(131072), INF48, INF48, True), (bytes(131072), INF48, ps[2], False)]
+        for blob, c, p, want in cases:
+            assert engine.verify_blob_proof(blob, c, p) is want
+            assert batch.verify_blob_proof(blob, c, p) is want
+            d = [torch.frombuffer(bytearray(x), dtype=torch.uint8).cuda() for x in (blob, c, p)]
+            assert engine.verify_blob_proof_batch_dev(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), 1) is want
+        # verify_proof: (z, y) from the engine's own proof at a caller's point
+        z = (0x1234567).to_bytes(32, "big")
+        prf, y = engine.proof(blobs[0], z)
+        y_bad = ((int.from_bytes(y, "big") + 1) % R).to_bytes(32, "big")
+        for s_ in (engine, batch):
+            assert s_.verify_proof(prf, cs[0], z, y) is True
+            assert s_.verify_proof(prf, cs[0], z, y_bad) is False
+            assert s_.verify_proof(prf, cs[1], z, y) is False
+            assert s_.verify_proof(INF48, c7, z, (7).to_bytes(32, "big")) is True  # a constant polynomial: y = 7 everywhere, proof = infinity
+        bad = bytes([0x80]) + bytes(46) + bytes([5])  # not on the curve / not in the group
+        for s_ in (engine, batch):
+            for args in ((blobs[0], bad, ps[0]), (blobs[0], cs[0], bad)):
+                with pytest.raises(kateth_amd.KzgError):
+                    s_.verify_blob_proof(*args)
+            with pytest.raises(kateth_amd.KzgError):
+                s_.verify_proof(bad, cs[0], z, y)
+            with pytest.raises(kateth_amd.KzgError):
+                s_.verify_blob_proof(R.to_bytes(32, "big") + blobs[0][32:], cs[0], ps[0])
+    finally:
+        batch.close()

@@ -473,3 +473,27 @@ def test_safegcd_inversion(hm):
             assert got == pow(a, -1, m), (which, hex(a))
         hm.hm_modinv30(which, out, bytes(nb))
         assert int.from_bytes(out.raw, "little") == 0
+
+
+def test_single_item_host_lincomb(hm):
+    """host_lincomb.hpp (the n = 1 ending of verification: commitment - [y]G + [z]proof as one double-scalar multiplication on the
+    host, points taken from the decoder's 2^392-domain output) against the oracle's group arithmetic: random scalars and points,
+    the zero scalars, scalars r - 1, a proof at infinity (constant polynomials), a commitment at infinity, and the cancellation
+    [z]P = [y]G"""
+    rnd = random.Random(0x51A61E)
+    out = ctypes.create_string_buffer(48)
+
+    def check(k1, pt, k2, com):
+        want = bls.g1_add(bls.g1_add(bls.g1_mul(pt, k1) if pt is not None else None, bls.g1_neg(bls.g1_mul(bls.G1_GEN, k2))), com)
+        rc = hm.hm_single_item_lincomb(out, k1.to_bytes(32, "big"), bls.g1_compress(pt), k2.to_bytes(32, "big"), bls.g1_compress(com))
+        assert rc == 0 and out.raw == bls.g1_compress(want), (k1, k2)
+
+    pts = [bls.g1_mul(bls.G1_GEN, rnd.randrange(1, R)) for _ in range(3)]
+    for _ in range(6):
+        check(rnd.randrange(R), rnd.choice(pts), rnd.randrange(R), rnd.choice(pts))
+    check(0, pts[0], 0, pts[1])
+    check(R - 1, pts[0], R - 1, pts[1])
+    check(rnd.randrange(R), None, rnd.randrange(R), pts[2])       # proof = infinity
+    check(rnd.randrange(R), pts[1], rnd.randrange(R), None)       # commitment = infinity
+    check(1, bls.G1_GEN, 1, None)                                  # [1]G - [1]G: the identity
+    check(0xF, bls.G1_GEN, 0xF0, bls.g1_mul(bls.G1_GEN, 0xE1))     # every step of one window adds a point and its negative
