@@ -768,6 +768,10 @@ int32_t verify_phase1_host(const kzg_ctx* ctx, const uint8_t* blobs, const uint8
     // has been hashed and evaluated, so the staging arena can be handed on; the statuses are read by the caller, later
     if (err6) {
       rc = phase1_finish(s, com, prf, out_root32, err6, tt);
+    } else if (n == 1 && !ctx->knobs.single_via_batch) {
+      // one item: no batch challenge (r^0 = 1), hence no transcript; the arena is free once the item's kernels have run
+      memset(out_root32, 0, 32);
+      if (hipStreamSynchronize(st) != hipSuccess) rc = fail(KZG_FAIL_HIP, "verify phase 1 synchronize failed");
     } else {
       rc = p1_transcript(s, com, prf);
       if (rc == 0) rc = p1_root(s, out_root32);
