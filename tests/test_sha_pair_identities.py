@@ -231,3 +231,15 @@ def test_consumer_thread_map():
         assert ((tid % 16) // 4) % 2 == (1 if is_y else 0)
         seen.add((slot, is_y))
     assert seen == {(s_, y) for s_ in range(64) for y in (False, True)}
+
+
+def test_committed_header_is_what_the_generator_writes():
+    """kateth_amd/csrc/sha_pair_asm.cuh is generated (tools/gen_sha_pair_asm.py) and committed: the two must not drift apart"""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("gen_sha_pair_asm", os.path.join(os.path.dirname(os.path.dirname(ASM)), "..", "tools", "gen_sha_pair_asm.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    src, counts = gen.render()
+    assert src == open(ASM).read()
+    assert counts == [len(asm_lines(nb)) for nb in (1, 2, 4)]

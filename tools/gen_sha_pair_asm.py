@@ -100,7 +100,8 @@ __device__ __forceinline__ void sha256_blocks_pair_asm%d(uint32_t& a0, uint32_t&
 """ % (nb, "" if nb == 1 else "s", len(lines), nb, addrs, text, ops, ", ".join('"%s"' % c for c in CLOBBERS)), len(lines)
 
 
-def main():
+def render():
+    """(source text of sha_pair_asm.cuh, instruction slots of the 1 / 2 / 4 block statements)"""
     parts, counts = [], []
     for nb in (1, 2, 4):
         src, n = function(nb)
@@ -119,6 +120,11 @@ constexpr uint32_t SHA_PAIR_ROW_QUADS = 65;
 %s#endif
 }  // namespace kzg
 """ % (ROW_BYTES, "\n".join(parts))
+    return src, counts
+
+
+def main():
+    src, counts = render()
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "kateth_amd", "csrc", "sha_pair_asm.cuh")
     open(path, "w").write(src)
     print("wrote", path, counts, "instruction slots for 1 / 2 / 4 blocks")
