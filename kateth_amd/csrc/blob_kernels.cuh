@@ -537,22 +537,29 @@ static __global__ __launch_bounds__(512, 4) void k_poly(const uint8_t* __restric
   __syncthreads();
   fr_t z;
   to_mont<FrParams>(z, z_plain[b]);
-  fr_t e[8], pre[8];
+  // The thread's eight blob elements are NOT kept in registers: with the eight prefix products they would be 128 VGPRs before any
+  // temporary, the kernel's whole budget at four waves per SIMD (592 bytes of scratch per lane while they were); they are read
+  // again where they are used -- twice more, 16-KiB coalesced rows that mostly still sit in the L2.  An element stays PLAIN:
+  // mont_mul(plain, X*R) = plain*X, so neither a to_mont nor a from_mont per element is needed.
+  auto element = [&](int k, bool& noncanonical) -> fr_t {
+    uint32_t sc[8];
+    load_scalar_be_(sc, blob + (uint64_t)(k * 512 + t) * 32u);
+    fr_t v;
+#pragma unroll
+    for (int q = 0; q < 8; q++) v.v[q] = sc[q];
+    noncanonical = !fr_is_canonical(v);
+    if (noncanonical) bn_zero(v);
+    return v;
+  };
+  fr_t pre[8];
   fr_t run = fr_one();
   bool bad = false;
 #pragma unroll
   for (int k = 0; k < 8; k++) {
     const int i = k * 512 + t;
-    uint32_t sc[8];
-    load_scalar_be_(sc, blob + (uint64_t)i * 32u);
-    fr_t v;
-#pragma unroll
-    for (int q = 0; q < 8; q++) v.v[q] = sc[q];
-    if (!fr_is_canonical(v)) {
-      bad = true;
-      bn_zero(v);
-    }
-    e[k] = v;  // kept PLAIN: mont_mul(plain, X*R) = plain*X, so neither a to_mont nor a from_mont per element is needed
+    bool nc;
+    (void)element(k, nc);
+    bad |= nc;
     fr_t d;
     fr_sub(d, z, roots_brp[i]);
     if (bn_is_zero(d)) {
@@ -607,7 +614,9 @@ static __global__ __launch_bounds__(512, 4) void k_poly(const uint8_t* __restric
     fr_mul(inv_run, inv_run, d);
     pre[k] = inv_d;  // slot k now holds 1/(z - w_i)
     fr_mul(term, w, inv_d);      // (w R)(inv_d R)/R = w inv_d R
-    fr_mul(term, e[k], term);    // plain e * (w inv_d R) / R = plain e w / (z - w)
+    bool nc;
+    const fr_t ek = element(k, nc);
+    fr_mul(term, ek, term);      // plain e * (w inv_d R) / R = plain e w / (z - w)
     if (i != domain) fr_add(ysum, ysum, term);
   }
   // block sum of ysum
@@ -636,9 +645,8 @@ static __global__ __launch_bounds__(512, 4) void k_poly(const uint8_t* __restric
   }
   __syncthreads();
   if (domain >= 0 && (domain & 511) == t) {
-#pragma unroll
-    for (int k = 0; k < 8; k++)
-      if (k == (domain >> 9)) sh_y = e[k];  // y = e_m (poly.rs:14-18)
+    bool nc;
+    sh_y = element(domain >> 9, nc);  // y = e_m (poly.rs:14-18)
   }
   __syncthreads();
   const fr_t y = sh_y;  // plain
@@ -654,7 +662,9 @@ static __global__ __launch_bounds__(512, 4) void k_poly(const uint8_t* __restric
     for (int k = 0; k < 8; k++) {
       const int i = k * 512 + t;
       fr_t q;
-      fr_sub(q, y, e[k]);        // plain
+      bool nc;
+      const fr_t ek = element(k, nc);
+      fr_sub(q, y, ek);          // plain
       fr_mul(q, q, pre[k]);      // plain * (1/(z - w_i)) R / R: plain quotient element
       if (i == domain) bn_zero(q);
       if (domain >= 0) {  // block-uniform
