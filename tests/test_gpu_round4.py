@@ -327,6 +327,19 @@ def test_single_item_verification_host_lincomb_agrees_with_the_batch_machinery(e
             assert batch.verify_blob_proof(blob, c, p) is want
             d = [torch.frombuffer(bytearray(x), dtype=torch.uint8).cuda() for x in (blob, c, p)]
             assert engine.verify_blob_proof_batch_dev(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), 1) is want
+        import random
+
+        rnd = random.Random(0x0E17)
+        for _ in range(24):  # every combination of the three triples' parts, and a blob with one element changed
+            i, j, k = (rnd.randrange(n) for _ in range(3))
+            blob = blobs[i]
+            tampered = rnd.random() < 0.25
+            if tampered:
+                e = rnd.randrange(4096)
+                blob = blob[:32 * e] + (1).to_bytes(32, "big") + blob[32 * e + 32:]
+            want = (i == j == k) and not tampered
+            assert engine.verify_blob_proof(blob, cs[j], ps[k]) is want
+            assert batch.verify_blob_proof(blob, cs[j], ps[k]) is want
         # verify_proof: (z, y) from the engine's own proof at a caller's point
         z = (0x1234567).to_bytes(32, "big")
         prf, y = engine.proof(blobs[0], z)
