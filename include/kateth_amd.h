@@ -21,6 +21,14 @@
  * host-buffer calls additionally serialise on the staging arena.  A context
  * created with kzg_config.devices / ndev spans several GPUs (below).
  *
+ * Streams and hardware queues: the HIP runtime multiplexes all streams of a
+ * process onto GPU_MAX_HW_QUEUES hardware queues (4 unless set) and streams
+ * that share a queue run one after the other.  The library's load-time
+ * constructor sets GPU_MAX_HW_QUEUES=16 if the variable is unset (setenv at
+ * dlopen time, before HIP initialises); a host program that initialises HIP
+ * before loading the library, or that is multi-threaded while loading it,
+ * should export the variable itself.
+ *
  * Return value of every call: 0 on success, a positive KZG_ERR_* code when an
  * input is rejected the way the reference returns Err, a negative KZG_FAIL_*
  * code for a runtime (HIP / allocation / argument) failure.
