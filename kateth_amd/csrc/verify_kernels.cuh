@@ -766,10 +766,8 @@ static __global__ __launch_bounds__(64) void k_var_fold(const g1_xyzz28* __restr
     if ((lane & m) == step) lds[lane >> 1] = acc;
     __syncthreads();
     if ((lane & m) == 0) {
-      g1_xyzz28 other = lds[(lane + step) >> 1];
-      g1_xyzz28 mine = acc;
-      xyzz28_add_complete(mine, other);
-      acc = mine;
+      const g1_xyzz28 other = lds[(lane + step) >> 1];
+      xyzz28_add_complete_inl(acc, other);  // inlined: the out-of-line adder passes both operands through scratch on every level
     }
     __syncthreads();
   }
@@ -797,8 +795,8 @@ static __global__ __launch_bounds__(64) void k_var_windows(const g1_xyzz28* __re
     const uint32_t idx = lane * per + k;
     if (idx < g.half) {
       g1_xyzz28 b = B[idx];
-      xyzz28_add_complete(run, b);
-      xyzz28_add_complete(tot, run);
+      xyzz28_add_complete_inl(run, b);
+      xyzz28_add_complete_inl(tot, run);
       owned++;
     }
   }
@@ -811,7 +809,7 @@ static __global__ __launch_bounds__(64) void k_var_windows(const g1_xyzz28* __re
     g1_xyzz28 v = buf[cur][lane];
     if (lane + off < 64) {
       g1_xyzz28 o = buf[cur][lane + off];
-      xyzz28_add_complete(v, o);
+      xyzz28_add_complete_inl(v, o);
     }
     buf[cur ^ 1][lane] = v;
     __syncthreads();
@@ -824,7 +822,7 @@ static __global__ __launch_bounds__(64) void k_var_windows(const g1_xyzz28* __re
   else
     xyzz28_set_inf(X);
   // each of the lane's `owned` suffix sums gains X: tot += owned * X  (owned <= per, tiny)
-  for (uint32_t k = 0; k < owned; k++) xyzz28_add_complete(tot, X);
+  for (uint32_t k = 0; k < owned; k++) xyzz28_add_complete_inl(tot, X);
 #pragma unroll 1
   for (int step = 1; step < 64; step <<= 1) {
     const int m = 2 * step - 1;
@@ -833,7 +831,7 @@ static __global__ __launch_bounds__(64) void k_var_windows(const g1_xyzz28* __re
     if ((lane & m) == 0) {
       g1_xyzz28 other = lds[(lane + step) >> 1];
       g1_xyzz28 mine = tot;
-      xyzz28_add_complete(mine, other);
+      xyzz28_add_complete_inl(mine, other);
       tot = mine;
     }
     __syncthreads();
