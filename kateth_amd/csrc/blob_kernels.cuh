@@ -495,7 +495,8 @@ static __global__ __launch_bounds__(256) void k_fr_store_be(const fr_t* __restri
 // ---------------------------------------------------------------------------
 // The root of k_poly's product tree is prod_i (z - w_i) = z^4096 - 1 (with the matching factor
 // replaced by 1 for an in-domain z = w_m: prod_{i != m} (w_m - w_i) = 4096 / w_m).  Its inverse is
-// therefore computed here, one blob per lane, instead of serially inside every workgroup.
+// therefore computed here, one blob per lane, instead of serially inside every workgroup -- and with it the factor
+// (z^4096 - 1) / 4096 of the barycentric sum, which needs the same twelve squarings: inv_root[2b] and inv_root[2b + 1].
 static __global__ __launch_bounds__(64) void k_poly_root_inverse(const fr_t* __restrict__ z_plain, uint64_t n, fr_t* __restrict__ inv_root) {
   issue_priority_latency();
   const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -505,16 +506,20 @@ static __global__ __launch_bounds__(64) void k_poly_root_inverse(const fr_t* __r
   zn = z;
   for (int q = 0; q < 12; q++) fr_sqr(zn, zn);
   fr_sub(zn, zn, fr_one());
-  if (bn_is_zero(zn)) {  // z is a 4096th root of unity: inverse of 4096 / z
-    fr_t f;
+  fr_t f;
+  {
     const uint32_t c4096[8] = KZG_FR_INV4096_MONT;
 #pragma unroll
     for (int q = 0; q < 8; q++) f.v[q] = c4096[q];
+  }
+  if (bn_is_zero(zn)) {  // z is a 4096th root of unity: inverse of 4096 / z
     fr_mul(r, z, f);
   } else {
     fr_inv(r, zn);
   }
-  inv_root[b] = r;
+  inv_root[2 * b] = r;
+  fr_mul(f, f, zn);  // (z^4096 - 1) / 4096, Montgomery (zero for an in-domain z: y is the matching element then)
+  inv_root[2 * b + 1] = f;
 }
 
 // (512, 4): at most 128 VGPRs, so that two 8-wave workgroups share a CU (129 VGPRs would halve the occupancy)
@@ -581,7 +586,7 @@ static __global__ __launch_bounds__(512, 4) void k_poly(const uint8_t* __restric
     }
     __syncthreads();
   }
-  if (t == 0) tree[1] = inv_root[b];  // = 1 / tree[1], from k_poly_root_inverse
+  if (t == 0) tree[1] = inv_root[2 * b];  // = 1 / tree[1], from k_poly_root_inverse
   __syncthreads();
   // push inverses down: children of j get inv(j) * sibling product
   for (int width = 1; width <= 256; width <<= 1) {
@@ -631,16 +636,8 @@ static __global__ __launch_bounds__(512, 4) void k_poly(const uint8_t* __restric
     __syncthreads();
   }
   if (t == 0) {
-    fr_t total = tree[0], zn = z, f;
-    for (int q = 0; q < 12; q++) fr_sqr(zn, zn);  // z^4096
-    fr_sub(zn, zn, fr_one());
-    {
-      const uint32_t c4096[8] = KZG_FR_INV4096_MONT;
-#pragma unroll
-      for (int q = 0; q < 8; q++) f.v[q] = c4096[q];
-    }
-    fr_mul(f, f, zn);
-    fr_mul(total, total, f);  // plain sum * Montgomery factor = plain y
+    fr_t total = tree[0];
+    fr_mul(total, total, inv_root[2 * b + 1]);  // plain sum * Montgomery (z^4096 - 1) / 4096 = plain y
     sh_y = total;
   }
   __syncthreads();

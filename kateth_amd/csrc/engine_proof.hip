@@ -26,7 +26,7 @@ static ProofLayout proof_layout(const kzg_ctx* ctx, uint64_t n) {
   };
   for (int sl = 0; sl < 2; sl++) {
     L.o_z[sl] = take(L.cn * sizeof(fr_t));
-    L.o_ir[sl] = take(L.cn * sizeof(fr_t));
+    L.o_ir[sl] = take(2 * L.cn * sizeof(fr_t));  // per blob: 1 / prod (z - w_i) and (z^4096 - 1) / 4096
     L.o_y[sl] = take(L.cn * sizeof(fr_t));
     L.o_cs[sl] = take(L.cn * sizeof(int32_t));
     L.o_q[sl] = take(L.cn * 4096 * sizeof(fr_t));
