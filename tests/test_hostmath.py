@@ -175,6 +175,30 @@ def test_host_pairing_against_oracle(hm, oracle_setup):
         assert got == int(want) == int(good)
 
 
+def test_host_pairing_on_the_external_point_evaluation_vector(hm, oracle_setup):
+    """the product's host pairing, G1 decoder and host lincomb on data produced outside this repository (the public EIP-4844
+    point-evaluation precompile test, tests/golden/external-vectors/README.md): verify_proof_inner of src/kzg/setup.rs:84-94,
+    e(-(C - [y]G), G2) * e(proof, [tau]_2 - [z]G2) == 1.  The G2 operand is the ceremony's g2_monomial[1] minus [z]G2 by the
+    oracle's G2 arithmetic; everything in G1 and the pairing run in the product's code"""
+    from test_oracle_kat import EXT_COMMITMENT, EXT_PROOF, EXT_Y, EXT_Z
+
+    assert hm.hm_g1_decompress_status(EXT_COMMITMENT) == 0 and hm.hm_g1_decompress_status(EXT_PROOF) == 0
+    out28 = ctypes.create_string_buffer(48)
+    assert hm.hm_g1_decompress28(out28, EXT_COMMITMENT) == 0 and out28.raw == EXT_COMMITMENT
+    z, y = int.from_bytes(EXT_Z, "big"), int.from_bytes(EXT_Y, "big")
+    c2 = bls.g2_compress
+
+    def decision(zz, yy):
+        c_minus_y = ctypes.create_string_buffer(48)  # [0]proof - [y]G + C through host_lincomb.hpp
+        assert hm.hm_single_item_lincomb(c_minus_y, bytes(32), EXT_PROOF, yy.to_bytes(32, "big"), EXT_COMMITMENT) == 0
+        tau_minus_z = bls.g2_add(oracle_setup.g2_monomial[1], bls.g2_neg(bls.g2_mul(bls.G2_GEN, zz)))
+        return hm.hm_pairing_check(c_minus_y.raw, c2(bls.G2_GEN), EXT_PROOF, c2(tau_minus_z))
+
+    assert decision(z, y) == 1
+    assert decision(z, (y + 1) % R) == 0
+    assert decision((z + 1) % R, y) == 0
+
+
 def test_host_final_exp_chain_matches_definition(hm):
     e = (P**12 - 1) // R
     nl = (e.bit_length() + 31) // 32

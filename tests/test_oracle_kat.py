@@ -287,3 +287,27 @@ def test_prove_on_monomials_matches_closed_form(oracle_setup):
         for j in range(k):
             want = bls.g1_add(want, bls.g1_mul(taus[j], pow(z, k - 1 - j, R)))
         assert pi == want
+
+
+# ---- the one EXTERNAL vector: public EIP-4844 point-evaluation precompile test (tests/golden/external-vectors/README.md) ------
+EXT_COMMITMENT = bytes.fromhex("8f59a8d2a1a625a17f3fea0fe5eb8c896db3764f3185481bc22f91b4aaffcca25f26936857bc3a7c2539ea8ec3a952b7")
+EXT_Z = bytes.fromhex("564c0a11a0f704f4fc3e8acfe0f8245f0ad1347b378fbf96e206da11a5d36306")
+EXT_Y = bytes.fromhex("24d25032e67a7e6a4910df5834b8fe70e6bcfeeac0352434196bdf4b2485d5a1")
+EXT_PROOF = bytes.fromhex("873033e038326e87ed3e1276fd140253fa08e9fc25fb2d9a98527fc22a2c9612fbeafdad446cbc7bcdbdcd780af2c16a")
+EXT_VERSIONED_HASH = bytes.fromhex("01e798154708fe7789429634053cbf9f99b619f9f084048927333fce637f549b")
+
+
+def test_external_point_evaluation_precompile_vector(oracle_setup):
+    """verify_proof_inner (src/kzg/setup.rs:84-94) on data an independent implementation produced: the vector authenticates
+    itself (versioned hash = 0x01 || sha256(commitment)[1:]; the pairing equation holds against the ceremony's [tau]_2), z is the
+    primitive 4096th root of unity -- a point ON the domain -- and the neighbours y + 1, z + 1 are rejected"""
+    assert b"\x01" + hashlib.sha256(EXT_COMMITMENT).digest()[1:] == EXT_VERSIONED_HASH
+    assert int.from_bytes(EXT_Z, "big") == domain.primitive_root_of_unity(4096) == pow(7, (R - 1) // 4096, R)
+    assert oracle_setup.verify_proof(EXT_PROOF, EXT_COMMITMENT, EXT_Z, EXT_Y) is True
+    assert oracle_setup.verify_proof(EXT_PROOF, EXT_COMMITMENT, EXT_Z, be32(int.from_bytes(EXT_Y, "big") + 1)) is False
+    assert oracle_setup.verify_proof(EXT_PROOF, EXT_COMMITMENT, be32(int.from_bytes(EXT_Z, "big") + 1), EXT_Y) is False
+    assert oracle_setup.verify_proof(EXT_COMMITMENT, EXT_PROOF, EXT_Z, EXT_Y) is False  # roles swapped
+    # both points decode, are in the group and re-encode to the same bytes
+    for enc in (EXT_COMMITMENT, EXT_PROOF):
+        pt = bls.g1_uncompress(enc)
+        assert bls.g1_in_subgroup(pt) and bls.g1_compress(pt) == enc

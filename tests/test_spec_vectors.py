@@ -10,6 +10,9 @@ Two vector sets, same layout:
     of invalid input, wrong lengths, length mismatches, the empty batch) whose outputs were produced by oracle/pyref
     (tests/golden/make_spec_layout_vectors.py).  They are not the official vectors; they make the runner -- and the
     engine behind kateth's six functions -- run end to end in that layout.
+  * "external": tests/golden/external-vectors -- data produced OUTSIDE this repository by an independent implementation and
+    kept because it self-authenticates (its README says how): today one verify_kzg_proof case, the public EIP-4844
+    point-evaluation precompile test.
 They run against the GPU engine (-m gpu) and, without a GPU, against the CPU oracle (a sample: the oracle made them)."""
 import glob
 import gzip
@@ -24,6 +27,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOTS = {
     "official": os.environ.get("KZG_SPEC_TESTS", os.path.join(HERE, "golden", "consensus-spec-tests")),
     "generated": os.path.join(HERE, "golden", "spec-layout-vectors"),
+    "external": os.path.join(HERE, "golden", "external-vectors"),
 }
 HANDLERS = ["blob_to_kzg_commitment", "compute_kzg_proof", "compute_blob_kzg_proof", "verify_kzg_proof", "verify_blob_kzg_proof", "verify_blob_kzg_proof_batch"]
 
@@ -174,6 +178,17 @@ def test_spec_vectors_gpu_group_context(handler, which, gpu_group):
     if not cases(handler, which):
         pytest.skip("consensus-spec-tests vectors not present; set KZG_SPEC_TESTS")
     assert _check(gpu_group, handler, which) >= 1
+
+
+@pytest.mark.gpu
+def test_external_vectors_gpu(gpu_engine, gpu_group):
+    """the externally produced case(s) through a plain and a group context; never skipped: the files are committed"""
+    for api in (gpu_engine, gpu_group):
+        assert _check(api, "verify_kzg_proof", "external") >= 1
+
+
+def test_external_vectors_oracle():
+    assert _check(OracleApi(), "verify_kzg_proof", "external") >= 1
 
 
 def test_generated_set_covers_every_handler_and_null_convention():
