@@ -68,9 +68,9 @@ def parse():
                          "16 -> 12.9 GB, 65,536 additions; 8 -> 100 MB, 131,072 additions")
     ap.add_argument("--default-budget", action="store_true", help="do NOT pass KZG_CFG_TABLE_MAX: the library's default budget (100 GiB -> the 96-GiB table, G = 4) "
                     "instead of the largest table the device has room for (192 GiB, G = 8)")
-    ap.add_argument("--in-flight", type=int, default=0, help="calls kept in flight: step i is enqueued on stream i mod F with result buffers of its own (0 = default: 3 for "
-                    "--workload proof -- a call's hash + quotient kernels run in the shadow of the others' MSMs; the context has three workspaces --, 1 otherwise; the timed region is still K steps "
-                    "between two full synchronisations)")
+    ap.add_argument("--in-flight", type=int, default=0, help="calls kept in flight: step i is enqueued on stream i mod F with result buffers of its own (0 = default = 1: one call at a "
+                    "time for every workload, as the reference's methods are called; --workload proof also reports the rate with 3 in flight as `value_three_calls_in_flight` -- a call's hash + "
+                    "quotient kernels then run in the shadow of the others' MSMs; the timed region is still K steps between two full synchronisations)")
     ap.add_argument("--blocking-setup", action="store_true", help="create the context without KZG_CFG_BUILD_ASYNC (kzg_ctx_create returns when the full table stands)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL, the measured path) or gloo (rehearsal: ranks may share one card, gathers go through the host)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -428,8 +428,9 @@ def roofline_object(workload, n, prof, window_bits, call_ms=None):
     roof = {
         "kernel": dominant,
         "bound": "valu",
-        "limiter": "VALU instruction issue (integer v_mad_u64_u32 / SHA-256 bit ops): see valu_issue (floor from SQ_INSTS_VALU x the measured issue interval) and DESIGN.md "
-                   "section 5; achieved / peak / frac below are the HBM figures the north star asks for (algorithmic bytes over the chip's 8 TB/s), kept as they were",
+        "limiter": "VALU instruction issue: valu_issue_frac = floor (SQ_INSTS_VALU x issue interval / clock) / call time; achieved/peak/frac = HBM",
+        "limiter_detail": "integer v_mad_u64_u32 / SHA-256 bit ops: see valu_issue (floor from SQ_INSTS_VALU x the measured issue interval) and DESIGN.md "
+                   "section 5; achieved / peak / frac are the HBM figures the north star asks for (algorithmic bytes over the chip's 8 TB/s), kept as they were",
         "achieved": ach,
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
@@ -449,9 +450,35 @@ def roofline_object(workload, n, prof, window_bits, call_ms=None):
     }
     if workload == "verify" and call_ms:
         call_ach = ALG_BYTES[workload] * n / (call_ms * 1e-3) / 1e9
+        longest = max(kinds, key=lambda k: kinds[k][0] / kinds[k][1])
         roof.update({"dominant_kernel_achieved": ach, "dominant_kernel_frac": ach / HBM_PEAK_GBS, "achieved": call_ach, "frac": call_ach / HBM_PEAK_GBS,
-                     "call_ms": call_ms, "scope": "whole verify_blob_kzg_proof_batch call (all kernels + host pairing); dominant_kernel_* is k_challenge alone"})
+                     "call_ms": call_ms, "scope": "whole verify_blob_kzg_proof_batch call (all kernels + host pairing); dominant_kernel_* is k_challenge alone",
+                     "longest_kernel_by_duration": longest, "longest_kernel_ms": kinds[longest][0] / kinds[longest][1],
+                     "dominant_kernel_by_bytes": dominant,
+                     "kernel_naming": "`kernel` = the kernel that moves the call's algorithmic bytes and runs ALONE on the chip (k_challenge: every blob byte once); "
+                                      "the longest event span of the call is `longest_kernel_by_duration` (the point decoder's, stretched by k_eval_frac beside it on a second stream)"})
     return roof
+
+
+ROOFLINE_FIRST = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "valu_issue_frac", "valu_issue_kernel_frac",
+                  "valu_issue_floor_ms", "shader_clock_ghz", "kernel_ms", "call_ms", "verify_valu_issue_frac", "verify_frac", "verify_longest_kernel_by_duration",
+                  "proof_valu_issue_frac", "proof_frac", "valu_frac", "launches")
+
+
+def flatten_valu_issue(roof):
+    """the figures that say how close a workload is to its real bound, as SCALARS of the roofline object itself (the nested
+    `valu_issue` dict stays for the detail): a reader that keeps only an object's first scalar fields still sees them"""
+    vi = roof.get("valu_issue") or {}
+    clk = roof.get("shader_clock_ghz_during_run")
+    roof["valu_issue_frac"] = vi.get("frac")
+    roof["valu_issue_kernel_frac"] = vi.get("kernel_frac")
+    roof["valu_issue_floor_ms"] = vi.get("floor_ms")
+    roof["shader_clock_ghz"] = clk[0] if isinstance(clk, (list, tuple)) and clk else vi.get("clock_ghz")
+    roof.setdefault("call_ms", vi.get("call_ms"))
+
+
+def ordered_roofline(roof):
+    return dict([(k, roof[k]) for k in ROOFLINE_FIRST if k in roof] + [(k, v) for k, v in roof.items() if k not in ROOFLINE_FIRST])
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -783,7 +810,7 @@ def run_rank(args, rank, local_rank, world):
     gathered = torch.empty(world * n * 48, dtype=torch.uint8, device=R.dev) if R.use_dist else None
     verdicts = []
 
-    flight = args.in_flight or (3 if wl == "proof" else 1)
+    flight = args.in_flight or 1  # one call at a time for every workload: what the reference's methods and its criterion bench are
     lanes = R.lanes(flight, n) if wl != "verify" else []
     tick = [0]
 
@@ -900,6 +927,23 @@ def run_rank(args, rank, local_rank, world):
             "hbm_plan_gib": {k: round(v / GIB, 2) for k, v in R.plan.items() if k in ("table", "blobs", "workspace", "resident_total", "peak_total", "hbm_total")},
         },
     }
+    if wl == "proof" and flight == 1 and not R.use_dist and not args.no_extra:  # (the PMC child passes run --no-extra: only the counted calls)
+        # beside the per-call figure (`value`): the amortised rate of a caller that keeps three calls in flight on three streams
+        lanes3 = R.lanes(3, n)
+        tick3 = [0]
+
+        def in_flight3():
+            st, raw, o, stt = lanes3[tick3[0] % 3]
+            tick3[0] += 1
+            with torch.cuda.stream(st):
+                R.prove(d_blobs, d_com, n, o, stt, raw)
+
+        dt3, _ = R.measure(in_flight3, max(6, 3 * ((args.steps + 2) // 3)), warm=6)
+        for _, _, o, stt in lanes3:
+            assert int(stt.abs().sum()) == 0 and torch.equal(o, d_out), "calls in flight must not change a byte"
+        result["value_three_calls_in_flight"] = n / dt3
+        result["ms_per_step_three_calls_in_flight"] = 1e3 * dt3
+        del lanes3
     if rank == 0:
         roof = roofline_object(wl, n, prof, setup.window_bits, call_ms=1e3 * elapsed / args.steps)
         if wl in ("commit", "proof") and roof and prof["msm_launches"]:
@@ -984,10 +1028,24 @@ def run_rank(args, rank, local_rank, world):
                     pmc2 = live_pmc(args, w2, n2, ("SQ_INSTS_VALU",))
                     rec["roofline"]["valu_issue"] = valu_issue_object(pmc2, w2, issue, simds, rec["ms_per_batch"], rec["roofline"].get("kernel_ms"),
                                                                       extra_calls=1 if w2 == "proof" else 0, run_clock=rec["roofline"].get("shader_clock_ghz_during_run"))
+                    flatten_valu_issue(rec["roofline"])
+                    rec["roofline"] = ordered_roofline(rec["roofline"])
                 for sm in result.get("secondary_metrics", []):
                     key = "verify_blob_kzg_proof_batch" if "verify" in sm["metric"] else "compute_blob_kzg_proof"
-                    vi = extra.get(key, {}).get("roofline", {}).get("valu_issue", {})
-                    sm["valu_issue_frac"] = vi.get("frac")
+                    r2 = extra.get(key, {}).get("roofline", {})
+                    sm.update({"valu_issue_frac": r2.get("valu_issue_frac"), "valu_issue_floor_ms": r2.get("valu_issue_floor_ms"),
+                               "valu_issue_kernel_frac": r2.get("valu_issue_kernel_frac"), "shader_clock_ghz": r2.get("shader_clock_ghz")})
+                # the other two workloads' bound figures as scalars of the HEADLINE roofline too (a reader of the first-level record
+                # sees how far each of BASELINE's three workloads is from its own issue floor)
+                rv, rp = (extra.get(k, {}).get("roofline") or {} for k in ("verify_blob_kzg_proof_batch", "compute_blob_kzg_proof"))
+                roof.update({"verify_valu_issue_frac": rv.get("valu_issue_frac"), "verify_frac": rv.get("frac"), "proof_valu_issue_frac": rp.get("valu_issue_frac"),
+                             "proof_frac": rp.get("frac"),
+                             "verify_longest_kernel_by_duration": "%s %.2f ms (beside k_eval_frac on a second stream); `kernel` of the verify roofline = %s %.2f ms, alone on the chip"
+                             % (rv.get("longest_kernel_by_duration"), rv.get("longest_kernel_ms") or 0.0, rv.get("dominant_kernel_by_bytes"), rv.get("kernel_ms") or 0.0)
+                             if rv.get("longest_kernel_by_duration") else None})
+            flatten_valu_issue(roof)
+        if roof is not None:
+            result["roofline"] = ordered_roofline(roof)
         print(json.dumps(result), flush=True)
     setup.close()
     if R.use_dist:
