@@ -81,6 +81,9 @@ def parse():
                     "verification through it -- exercises the RCCL calls of the N-rank path on a one-GPU box")
     ap.add_argument("--spawn", action="store_true", help="start the rank processes through this script's launcher even for --gpus 1 (checks the launcher against the direct path)")
     ap.add_argument("--rank-logs", default=os.path.join(ROOT, "gpurun_out", "bench_ranks"), help="launcher: directory for every rank's stdout/stderr (rank<k>.out / rank<k>.err)")
+    ap.add_argument("--group", type=int, default=0, help="ONE process, a GROUP context of N members behind the C ABI (kzg_config.devices / ndev) driven through the "
+                    "device-resident sharded calls kzg_*_group_dev: member k's --batch blobs resident on member k's GPU, no torch.distributed, no collective.  Members sit on "
+                    "devices 0..N-1; when fewer GPUs are visible they share device 0 (a rehearsal of the code path, not a speed-up).  Same JSON line; roofline from member 0's kernels")
     ap.add_argument("--dry-run", action="store_true", help="print every rank's HBM plan for --workload/--batch/--gpus as one JSON line and exit non-zero if it cannot fit; touches no GPU")
     ap.add_argument("--assume-hbm-gib", type=float, default=0.0, help="--dry-run: HBM per GPU in GiB (default: 288, what an MI355X reports)")
     return ap.parse_args()
@@ -1053,10 +1056,122 @@ def run_rank(args, rank, local_rank, world):
         R.dist.destroy_process_group()
 
 
+def run_group(args):
+    """`--group N`: the drop-in's multi-GPU path (Setup::load_json creates ONE context over the node's
+    GPUs) measured the way `--gpus N` measures the one-process-per-GPU path: weak scaling, --batch items per member, inputs resident
+    on each member's device, K steps between two full synchronisations of every device."""
+    import torch
+
+    import kateth_amd
+
+    wl, S = args.workload, args.group
+    n = args.batch or DEFAULT_BATCH[wl]
+    ndev = torch.cuda.device_count()
+    assert torch.cuda.is_available() and ndev >= 1, "bench.py needs an MI355X; the engine has no CPU fallback"
+    devices = list(range(S)) if ndev >= S else [0] * S
+    setup_path = os.path.join(ROOT, "tests", "golden", "trusted_setup_4096.json")
+    t0 = time.time()
+    # members that share a card share its HBM: an explicit class that fits S times (class 16 = 12.9 GB each) unless the caller chose
+    wb = args.window_bits or (0 if len(set(devices)) == S else 16)
+    setup = kateth_amd.Setup.load_json(setup_path, window_bits=wb, devices=devices, table_max=not args.default_budget and len(set(devices)) == S)
+    setup.wait_ready()
+    t_setup = time.time() - t0
+    members = [setup.member(k) for k in range(S)]
+
+    def on(k):
+        return torch.device("cuda", devices[k])
+
+    def sync_all():
+        for d in sorted(set(devices)):
+            torch.cuda.synchronize(d)
+
+    blobs, com, prf, out, stat = [], [], [], [], []
+    for k in range(S):
+        with torch.cuda.device(devices[k]):
+            b = torch.empty(n * BYTES_PER_BLOB, dtype=torch.uint8, device=on(k))
+            members[k].synth_blobs_dev(SEED, k * n, n, b.data_ptr(), torch.cuda.current_stream(devices[k]).cuda_stream)
+            blobs.append(b)
+            out.append(torch.zeros(n * 48, dtype=torch.uint8, device=on(k)))
+            stat.append(torch.zeros(n, dtype=torch.int32, device=on(k)))
+    sync_all()
+    ptr = lambda ts: [t.data_ptr() for t in ts]  # noqa: E731
+    counts = [n] * S
+    streams = []
+    for k in range(S):
+        with torch.cuda.device(devices[k]):
+            streams.append(torch.cuda.Stream(device=on(k)))
+    raw_streams = [st.cuda_stream for st in streams]
+    verdicts = []
+    if wl != "commit":  # the inputs of the timed calls come from the same group calls
+        com = [torch.zeros(n * 48, dtype=torch.uint8, device=on(k)) for k in range(S)]
+        setup.blob_to_commitment_batch_group_dev(ptr(blobs), counts, ptr(com), ptr(stat), raw_streams)
+        sync_all()
+    if wl == "verify":
+        prf = [torch.zeros(n * 48, dtype=torch.uint8, device=on(k)) for k in range(S)]
+        setup.compute_blob_proof_batch_group_dev(ptr(blobs), ptr(com), counts, ptr(prf), ptr(stat), raw_streams)
+        sync_all()
+    assert all(int(t.abs().sum()) == 0 for t in stat), "synthetic blobs must all be valid"
+
+    def step():
+        if wl == "commit":
+            setup.blob_to_commitment_batch_group_dev(ptr(blobs), counts, ptr(out), ptr(stat), raw_streams)
+        elif wl == "proof":
+            setup.compute_blob_proof_batch_group_dev(ptr(blobs), ptr(com), counts, ptr(out), ptr(stat), raw_streams)
+        else:
+            verdicts.append(setup.verify_blob_proof_batch_group_dev(ptr(blobs), ptr(com), ptr(prf), counts, raw_streams))
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    members[0].profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    prof = members[0].profile_end()
+    prof["calls"] = args.steps
+    assert all(int(t.abs().sum()) == 0 for t in stat) and all(v is True for v in verdicts)
+    if wl != "verify":  # member 0's share holds the golden blobs
+        check_golden(out[0].cpu().numpy().tobytes(), n, 0, "commitment" if wl == "commit" else "proof")
+        # and the last member's share against the single-device call of the same member
+        ref = torch.zeros_like(out[-1])
+        st2 = torch.zeros_like(stat[-1])
+        with torch.cuda.device(devices[-1]):
+            if wl == "commit":
+                members[-1].blob_to_commitment_batch_dev(blobs[-1].data_ptr(), n, ref.data_ptr(), st2.data_ptr(), raw_streams[-1])
+            else:
+                members[-1].compute_blob_proof_batch_dev(blobs[-1].data_ptr(), com[-1].data_ptr(), n, ref.data_ptr(), st2.data_ptr(), raw_streams[-1])
+        sync_all()
+        assert torch.equal(ref, out[-1]), "group call != single-device call on the last member's share"
+    roof = roofline_object(wl, n, prof, members[0].window_bits, call_ms=1e3 * elapsed / args.steps)
+    if roof is not None:
+        roof["scope"] = "member 0's kernels (one of %d members); achieved = algorithmic bytes of ONE member's share / its kernel time" % S
+        roof = ordered_roofline(roof)
+    result = {
+        "metric": METRIC[wl], "value": S * n * args.steps / elapsed, "unit": "blobs/s", "n_gpus": len(set(devices)), "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE,
+        "data": "synthetic: element(b,i)=SHA-256(seed||b||i) mod r, generated on each member's device, resident in its HBM",
+        "config": {"workload": "%s batch=%d items per member, GROUP context of %d members in one process (kzg_*_group_dev, device-resident shares)"
+                               % ({"commit": "blob_to_kzg_commitment", "proof": "compute_blob_kzg_proof", "verify": "verify_blob_kzg_proof_batch"}[wl], n, S),
+                   "blobs_per_gpu": n, "members": S, "member_devices": devices, "members_share_a_card": len(set(devices)) != S, "window_bits": members[0].window_bits,
+                   "table_gib_per_member": members[0].table_bytes / 2**30, "plane_groups": members[0].plane_groups, "setup_s": t_setup,
+                   "parallelism": "blob-sharded x%d inside one process behind the C ABI: no collective; verify: the members' 32-B roots seed one challenge, 192-B partial sums, "
+                                  "one pairing" % S},
+        "roofline": roof,
+        "cpu_baseline": None,
+        "note": "cpu_baseline and the live PMC passes belong to the default single-GPU run (python bench.py); this mode measures the group path",
+    }
+    print(json.dumps(result), flush=True)
+    setup.close()
+
+
 def main():
     args = parse()
     if args.dry_run:
         return dry_run(args)
+    if args.group:
+        return run_group(args)
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None:
         if args.gpus > 1 or args.spawn:

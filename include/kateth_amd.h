@@ -23,11 +23,13 @@
  *
  * Streams and hardware queues: the HIP runtime multiplexes all streams of a
  * process onto GPU_MAX_HW_QUEUES hardware queues (4 unless set) and streams
- * that share a queue run one after the other.  The library's load-time
- * constructor sets GPU_MAX_HW_QUEUES=16 if the variable is unset (setenv at
- * dlopen time, before HIP initialises); a host program that initialises HIP
- * before loading the library, or that is multi-threaded while loading it,
- * should export the variable itself.
+ * that share a queue run one after the other.  The variable is read when the
+ * PROCESS first touches HIP, so it is the host program's to set: the library
+ * never changes the environment.  kzg_recommended_env() returns the setting
+ * the measured configurations ran with ("GPU_MAX_HW_QUEUES=16"); with
+ * KATETH_AMD_TRACE set, kzg_ctx_create says once when it is missing or below
+ * 8.  Results never depend on it -- only how many
+ * calls kept in flight on different streams really overlap.
  *
  * Return value of every call: 0 on success, a positive KZG_ERR_* code when an
  * input is rejected the way the reference returns Err, a negative KZG_FAIL_*
@@ -109,6 +111,9 @@ typedef struct kzg_ctx kzg_ctx;
                                  * identical before and after the swap (kzg_ctx_ready / kzg_ctx_wait_ready) */
 #define KZG_ALL_DEVICES 0xffffffffu /* ndev: every HIP device visible to the process */
 typedef struct kzg_config {
+  uint32_t struct_size; /* = sizeof(kzg_config) of the header the caller was compiled against (KZG_CONFIG_INIT sets it): the library
+                         * rejects a size it does not know instead of reading fields the caller never wrote (the struct has grown
+                         * between rounds and will again) */
   int32_t device;       /* HIP device ordinal this context lives on (ignored when ndev != 0) */
   int32_t window_bits;  /* table class: 22, 16..21 (-> 16), 8..15 (-> 8), 4..7 (-> 4); 0 = automatic (above) */
   int32_t flags;        /* KZG_CFG_* bits */
@@ -126,6 +131,11 @@ typedef struct kzg_config {
   uint32_t ndev;          /* 0 = a single-device context on `device` */
   uint32_t reserved;      /* must be 0 */
 } kzg_config;
+#define KZG_CONFIG_INIT {(uint32_t)sizeof(kzg_config), 0, 0, 0, 0, 0, NULL, 0, 0} /* kzg_config cfg = KZG_CONFIG_INIT; then set fields */
+
+/* "NAME=value" of the one environment variable of the HIP runtime the measured configurations depend on (see "Streams and
+ * hardware queues" above); static storage.  The library itself never calls setenv. */
+const char* kzg_recommended_env(void);
 
 /* Thread-local text for the last negative return on this thread ("" if none). */
 const char* kzg_last_error(void);
@@ -165,6 +175,9 @@ int32_t kzg_ctx_window_bits(const kzg_ctx* ctx);
 const char* kzg_ctx_msm_kernel_name(const kzg_ctx* ctx); /* the dominant kernel bench.py names in `roofline` */
 int32_t kzg_ctx_plane_groups(const kzg_ctx* ctx);
 uint64_t kzg_ctx_table_bytes(const kzg_ctx* ctx);
+/* bytes of commitment / proof workspace slot `slot` (0..2) as allocated so far: a caller that runs one call at a time only ever
+ * grows slot 0; slots 1 and 2 are allocated when calls are found in flight side by side (tests, memory accounting) */
+uint64_t kzg_ctx_workspace_bytes(const kzg_ctx* ctx, uint32_t slot);
 
 /*
  * Replaces Setup::blob_to_commitment + Compress::compress for n blobs
@@ -245,6 +258,31 @@ int32_t kzg_verify_blob_proof(const kzg_ctx* ctx, const uint8_t* blob, const uin
 
 /* Replaces Setup::verify_proof (src/kzg/setup.rs:96-113). */
 int32_t kzg_verify_proof(const kzg_ctx* ctx, const uint8_t* proof48, const uint8_t* commitment48, const uint8_t* z32, const uint8_t* y32, int32_t* ok);
+
+/*
+ * DEVICE-RESIDENT sharded calls on a GROUP context (kzg_config.devices / ndev): member k's share of the batch is resident on
+ * member k's GPU -- what a node keeps when blobs arrive over the network or are produced on the devices, and the only way a
+ * group verifies faster than PCIe delivers (host-buffer verification tops out near 0.37 M blobs/s per GPU, device-resident
+ * verification runs at 4.4 M).  Every array argument has kzg_ctx_members(ctx) entries, indexed by member; the GLOBAL order of
+ * the batch is member order (member 0's n_local[0] items first), which is what the powers r^i of the batch check and the
+ * first-error-wins order (src/kzg/setup.rs:259-271: lowest global index of the first kind with an error) are taken over.
+ * n_local[k] may be 0.  hip_streams may be NULL (every member's default stream) or one hipStream_t per member, created on that
+ * member's device.
+ *   commit / proof : enqueue on every member and return WITHOUT synchronising, like the *_dev calls
+ *                    (src/kzg/setup.rs:167-171, 177-183 per item); results and per-item statuses stay on each member's device.
+ *   verify         : synchronous like kzg_verify_blob_proof_batch_dev: per member hash, evaluation, decoding and transcript,
+ *                    the members' roots seed ONE challenge, per member the two partial lincombs (bucket kernels start the
+ *                    moment that member's decoder ends, as in the single-device call), one pairing check
+ *                    (src/kzg/setup.rs:223-275).  Same boolean and same first-error code as the single-device call over the
+ *                    concatenated batch.
+ * On a single-device context they are the *_dev calls with one-element arrays.
+ */
+int32_t kzg_blob_to_commitment_batch_group_dev(const kzg_ctx* ctx, const void* const* d_blobs, const uint64_t* n_local, void* const* d_out48,
+                                               void* const* d_status, void* const* hip_streams);
+int32_t kzg_compute_blob_proof_batch_group_dev(const kzg_ctx* ctx, const void* const* d_blobs, const void* const* d_commitments48, const uint64_t* n_local,
+                                               void* const* d_out48, void* const* d_status, void* const* hip_streams);
+int32_t kzg_verify_blob_proof_batch_group_dev(const kzg_ctx* ctx, const void* const* d_blobs, const void* const* d_commitments48,
+                                              const void* const* d_proofs48, const uint64_t* n_local, int32_t* ok, void* const* hip_streams);
 
 /*
  * Multi-GPU batch verification.  Blobs are sharded by

@@ -9,12 +9,82 @@
 
 #include <algorithm>
 // The engine overlaps kernels on several HIP streams; the runtime multiplexes all streams of a process onto
-// GPU_MAX_HW_QUEUES hardware queues (4 by default) and streams that share a queue run one after the other.  The flag is read
-// when HIP initialises (the first API call), so a load-time default is in time for every caller that has not touched HIP yet;
-// an explicit setting in the environment is left alone.  16: a process that keeps three calls in flight has the caller's three
+// GPU_MAX_HW_QUEUES hardware queues (4 by default) and streams that share a queue run one after the other.  The variable is
+// read when HIP initialises (the first API call of the PROCESS), so it belongs to the host program: the library does not touch
+// the environment (rounds 3-4 set it from a load-time constructor: a process-wide side effect, not thread-safe, and silently
+// void when HIP was already up -- VERDICT r04 #6).  kzg_recommended_env() names the setting; kzg_ctx_create says so once under
+// KATETH_AMD_TRACE when the variable is missing or low.  16: a process that keeps three calls in flight has the caller's three
 // streams beside a dozen of the engine's own (copy, staging, session streams); with 8 queues two of the three lanes shared a
-// queue in bench.py's default run (+5 % instead of +11 % over one call at a time), with 12, 16 and 24 none did.
-__attribute__((constructor)) static void kzg_default_hw_queues() { (void)setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+// queue in bench.py's proof run (+5 % instead of +11 % over one call at a time), with 12, 16 and 24 none did.
+extern "C" const char* kzg_recommended_env(void) { return "GPU_MAX_HW_QUEUES=16"; }
+static void hw_queues_note(bool trace) {
+  static std::atomic<bool> said{false};
+  if (!trace || said.exchange(true)) return;
+  const char* e = getenv("GPU_MAX_HW_QUEUES");
+  if (!e || atoi(e) < 8)
+    fprintf(stderr, "[kateth_amd trace] GPU_MAX_HW_QUEUES is %s: calls kept in flight on several streams may share a hardware queue and run one after "
+                    "the other; export %s before the process first touches HIP (the library does not change the environment)\n",
+            e ? e : "unset (the runtime's default is 4)", kzg_recommended_env());
+}
+
+// ---- pooled helper threads (engine_internal.hpp: helper_dispatch / run_on_helpers) ----------------------------------------
+namespace {
+class HelperPool {
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<std::function<void()>> q;
+  std::vector<std::thread> threads;
+  uint32_t idle = 0;
+  bool stop = false;
+  static constexpr uint32_t CAP = 96;  // group members (<= 64) + the two-thread endings of the members' calls
+
+  void worker() {
+    std::unique_lock<std::mutex> lk(mu);
+    for (;;) {
+      idle++;
+      cv.wait(lk, [&] { return stop || !q.empty(); });
+      idle--;
+      if (q.empty()) return;  // stop
+      std::function<void()> fn = std::move(q.front());
+      q.pop_front();
+      lk.unlock();
+      fn();
+      lk.lock();
+    }
+  }
+
+ public:
+  bool dispatch(std::function<void()>&& fn) {
+    std::lock_guard<std::mutex> g(mu);
+    if (stop) return false;
+    if (idle > q.size()) {  // an idle worker for every queued job and for this one
+      q.push_back(std::move(fn));
+      cv.notify_one();
+      return true;
+    }
+    if (threads.size() >= CAP) return false;
+    try {
+      threads.emplace_back([this] { worker(); });
+    } catch (...) {  // std::system_error: no thread to be had
+      return false;
+    }
+    q.push_back(std::move(fn));
+    cv.notify_one();
+    return true;
+  }
+  ~HelperPool() {
+    {
+      std::lock_guard<std::mutex> g(mu);
+      stop = true;
+    }
+    cv.notify_all();
+    for (std::thread& t : threads)
+      if (t.joinable()) t.join();
+  }
+};
+HelperPool g_helpers;
+}  // namespace
+bool helper_dispatch(std::function<void()> fn) { return g_helpers.dispatch(std::move(fn)); }
 
 // ---------------------------------------------------------------------------
 // error plumbing
@@ -53,33 +123,63 @@ void error_publish(const ErrorSnapshot& e) {
 
 static int32_t ws_grow(WsSlot& w, size_t bytes) {
   if (w.bytes >= bytes) return 0;
+  size_t want = bytes;
   if (w.p) {
     if (w.ev) HIP_TRY(hipEventSynchronize(w.ev));  // nothing enqueued may still use the old buffer
     HIP_TRY(hipFree(w.p));
     w.p = nullptr;
     w.bytes = 0;
+    want += bytes / 8;  // a slot that grows again is likely to see still larger calls: slack on RE-growth only
   }
-  const size_t want = bytes + bytes / 8;
-  HIP_TRY(hipMalloc(&w.p, want));
+  if (hipMalloc(&w.p, want) != hipSuccess) {
+    (void)hipGetLastError();
+    w.p = nullptr;
+    if (want == bytes || hipMalloc(&w.p, bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      w.p = nullptr;
+      return fail(KZG_FAIL_HIP, "workspace allocation of " + std::to_string(bytes >> 20) + " MiB failed");
+    }
+    want = bytes;
+  }
   w.bytes = want;
   return 0;
 }
-// Every slot grows together: the first large call pays for all of them, so that the SECOND call of a pair in flight does
-// not allocate (and synchronise the device: hipFree) in the middle of a pipeline -- seen as a 20-ms hole in the second step of a
-// traced run.  A slot that is in use is waited for on the host first; growth happens on the first call(s) of a size only.
-int32_t ws_reserve(const kzg_ctx* ctx, size_t bytes) { return ws_reserve_all(ctx, bytes); }
-int32_t ws_reserve_all(const kzg_ctx* ctx, size_t bytes) {
-  for (WsSlot& w : ctx->wss) {
-    int32_t rc = ws_grow(w, bytes);
-    if (rc) return rc;
-  }
-  return 0;
+// The slot of the call being enqueued grows by itself (growing all three together cost a caller that never keeps
+// calls in flight 3 x the workspace, e.g. 14 instead of 5 GiB for proofs in chunks of 16,384 blobs).  If the device has no
+// room for a second or third slot -- a class-16 context created at the 21-GiB rung of the ladder serves ONE 7.5-GiB proof
+// workspace -- the call falls back to a slot that is large enough already and queues behind its user instead of failing.
+int32_t ws_reserve(const kzg_ctx* ctx, size_t bytes, hipStream_t st) {
+  WsSlot& w = ctx->wss[ctx->ws_cur];
+  if (w.bytes >= bytes) return 0;
+  const int32_t rc = ws_grow(w, bytes);
+  if (rc == 0) return 0;
+  for (uint32_t k = 0; k < (uint32_t)KZG_WS_SLOTS; k++)
+    if (k != ctx->ws_cur && ctx->wss[k].bytes >= bytes) {
+      ctx->ws_cur = k;
+      return ws_wait(ctx, st);
+    }
+  return rc;
 }
 
-// Successive calls take the slots in turn; a slot's users on different streams are ordered by its event.
+// A call takes the lowest slot whose previous user has completed; when every slot is busy, the slots in turn.  A slot's users on
+// different streams are ordered by its event.
 int32_t ws_begin(const kzg_ctx* ctx, hipStream_t st) {
-  ctx->ws_cur = ctx->ws_next;
-  ctx->ws_next = (ctx->ws_next + 1u) % KZG_WS_SLOTS;
+  uint32_t pick = (uint32_t)KZG_WS_SLOTS;
+  for (uint32_t k = 0; k < (uint32_t)KZG_WS_SLOTS && pick == (uint32_t)KZG_WS_SLOTS; k++) {
+    const WsSlot& w = ctx->wss[k];
+    if (!w.ev) {
+      pick = k;
+    } else {
+      const hipError_t q = hipEventQuery(w.ev);
+      if (q == hipSuccess) pick = k;
+      else (void)hipGetLastError();  // hipErrorNotReady is not an error of this call
+    }
+  }
+  if (pick == (uint32_t)KZG_WS_SLOTS) {
+    pick = ctx->ws_next % (uint32_t)KZG_WS_SLOTS;
+    ctx->ws_next = (pick + 1u) % (uint32_t)KZG_WS_SLOTS;
+  }
+  ctx->ws_cur = pick;
   return ws_wait(ctx, st);
 }
 int32_t ws_wait(const kzg_ctx* ctx, hipStream_t st) {
@@ -265,6 +365,11 @@ extern "C" uint64_t kzg_ctx_table_bytes(const kzg_ctx* ctx) {
   if (!ctx) return 0;
   std::lock_guard<std::mutex> guard(ctx->lock);
   return ctx->table_bytes;
+}
+extern "C" uint64_t kzg_ctx_workspace_bytes(const kzg_ctx* ctx, uint32_t slot) {
+  if (!ctx || slot >= (uint32_t)KZG_WS_SLOTS) return 0;
+  std::lock_guard<std::mutex> guard(ctx->lock);
+  return ctx->wss[slot].bytes;
 }
 extern "C" uint32_t kzg_ctx_members(const kzg_ctx* ctx) { return ctx ? 1u + (uint32_t)ctx->peers.size() : 0u; }
 extern "C" const kzg_ctx* kzg_ctx_member(const kzg_ctx* ctx, uint32_t k) {
@@ -687,7 +792,9 @@ int32_t ctx_create_single(const uint8_t* g1_lagrange, const uint8_t* g2_monomial
   //   class 22, G = 4 = 96 GiB (63 instead of 31 Horner doublings per lane: -2 %)                         if >= 136 GiB
   //   class 16 (blocks of 16, G = 16, 65,536 additions per blob: -25 %) = 12.9 GB                         if >=  21 GiB
   //   class 8  (blocks of 8, G = 16) = 100 MB                                                             otherwise
-  // (the margins cover the build's 13 GB of staging, the 0.4-GB latency comb, the call workspace and the caller's blobs).
+  // (the margins cover the build's 13 GB of staging, the 0.4-GB latency comb, the caller's blobs and the call workspace: ONE slot --
+  // at most 7.5 GiB, a proof call in chunks of 16,384 blobs -- for a caller that runs one call at a time; callers that keep calls
+  // in flight get up to three slots while the device has room and queue behind a large-enough slot when it has not: ws_reserve).
   // The default budget is 100 GiB: an unconfigured context stops at the 96-GiB table and leaves a 288-GB part two thirds free;
   // KZG_CFG_TABLE_MAX or an explicit table_budget_bytes moves the cap.  If the allocation of an automatically
   // chosen table fails all the same (fragmentation, another process), the next smaller choice is tried.  Precedence: a
@@ -730,6 +837,7 @@ int32_t ctx_create_single(const uint8_t* g1_lagrange, const uint8_t* g2_monomial
   // src/kzg/setup.rs:59-72 -- the context is usable after about as much work), build the chosen table beside the first calls
   if ((flags & KZG_CFG_BUILD_ASYNC) && !g_msm_override_hook && class_blocks(ladder[0].c) < 8u) {
     kzg_ctx* ctx = nullptr;
+    hw_queues_note(getenv("KATETH_AMD_TRACE") != nullptr);
     if (getenv("KATETH_AMD_TRACE"))
       fprintf(stderr, "[kateth_amd trace] kzg_ctx_create device %d: first-use table class 8; class %u, %u plane groups follows in the background\n", device,
               ladder[0].c, ladder[0].G);
@@ -748,6 +856,7 @@ int32_t ctx_create_single(const uint8_t* g1_lagrange, const uint8_t* g2_monomial
     return 0;
   }
   const bool trace = getenv("KATETH_AMD_TRACE") != nullptr;
+  hw_queues_note(trace);
   auto say = [&](const char* how, const TableChoice& ch) {  // the choice, once per context, for whoever asks (KATETH_AMD_TRACE=1)
     if (trace)
       fprintf(stderr, "[kateth_amd trace] kzg_ctx_create device %d: table class %u, %u plane groups (%s; %.1f GiB free, budget %s)\n", device, ch.c, ch.G, how,
@@ -763,9 +872,18 @@ int32_t ctx_create_single(const uint8_t* g1_lagrange, const uint8_t* g2_monomial
   return rc;
 }
 
+// a caller compiled against another revision of the header passes another size: refused, never read past
+static int32_t cfg_check(const kzg_config* cfg) {
+  if (cfg && cfg->struct_size != (uint32_t)sizeof(kzg_config))
+    return fail(KZG_FAIL_ARGUMENT, "kzg_config.struct_size is " + std::to_string(cfg->struct_size) + ", this library's kzg_config has " +
+                                       std::to_string(sizeof(kzg_config)) + " bytes: initialise with KZG_CONFIG_INIT from the matching include/kateth_amd.h");
+  return 0;
+}
+
 extern "C" int32_t kzg_ctx_create(const uint8_t* g1_lagrange, const uint8_t* g2_monomial, const kzg_config* cfg, kzg_ctx** out) {
   if (!g1_lagrange || !g2_monomial || !out) return fail(KZG_FAIL_ARGUMENT, "null argument");
   *out = nullptr;
+  if (int32_t rcc = cfg_check(cfg)) return rcc;
   const int32_t ndev = kzg_device_count();
   if (ndev < 0) return ndev;
   if (cfg && cfg->ndev != 0) return group_create(g1_lagrange, g2_monomial, cfg, out);  // engine_multi.hip
@@ -776,7 +894,8 @@ extern "C" int32_t kzg_ctx_create(const uint8_t* g1_lagrange, const uint8_t* g2_
 
 extern "C" int32_t kzg_ctx_create_multi(const uint8_t* g1_lagrange, const uint8_t* g2_monomial, const int32_t* devices, uint32_t ndev,
                                         const kzg_config* cfg, kzg_ctx** out) {
-  kzg_config c{};
+  kzg_config c = KZG_CONFIG_INIT;
+  if (int32_t rcc = cfg_check(cfg)) return rcc;
   if (cfg) c = *cfg;
   c.devices = devices;
   c.ndev = ndev;
@@ -796,7 +915,7 @@ static int32_t commit_dev_locked(const kzg_ctx* ctx, const void* d_blobs, uint64
   const size_t partial_bytes = align_up((size_t)cn * splits * 65 * sizeof(g1_xyzz), 256);  // 64 lane sums + 1 unit sum per (blob, split)
   const size_t sums_bytes = align_up((size_t)cn * sizeof(g1_xyzz), 256);
   const size_t need = partial_bytes + sums_bytes + msm_scratch_bytes(ctx, cn);
-  int32_t rc = ws_reserve(ctx, need);
+  int32_t rc = ws_reserve(ctx, need, st);
   if (rc) return rc;
   g1_xyzz* partials = reinterpret_cast<g1_xyzz*>(ws_ptr(ctx));
   g1_xyzz* sums = reinterpret_cast<g1_xyzz*>(ws_ptr(ctx) + partial_bytes);
@@ -819,9 +938,10 @@ extern "C" int32_t kzg_blob_to_commitment_batch_dev(const kzg_ctx* ctx, const vo
   HIP_TRY(hipSetDevice(ctx->device));
   std::lock_guard<std::mutex> guard(ctx->lock);
   hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
-  int32_t rc = ws_begin(ctx, st);
+  WsCall ws(ctx, st);
+  int32_t rc = ws.begin();
   if (rc == 0) rc = commit_dev_locked(ctx, d_blobs, n, d_out48, nullptr, reinterpret_cast<int32_t*>(d_status), st);
-  if (rc == 0) rc = ws_end(ctx, st);
+  if (rc == 0) rc = ws.end();
   return rc;
 }
 
@@ -889,6 +1009,7 @@ int32_t commit_host(const kzg_ctx* ctx, const uint8_t* blobs, uint64_t n, uint8_
   hipStream_t comp[2] = {ctx->stage_streams[0], ctx->stage_streams[1]};
   hipStream_t copy_st = one_chunk ? comp[0] : ctx->stage_copy_stream;
   std::lock_guard<std::mutex> guard(ctx->lock);  // the workspace: per slot the lane sums, the sums and the bit-plane masks of a chunk
+  WsCall ws(ctx, comp[0]);
   uint64_t max_units = 1;  // launch shapes follow the table in use, which only changes under this lock
   for (uint64_t m : plan) {
     const uint32_t sp = choose_splits(ctx, m);
@@ -900,9 +1021,9 @@ int32_t commit_host(const kzg_ctx* ctx, const uint8_t* blobs, uint64_t n, uint8_
     const size_t sums_bytes = align_up((size_t)max_chunk * sizeof(g1_xyzz), 256);
     const size_t scratch_bytes = align_up(msm_scratch_bytes(ctx, max_chunk), 256);
     const size_t per_slot = partial_bytes + sums_bytes + scratch_bytes;
-    rc = ws_begin(ctx, comp[0]);
+    rc = ws.begin();
+    if (rc == 0) rc = ws_reserve(ctx, nslots * per_slot, comp[0]);
     if (rc == 0 && !one_chunk) rc = ws_wait(ctx, comp[1]);
-    if (rc == 0) rc = ws_reserve(ctx, nslots * per_slot);
     if (rc) break;
     if (hipMemsetAsync(d_status, 0, n * sizeof(int32_t), comp[0]) != hipSuccess ||
         (!one_chunk && (hipEventRecord(ctx->stage_join[0], comp[0]) != hipSuccess || hipStreamWaitEvent(comp[1], ctx->stage_join[0], 0) != hipSuccess))) {
@@ -941,7 +1062,7 @@ int32_t commit_host(const kzg_ctx* ctx, const uint8_t* blobs, uint64_t n, uint8_
       rc = fail(KZG_FAIL_HIP, "stream join failed");
       break;
     }
-    rc = ws_end(ctx, comp[0]);
+    rc = ws.end();
     if (rc) break;
     if (hipMemcpyAsync(out48 ? out48 : out_affine96, d_res, (size_t)n * (out48 ? 48 : 96), hipMemcpyDeviceToHost, comp[0]) != hipSuccess ||
         hipMemcpyAsync(status, d_status, n * sizeof(int32_t), hipMemcpyDeviceToHost, comp[0]) != hipSuccess ||

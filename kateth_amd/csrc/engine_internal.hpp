@@ -9,6 +9,8 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <deque>
+#include <functional>
 #include <mutex>
 #include <new>
 #include <string>
@@ -34,35 +36,59 @@ struct ErrorSnapshot {
 ErrorSnapshot error_snapshot();
 void error_publish(const ErrorSnapshot& e);
 
-// Runs job(k) for k < count: job 0 on the calling thread, the others on one helper thread each (a helper that cannot be
-// started -- thread exhaustion -- runs inline instead: nothing throws across the C boundary).  Returns the first non-zero
-// code in k order, with THAT job's error text re-published on the calling thread.
+// Persistent helper threads of the process (engine.hip): a job goes to an idle worker, or to a new one while fewer than the
+// cap exist; `false` = no worker to be had, the caller runs the job itself.  Workers never block on other jobs' results, so nested
+// use (a group call whose members each split their ending over two threads) cannot deadlock.  ADVICE r04: run_on_helpers used to
+// start a std::thread per job -- thread creation and a first hipSetDevice on the latency path of every group call and of every
+// single-item verification.
+bool helper_dispatch(std::function<void()> fn);
+
+// Runs job(k) for k < count: job 0 on the calling thread, the others on pooled helper threads (a job no helper can take runs
+// inline: nothing throws across the C boundary).  Returns the first non-zero code in k order, with THAT job's error text
+// re-published on the calling thread.
 template <class Job>
 static int32_t run_on_helpers(uint32_t count, Job&& job) {
   if (count == 0) return 0;
   std::vector<int32_t> rc(count, 0);
   std::vector<ErrorSnapshot> err(count);
-  std::vector<std::thread> helpers;
-  helpers.reserve(count);
-  std::vector<char> started(count, 0);
+  std::vector<char> handed(count, 0);
+  std::mutex mu;
+  std::condition_variable cv;
+  uint32_t pending = 0;
   for (uint32_t k = 1; k < count; k++) {
+    {
+      std::lock_guard<std::mutex> g(mu);
+      pending++;
+    }
+    bool ok = false;
     try {
-      helpers.emplace_back([&, k]() {
+      ok = helper_dispatch([&, k]() {
         rc[k] = job(k);
         if (rc[k]) err[k] = error_snapshot();
+        std::lock_guard<std::mutex> g(mu);  // notified under the lock: the waiter cannot destroy `cv` before this returns
+        pending--;
+        cv.notify_one();
       });
-      started[k] = 1;
-    } catch (...) {  // std::system_error: no thread to be had
+    } catch (...) {  // std::bad_alloc building the closure
+    }
+    if (ok) {
+      handed[k] = 1;
+    } else {
+      std::lock_guard<std::mutex> g(mu);
+      pending--;
     }
   }
   rc[0] = job(0);
   if (rc[0]) err[0] = error_snapshot();
   for (uint32_t k = 1; k < count; k++)
-    if (!started[k]) {
+    if (!handed[k]) {
       rc[k] = job(k);
       if (rc[k]) err[k] = error_snapshot();
     }
-  for (auto& t : helpers) t.join();
+  {
+    std::unique_lock<std::mutex> g(mu);
+    cv.wait(g, [&] { return pending == 0; });
+  }
   for (uint32_t k = 0; k < count; k++)
     if (rc[k]) {
       error_publish(err[k]);
@@ -198,11 +224,13 @@ struct kzg_ctx {
   EnvKnobs knobs;  // read once at kzg_ctx_create
   // workspace (grown on demand, guarded by lock)
   mutable std::mutex lock;
-  // KZG_WS_SLOTS workspaces taken in turn by successive commitment / proof calls: a call's stream waits for the previous
-  // user of ITS slot only, so calls enqueued on several streams run side by side (one call's hash and quotient kernels in
-  // the shadow of the other's MSM) instead of queueing behind one shared buffer
+  // KZG_WS_SLOTS workspaces for commitment / proof calls: a call takes the LOWEST slot whose previous user has completed (a
+  // caller that runs one call at a time lives in slot 0, and only slot 0 is ever allocated), else the slots in turn; its
+  // stream waits for the previous user of ITS slot only, so calls enqueued on several streams run side by side (one call's
+  // hash and quotient kernels in the shadow of the other's MSM) instead of queueing behind one shared buffer.  Each slot
+  // grows by itself, to the largest call it has served.
   mutable WsSlot wss[KZG_WS_SLOTS];
-  mutable uint32_t ws_next = 0;  // slot of the next call
+  mutable uint32_t ws_next = 0;  // next slot in turn when every slot is busy
   mutable uint32_t ws_cur = 0;   // slot of the call being enqueued (between ws_begin and ws_end, under `lock`)
   mutable std::vector<hipEvent_t> proof_events;  // pooled fork/join events of the proof path's chunk pipeline (guarded by lock)
   // profiling (kzg_profile_begin/end): event pairs around the launches of the kernels named by ProfKind, each pair on the
@@ -252,6 +280,14 @@ int32_t multi_verify_batch(const kzg_ctx* ctx, const uint8_t* blobs, const uint8
 int32_t multi_verify_proof(const kzg_ctx* ctx, const uint8_t* proof48, const uint8_t* commitment48, const uint8_t* z32, const uint8_t* y32, int32_t* ok);
 int32_t multi_g1_decompress(const kzg_ctx* ctx, const uint8_t* in48, uint64_t n, uint8_t* out_affine96, int32_t* status);
 int32_t multi_evaluate_blobs(const kzg_ctx* ctx, const uint8_t* blobs, const uint8_t* z32, uint64_t n, uint8_t* out_y32, int32_t* status);
+// one member's device-resident share of a group verification (kzg_verify_blob_proof_batch_group_dev): global range [first, first + count)
+struct GroupDevShare {
+  const kzg_ctx* member;
+  const uint8_t *blobs, *commitments48, *proofs48;  // resident on member->device
+  uint64_t first, count;
+  hipStream_t st;
+};
+int32_t verify_group_dev(const kzg_ctx* ctx, const std::vector<GroupDevShare>& shares, uint64_t n_total, int32_t* ok);  // engine_verify.hip
 int32_t stage_init(const kzg_ctx* ctx);                                             // caller holds stage_lock
 int32_t stage_reserve(const kzg_ctx* ctx, size_t arena_bytes, size_t io_bytes);   // caller holds stage_lock
 void stage_destroy(const kzg_ctx* ctx);
@@ -259,9 +295,29 @@ void stage_destroy(const kzg_ctx* ctx);
 // workspace of the call being enqueued (caller holds ctx->lock from ws_begin to ws_end)
 int32_t ws_begin(const kzg_ctx* ctx, hipStream_t st);    // takes the next slot; `st` waits for the slot's previous user
 int32_t ws_wait(const kzg_ctx* ctx, hipStream_t st);     // a further stream of the same call waits for it too
-int32_t ws_reserve(const kzg_ctx* ctx, size_t bytes);    // grows the slot (waits for its previous user on the host first)
-int32_t ws_reserve_all(const kzg_ctx* ctx, size_t bytes);  // every slot: a pipeline sizes them once, before anything is in flight
+int32_t ws_reserve(const kzg_ctx* ctx, size_t bytes, hipStream_t st);  // grows THIS slot only (waits for its previous user on the host first); if the
+                                                                        // device has no room, falls back to a slot that is large enough already and makes `st` wait for it
 int32_t ws_end(const kzg_ctx* ctx, hipStream_t st);      // records the slot's event on `st`
+// ws_begin ... ws_end of one call; an error return in between still records the slot's event (kernels of the failed call that
+// were already enqueued are then ordered before the slot's next user -- ADVICE r04)
+struct WsCall {
+  const kzg_ctx* ctx;
+  hipStream_t st;
+  bool open = false;
+  WsCall(const kzg_ctx* c, hipStream_t s) : ctx(c), st(s) {}
+  int32_t begin() {
+    const int32_t rc = ws_begin(ctx, st);
+    open = rc == 0;
+    return rc;
+  }
+  int32_t end() {
+    open = false;
+    return ws_end(ctx, st);
+  }
+  ~WsCall() {
+    if (open) (void)ws_end(ctx, st);
+  }
+};
 static inline uint8_t* ws_ptr(const kzg_ctx* ctx) { return reinterpret_cast<uint8_t*>(ctx->wss[ctx->ws_cur].p); }
 int32_t prof_next(const kzg_ctx* ctx, int kind, hipEvent_t* e0, hipEvent_t* e1);
 // brackets the launches enqueued on `st` during its lifetime with an event pair (no-op unless profiling)

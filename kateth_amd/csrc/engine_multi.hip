@@ -149,3 +149,51 @@ int32_t multi_verify_batch(const kzg_ctx* ctx, const uint8_t* blobs, const uint8
   if (rc) return rc;
   return kzg_verify_batch_finish(ctx, partials.data(), W, ok);
 }
+
+// ---- device-resident sharded calls (include/kateth_amd.h: kzg_*_group_dev) -------------------------------------------------
+// Member k's share is resident on member k's GPU.  Commitments and proofs only ENQUEUE (like the *_dev calls), one pooled host
+// thread per member so that the members' launches go out side by side; nothing is gathered -- results stay where they were
+// computed.  Batch verification: engine_verify.hip (verify_group_dev).
+namespace {
+template <class Call>
+int32_t group_enqueue(const kzg_ctx* ctx, const uint64_t* n_local, Call&& call) {
+  const uint32_t S = 1u + (uint32_t)ctx->peers.size();
+  std::vector<uint32_t> busy;
+  for (uint32_t k = 0; k < S; k++)
+    if (n_local[k]) busy.push_back(k);
+  return run_on_helpers((uint32_t)busy.size(), [&](uint32_t j) -> int32_t { return call(busy[j], member_of(ctx, busy[j])); });
+}
+}  // namespace
+
+extern "C" int32_t kzg_blob_to_commitment_batch_group_dev(const kzg_ctx* ctx, const void* const* d_blobs, const uint64_t* n_local, void* const* d_out48,
+                                                          void* const* d_status, void* const* hip_streams) {
+  if (!ctx || !d_blobs || !n_local || !d_out48 || !d_status) return fail(KZG_FAIL_ARGUMENT, "null argument");
+  return group_enqueue(ctx, n_local, [&](uint32_t k, const kzg_ctx* m) -> int32_t {
+    return kzg_blob_to_commitment_batch_dev(m, d_blobs[k], n_local[k], d_out48[k], d_status[k], hip_streams ? hip_streams[k] : nullptr);
+  });
+}
+
+extern "C" int32_t kzg_compute_blob_proof_batch_group_dev(const kzg_ctx* ctx, const void* const* d_blobs, const void* const* d_commitments48,
+                                                          const uint64_t* n_local, void* const* d_out48, void* const* d_status, void* const* hip_streams) {
+  if (!ctx || !d_blobs || !d_commitments48 || !n_local || !d_out48 || !d_status) return fail(KZG_FAIL_ARGUMENT, "null argument");
+  return group_enqueue(ctx, n_local, [&](uint32_t k, const kzg_ctx* m) -> int32_t {
+    return kzg_compute_blob_proof_batch_dev(m, d_blobs[k], d_commitments48[k], n_local[k], d_out48[k], d_status[k], hip_streams ? hip_streams[k] : nullptr);
+  });
+}
+
+extern "C" int32_t kzg_verify_blob_proof_batch_group_dev(const kzg_ctx* ctx, const void* const* d_blobs, const void* const* d_commitments48,
+                                                         const void* const* d_proofs48, const uint64_t* n_local, int32_t* ok, void* const* hip_streams) {
+  if (!ctx || !ok || !d_blobs || !d_commitments48 || !d_proofs48 || !n_local) return fail(KZG_FAIL_ARGUMENT, "null argument");
+  *ok = 0;
+  const uint32_t S = 1u + (uint32_t)ctx->peers.size();
+  std::vector<GroupDevShare> shares;
+  uint64_t total = 0;
+  for (uint32_t k = 0; k < S; k++) {
+    if (n_local[k] == 0) continue;
+    if (!d_blobs[k] || !d_commitments48[k] || !d_proofs48[k]) return fail(KZG_FAIL_ARGUMENT, "null device pointer for a member with items");
+    shares.push_back(GroupDevShare{member_of(ctx, k), (const uint8_t*)d_blobs[k], (const uint8_t*)d_commitments48[k], (const uint8_t*)d_proofs48[k], total, n_local[k],
+                                   hip_streams ? (hipStream_t)hip_streams[k] : nullptr});
+    total += n_local[k];
+  }
+  return verify_group_dev(ctx, shares, total, ok);
+}

@@ -55,7 +55,7 @@ static int32_t proof_dev_locked(const kzg_ctx* ctx, const uint8_t* d_blobs, cons
   const ProofLayout L = proof_layout(ctx, n);
   const uint64_t cn = L.cn, nchunks = (n + cn - 1) / cn;
   const uint32_t splits = L.splits;
-  int32_t rc = ws_reserve(ctx, L.total);
+  int32_t rc = ws_reserve(ctx, L.total, st);
   if (rc) return rc;
   uint8_t* ws = ws_ptr(ctx);
   const size_t *o_z = L.o_z, *o_y = L.o_y, *o_cs = L.o_cs, *o_q = L.o_q, *o_ir = L.o_ir;
@@ -149,11 +149,12 @@ extern "C" int32_t kzg_compute_blob_proof_batch_dev(const kzg_ctx* ctx, const vo
   HIP_TRY(hipSetDevice(ctx->device));
   std::lock_guard<std::mutex> guard(ctx->lock);
   hipStream_t st = (hipStream_t)hip_stream;
-  int32_t rc = ws_begin(ctx, st);
+  WsCall ws(ctx, st);
+  int32_t rc = ws.begin();
   if (rc == 0)
     rc = proof_dev_locked(ctx, (const uint8_t*)d_blobs, (const uint8_t*)d_commitments48, nullptr, n, (uint8_t*)d_out48, nullptr, nullptr,
                           (int32_t*)d_status, st);
-  if (rc == 0) rc = ws_end(ctx, st);
+  if (rc == 0) rc = ws.end();
   return rc;
 }
 
@@ -211,6 +212,7 @@ int32_t proof_host(const kzg_ctx* ctx, const uint8_t* blobs, const uint8_t* side
   const bool one_pass = plan.size() == 1;  // nothing to overlap: the copy rides on the compute stream, no event between hardware queues
   hipStream_t copy_st = one_pass ? st : ctx->stage_copy_stream;
   std::lock_guard<std::mutex> guard(ctx->lock);
+  WsCall ws(ctx, st);
   do {
     if (hipMemcpyAsync(d_side, side, n * side_bytes, hipMemcpyHostToDevice, st) != hipSuccess) {
       rc = fail(KZG_FAIL_HIP, "host-to-device copy failed");
@@ -218,8 +220,8 @@ int32_t proof_host(const kzg_ctx* ctx, const uint8_t* blobs, const uint8_t* side
     }
     // one workspace slot for all passes (they follow each other on `st`), sized for the largest pass BEFORE anything is in
     // flight: growing it between passes would free memory under the pipeline
-    rc = ws_begin(ctx, st);
-    if (rc == 0) rc = ws_reserve(ctx, proof_layout(ctx, max_pass).total);
+    rc = ws.begin();
+    if (rc == 0) rc = ws_reserve(ctx, proof_layout(ctx, max_pass).total, st);
     uint64_t base = 0;
     for (size_t k = 0; k < plan.size() && rc == 0; base += plan[k], k++) {
       const int slot = (int)(k & 1);
@@ -241,7 +243,7 @@ int32_t proof_host(const kzg_ctx* ctx, const uint8_t* blobs, const uint8_t* side
       if (rc == 0 && hipEventRecord(ctx->stage_done[slot], st) != hipSuccess) rc = fail(KZG_FAIL_HIP, "event record failed");
     }
     if (rc) break;
-    rc = ws_end(ctx, st);
+    rc = ws.end();
     if (rc) break;
     if ((out48 && hipMemcpyAsync(out48, d_out, n * 48, hipMemcpyDeviceToHost, st) != hipSuccess) ||
         (out_affine96 && hipMemcpyAsync(out_affine96, d_aff, n * 96, hipMemcpyDeviceToHost, st) != hipSuccess) ||

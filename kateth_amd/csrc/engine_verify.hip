@@ -6,6 +6,7 @@
 #include <chrono>
 
 #include "engine_internal.hpp"
+#include "multi_split.hpp"
 
 #include <thread>
 #include "verify_kernels.cuh"
@@ -1257,6 +1258,91 @@ extern "C" int32_t kzg_verify_blob_proof_batch_dev(const kzg_ctx* ctx, const voi
   rc = phase1_items(s, (const uint8_t*)d_blobs, com, prf, 0, n, s->st, true);
   if (rc == 0) rc = verify_fused(s, com, prf, ok);
   kzg_verify_session_destroy(s);
+  return rc;
+}
+
+// Setup::verify_blob_proof_batch (src/kzg/setup.rs:223-275) over device-resident shares of a group context, phases
+// interleaved PER MEMBER as in verify_fused: round 1 enqueues hash, [decoder on the side stream] || evaluation and the
+// transcript on every member and returns the members' roots while the decoders still run; round 2 seeds ONE challenge with all
+// roots and, per member, enqueues the scalars (global powers r^i), the sorting halves of both lincombs beside the decoder, the
+// bucket kernels behind it, reads the statuses and takes the member's two partial sums.  Then the first-error merge in the
+// reference's order (src/kzg/setup.rs:259-271) and one pairing check.  Two fork/joins of pooled host threads per call.
+int32_t verify_group_dev(const kzg_ctx* ctx, const std::vector<GroupDevShare>& shares, uint64_t n_total, int32_t* ok) {
+  *ok = 0;
+  const uint32_t W = (uint32_t)shares.size();
+  if (W == 0) {  // reference quirk Q4: the empty batch verifies
+    *ok = 1;
+    return 0;
+  }
+  if (W == 1)  // one share: exactly the single-device call (one root seeds the challenge)
+    return kzg_verify_blob_proof_batch_dev(shares[0].member, shares[0].blobs, shares[0].commitments48, shares[0].proofs48, shares[0].count, ok, shares[0].st);
+  TraceTimer tt(ctx->knobs.trace, "group verify (device-resident)");
+  std::vector<uint8_t> roots(32 * (size_t)W), partials(192 * (size_t)W);
+  std::vector<int32_t> err6(6 * (size_t)W);
+  for (size_t k = 0; k < err6.size(); k++) err6[k] = (k % 2 == 0) ? -1 : 0;
+  std::vector<kzg_verify_session*> sessions(W, nullptr);
+  auto release = [&]() {
+    const ErrorSnapshot keep = error_snapshot();
+    for (kzg_verify_session* s : sessions)
+      if (s) kzg_verify_session_destroy(s);
+    error_publish(keep);
+  };
+  int32_t rc = run_on_helpers(W, [&](uint32_t j) -> int32_t {
+    const GroupDevShare& sh = shares[j];
+    if (hipSetDevice(sh.member->device) != hipSuccess) return fail(KZG_FAIL_HIP, "hipSetDevice failed");
+    int32_t r = session_acquire(sh.member, sh.count, sh.st, &sessions[j]);
+    if (r) return r;
+    kzg_verify_session* s = sessions[j];
+    r = phase1_items(s, sh.blobs, sh.commitments48, sh.proofs48, 0, sh.count, s->st, true);
+    if (r == 0) r = p1_transcript(s, sh.commitments48, sh.proofs48);
+    if (r == 0) r = p1_root(s, roots.data() + 32 * (size_t)j);
+    if (r) {
+      (void)hipStreamSynchronize(s->st);
+      (void)hipStreamSynchronize(s->side);
+    }
+    return r;
+  });
+  tt.mark("round 1: hash, evaluation, transcript, roots (decoders still running)");
+  if (rc) {
+    for (uint32_t j = 0; j < W; j++)  // drain the members that did enqueue before their sessions go back to the pools
+      if (sessions[j] && hipSetDevice(shares[j].member->device) == hipSuccess) {
+        (void)hipStreamSynchronize(sessions[j]->st);
+        (void)hipStreamSynchronize(sessions[j]->side);
+      }
+    release();
+    return rc;
+  }
+  std::vector<int32_t> codes(W, 0);
+  rc = run_on_helpers(W, [&](uint32_t j) -> int32_t {
+    const GroupDevShare& sh = shares[j];
+    kzg_verify_session* s = sessions[j];
+    if (hipSetDevice(sh.member->device) != hipSuccess) return fail(KZG_FAIL_HIP, "hipSetDevice failed");
+    Phase2 p2;
+    int32_t r = p2_scalars(s, roots.data(), W, sh.first, n_total);
+    if (r == 0) r = p2_sort(s, p2, true);
+    if (r == 0) r = p2_accumulate(s, p2);
+    if (r == 0) r = p1_status(s, err6.data() + 6 * (size_t)j);
+    if (r == 0) codes[j] = first_error_code(err6.data() + 6 * (size_t)j);
+    if (r == 0 && codes[j] == 0) r = p2_finish(s, p2, partials.data() + 192 * (size_t)j);
+    if (r || codes[j]) {  // drain what is enqueued before the session goes back to the pool; a rejected input's sums are discarded
+      (void)hipStreamSynchronize(s->st);
+      (void)hipStreamSynchronize(s->aux);
+      (void)hipStreamSynchronize(s->side);
+      if (p2.ja.owns_buf && p2.ja.buf) (void)hipFree(p2.ja.buf);
+      if (p2.jb.owns_buf && p2.jb.buf) (void)hipFree(p2.jb.buf);
+    }
+    return r;
+  });
+  tt.mark("round 2: scalars, lincombs, statuses, partial sums");
+  release();
+  if (rc) return rc;
+  // first-error-wins over the members' records, global indices (multi_split.hpp)
+  std::vector<kzg::multi::Share> ms(W);
+  for (uint32_t j = 0; j < W; j++) ms[j] = kzg::multi::Share{j, shares[j].first, shares[j].count};
+  const int32_t code = kzg::multi::merged_first_error(ms, err6.data());
+  if (code) return code;
+  rc = kzg_verify_batch_finish(ctx, partials.data(), W, ok);
+  tt.mark("sum of partials + pairing");
   return rc;
 }
 

@@ -230,7 +230,7 @@ class Setup {
   // window_bits = 0 / plane_groups = 0: the engine picks the fastest table class within its default budget (the 96-GiB table)
   // that the device has room for; flags: KZG_CFG_TABLE_MAX lifts the budget, KZG_CFG_BUILD_ASYNC returns on a first-use table
   static Setup load(const uint8_t* g1_lagrange, const uint8_t* g2_monomial, int device = 0, int window_bits = 0, int plane_groups = 0, int flags = 0) {
-    kzg_config cfg{};
+    kzg_config cfg = KZG_CONFIG_INIT;
     cfg.device = device;
     cfg.window_bits = window_bits;
     cfg.flags = flags;
@@ -244,7 +244,7 @@ class Setup {
   // every host-buffer batch over the members (include/kateth_amd.h, kzg_config.devices); single items go to a rotating member.
   static Setup load_multi(const uint8_t* g1_lagrange, const uint8_t* g2_monomial, const std::vector<int32_t>& devices = {}, int window_bits = 0,
                           int plane_groups = 0, int flags = 0) {
-    kzg_config cfg{};
+    kzg_config cfg = KZG_CONFIG_INIT;
     cfg.window_bits = window_bits;
     cfg.flags = flags;
     cfg.plane_groups = plane_groups;

@@ -96,8 +96,13 @@ def _kzg_error(code: int) -> KzgError:
 # ---------------------------------------------------------------------------
 class _Config(ctypes.Structure):
     """kzg_config (include/kateth_amd.h)"""
-    _fields_ = [("device", ctypes.c_int32), ("window_bits", ctypes.c_int32), ("flags", ctypes.c_int32), ("plane_groups", ctypes.c_int32),
+    _fields_ = [("struct_size", ctypes.c_uint32), ("device", ctypes.c_int32), ("window_bits", ctypes.c_int32), ("flags", ctypes.c_int32), ("plane_groups", ctypes.c_int32),
                 ("table_budget_bytes", ctypes.c_uint64), ("devices", ctypes.POINTER(ctypes.c_int32)), ("ndev", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
+
+    @classmethod
+    def new(cls, device=0, window_bits=0, flags=0, plane_groups=0, table_budget_bytes=0, devices=None, ndev=0, reserved=0):
+        """KZG_CONFIG_INIT + fields: struct_size = sizeof(kzg_config), which the library checks"""
+        return cls(ctypes.sizeof(cls), device, window_bits, flags, plane_groups, table_budget_bytes, devices, ndev, reserved)
 
 
 CFG_TABLE_MAX = 0x1    # KZG_CFG_TABLE_MAX: the automatic table choice may take the largest table the device has room for (192 GiB)
@@ -114,6 +119,8 @@ _ALT_LIBS = {}
 
 _u8p = ctypes.c_void_p
 _i32p = ctypes.POINTER(ctypes.c_int32)
+_vpp = ctypes.POINTER(ctypes.c_void_p)
+_u64p = ctypes.POINTER(ctypes.c_uint64)
 
 _SIGNATURES = {
     "kzg_last_error": (ctypes.c_char_p, []),
@@ -149,6 +156,11 @@ _SIGNATURES = {
         ctypes.c_int32,
         [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, _u8p, _i32p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p],
     ),
+    "kzg_blob_to_commitment_batch_group_dev": (ctypes.c_int32, [ctypes.c_void_p, _vpp, _u64p, _vpp, _vpp, _vpp]),
+    "kzg_compute_blob_proof_batch_group_dev": (ctypes.c_int32, [ctypes.c_void_p, _vpp, _vpp, _u64p, _vpp, _vpp, _vpp]),
+    "kzg_verify_blob_proof_batch_group_dev": (ctypes.c_int32, [ctypes.c_void_p, _vpp, _vpp, _vpp, _u64p, _i32p, _vpp]),
+    "kzg_recommended_env": (ctypes.c_char_p, []),
+    "kzg_ctx_workspace_bytes": (ctypes.c_uint64, [ctypes.c_void_p, ctypes.c_uint32]),
     "kzg_verify_phase2_dev": (ctypes.c_int32, [ctypes.c_void_p, _u8p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, _u8p]),
     "kzg_verify_session_destroy": (None, [ctypes.c_void_p]),
     "kzg_verify_session_zy": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, _u8p, _u8p]),
@@ -364,7 +376,7 @@ class Setup:
             raise LoadSetupError("Bls(ECGroup(InvalidEncoding))")
         lib = load_library(lib_path)
         flags = (CFG_TABLE_MAX if table_max else 0) | (CFG_BUILD_ASYNC if build_async else 0)
-        cfg = _Config(device, window_bits, flags, plane_groups, table_budget_bytes, None, 0, 0)
+        cfg = _Config.new(device, window_bits, flags, plane_groups, table_budget_bytes, None, 0, 0)
         keep = None
         if devices is not None:
             if isinstance(devices, str):
@@ -443,6 +455,10 @@ class Setup:
     @property
     def table_bytes(self) -> int:
         return self._lib.kzg_ctx_table_bytes(self._h)
+
+    def workspace_bytes(self):
+        """bytes of the three commitment / proof workspace slots as allocated so far"""
+        return [int(self._lib.kzg_ctx_workspace_bytes(self._h, k)) for k in range(3)]
 
     def _check(self, rc: int, what: str):
         if rc < 0:
@@ -695,6 +711,44 @@ class Setup:
         ok = ctypes.c_int32(0)
         rc = self._lib.kzg_verify_blob_proof_batch_dev(self._h, d_blobs, d_commitments, d_proofs, n, ctypes.byref(ok), stream)
         self._check(rc, "kzg_verify_blob_proof_batch_dev")
+        if rc > 0:
+            raise _kzg_error(rc)
+        return bool(ok.value)
+
+    # -- device-resident SHARDED calls on a group context: one entry per member, member k's buffers resident on member k's GPU ---
+    def _per_member(self, values, what):
+        m = self.members
+        if len(values) != m:
+            raise ValueError("%s: %d entries for a context of %d members" % (what, len(values), m))
+        return (ctypes.c_void_p * m)(*[int(v) if v else None for v in values])
+
+    def _streams(self, streams):
+        return self._per_member(streams, "streams") if streams is not None else None
+
+    def _counts(self, n_local):
+        if len(n_local) != self.members:
+            raise ValueError("n_local: %d entries for a context of %d members" % (len(n_local), self.members))
+        return (ctypes.c_uint64 * len(n_local))(*n_local)
+
+    def blob_to_commitment_batch_group_dev(self, d_blobs, n_local, d_out48, d_status, streams=None):
+        """enqueues on every member and returns without synchronising (like the *_dev calls)"""
+        rc = self._lib.kzg_blob_to_commitment_batch_group_dev(self._h, self._per_member(d_blobs, "d_blobs"), self._counts(n_local), self._per_member(d_out48, "d_out48"),
+                                                              self._per_member(d_status, "d_status"), self._streams(streams))
+        self._check(rc, "kzg_blob_to_commitment_batch_group_dev")
+
+    def compute_blob_proof_batch_group_dev(self, d_blobs, d_commitments, n_local, d_out48, d_status, streams=None):
+        rc = self._lib.kzg_compute_blob_proof_batch_group_dev(self._h, self._per_member(d_blobs, "d_blobs"), self._per_member(d_commitments, "d_commitments"),
+                                                              self._counts(n_local), self._per_member(d_out48, "d_out48"), self._per_member(d_status, "d_status"),
+                                                              self._streams(streams))
+        self._check(rc, "kzg_compute_blob_proof_batch_group_dev")
+
+    def verify_blob_proof_batch_group_dev(self, d_blobs, d_commitments, d_proofs, n_local, streams=None) -> bool:
+        """Setup::verify_blob_proof_batch over the members' resident shares (global order = member order): the boolean, or the
+        reference's first error"""
+        ok = ctypes.c_int32(0)
+        rc = self._lib.kzg_verify_blob_proof_batch_group_dev(self._h, self._per_member(d_blobs, "d_blobs"), self._per_member(d_commitments, "d_commitments"),
+                                                             self._per_member(d_proofs, "d_proofs"), self._counts(n_local), ctypes.byref(ok), self._streams(streams))
+        self._check(rc, "kzg_verify_blob_proof_batch_group_dev")
         if rc > 0:
             raise _kzg_error(rc)
         return bool(ok.value)

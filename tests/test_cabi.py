@@ -56,7 +56,7 @@ def test_header_compiles_as_c_and_links(lib, tmp_path):
     names = declared_functions()
     src = tmp_path / "use_header.c"
     src.write_text('#include "kateth_amd.h"\n#include <stdio.h>\ntypedef void (*fn)(void);\nint main(void) {\n  fn table[] = {%s};\n'
-                   '  kzg_config cfg = {0, 8, 0, 0};\n  printf("%%d %%d\\n", (int)(sizeof table / sizeof table[0]), (int)cfg.window_bits + KZG_BYTES_PER_G1);\n  return table[0] == 0;\n}\n'
+                   '  kzg_config cfg = KZG_CONFIG_INIT;\n  cfg.window_bits = 8;\n  printf("%%d %%d\\n", (int)(sizeof table / sizeof table[0]), (int)cfg.window_bits + KZG_BYTES_PER_G1);\n  return table[0] == 0;\n}\n'
                    % ", ".join("(fn)%s" % n for n in names))
     exe = str(tmp_path / "use_header")
     hip = "/opt/rocm/lib/libamdhip64.so"
@@ -73,7 +73,7 @@ def test_fails_loudly_without_gpu(lib):
         pytest.skip("a GPU is present")
     from kateth_amd import kzg
 
-    cfg = kzg._Config(0, 8, 0, 0)
+    cfg = kzg._Config.new(0, 8, 0, 0)
     out = ctypes.c_void_p()
     rc = lib.kzg_ctx_create(bytes(4096 * 48), bytes(65 * 96), ctypes.byref(cfg), ctypes.byref(out))
     assert rc == -3 and not out.value  # KZG_FAIL_NO_DEVICE
@@ -217,19 +217,26 @@ def test_product_sources_have_one_msm_path():
     assert "k_msm_comb28" in syms and "k_msm_fixed" not in syms and "kzg_test_read_wave_times" not in syms
 
 
-def test_library_load_defaults_the_hardware_queue_count(lib):
-    """the load-time constructor (engine.hip, kzg_default_hw_queues) sets GPU_MAX_HW_QUEUES=16 before HIP can initialise, and
-    leaves an explicit setting alone"""
+def test_library_load_leaves_the_environment_alone(lib):
+    """round 5: no load-time constructor calls setenv any more -- GPU_MAX_HW_QUEUES is the host program's to set;
+    the library only NAMES the setting (kzg_recommended_env) and its undefined-symbol list has no setenv / putenv"""
     import sys
 
     from kateth_amd import kzg
 
     LIB = kzg.library_path()
     # the library binds to the HIP runtime already in the process (no DT_NEEDED): load one first, as a C host program's link line does
-    prog = ("import ctypes, os, sys; ctypes.CDLL('/opt/rocm/lib/libamdhip64.so', mode=ctypes.RTLD_GLOBAL); ctypes.CDLL(sys.argv[1]); "
-            "libc = ctypes.CDLL(None); libc.getenv.restype = ctypes.c_char_p; print((libc.getenv(b'GPU_MAX_HW_QUEUES') or b'').decode())")
+    prog = ("import ctypes, os, sys; ctypes.CDLL('/opt/rocm/lib/libamdhip64.so', mode=ctypes.RTLD_GLOBAL); lib = ctypes.CDLL(sys.argv[1]); "
+            "libc = ctypes.CDLL(None); libc.getenv.restype = ctypes.c_char_p; lib.kzg_recommended_env.restype = ctypes.c_char_p; "
+            "print((libc.getenv(b'GPU_MAX_HW_QUEUES') or b'unset').decode(), lib.kzg_recommended_env().decode())")
     base = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
     got = subprocess.run([sys.executable, "-c", prog, LIB], env=base, capture_output=True, text=True, timeout=120)
-    assert got.returncode == 0 and got.stdout.strip() == "16", (got.stdout, got.stderr[-300:])
+    assert got.returncode == 0 and got.stdout.split() == ["unset", "GPU_MAX_HW_QUEUES=16"], (got.stdout, got.stderr[-300:])
     got = subprocess.run([sys.executable, "-c", prog, LIB], env=dict(base, GPU_MAX_HW_QUEUES="4"), capture_output=True, text=True, timeout=120)
-    assert got.returncode == 0 and got.stdout.strip() == "4", (got.stdout, got.stderr[-300:])
+    assert got.returncode == 0 and got.stdout.split() == ["4", "GPU_MAX_HW_QUEUES=16"], (got.stdout, got.stderr[-300:])
+    undefined = subprocess.check_output(["nm", "-D", "--undefined-only", LIB], text=True)
+    assert " setenv" not in undefined and " putenv" not in undefined
+    # the Python package (which owns ITS process) still defaults the variable before anything initialises HIP
+    got = subprocess.run([sys.executable, "-c", "import os, kateth_amd; print(os.environ.get('GPU_MAX_HW_QUEUES'))"], env=base, capture_output=True, text=True,
+                         timeout=300, cwd=ROOT)
+    assert got.returncode == 0 and got.stdout.strip() == "16", (got.stdout, got.stderr[-300:])

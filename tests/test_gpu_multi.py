@@ -273,11 +273,18 @@ def test_group_creation_errors():
     raw0 = json.load(open(TRUSTED_SETUP))
     g1b = b"".join(bytes.fromhex(x[2:]) for x in raw0["g1_lagrange"])
     g2b = b"".join(bytes.fromhex(x[2:]) for x in raw0["g2_monomial"])
-    for cfg, what in ((kzg._Config(0, 8, 0x40, 0, 0, None, 0, 0), b"flags"), (kzg._Config(0, 8, 0, 0, 0, None, 0, 7), b"reserved"),
-                      (kzg._Config(0, 8, 0, 0, 0, None, 2, 0), b"devices"), (kzg._Config(0, 8, 0, 3, 0, None, 0, 0), b"plane groups")):
+    for cfg, what in ((kzg._Config.new(0, 8, 0x40, 0, 0, None, 0, 0), b"flags"), (kzg._Config.new(0, 8, 0, 0, 0, None, 0, 7), b"reserved"),
+                      (kzg._Config.new(0, 8, 0, 0, 0, None, 2, 0), b"devices"), (kzg._Config.new(0, 8, 0, 3, 0, None, 0, 0), b"plane groups")):
         out = ctypes.c_void_p()
         assert lib.kzg_ctx_create(g1b, g2b, ctypes.byref(cfg), ctypes.byref(out)) == -1 and not out.value  # KZG_FAIL_ARGUMENT
         assert what in lib.kzg_last_error()
+    # a struct of another size (a caller compiled against another revision of the header) is refused before any field is believed
+    for size in (0, 16, 40, 56):
+        cfg = kzg._Config.new(0, 8, 0, 0, 0, None, 0, 0)
+        cfg.struct_size = size
+        out = ctypes.c_void_p()
+        assert lib.kzg_ctx_create(g1b, g2b, ctypes.byref(cfg), ctypes.byref(out)) == -1 and not out.value
+        assert b"struct_size" in lib.kzg_last_error()
     # a rejected setup point is reported like the single-device creation reports it (LoadSetupError::Bls, src/kzg/setup.rs:59-64)
     raw = json.load(open(TRUSTED_SETUP))
     g1 = [bytes.fromhex(s[2:]) for s in raw["g1_lagrange"]]
@@ -310,7 +317,7 @@ int main(int argc, char** argv) {
   const size_t m = 9;
   unsigned char *g1 = slurp(argv[1], 4096 * 48), *g2 = slurp(argv[2], 65 * 96), *blobs = slurp(argv[3], m * KZG_BYTES_PER_BLOB);
   const int32_t devices[2] = {0, 0};
-  kzg_config cfg = {0};
+  kzg_config cfg = KZG_CONFIG_INIT;
   cfg.window_bits = 8;
   kzg_ctx *group = NULL, *one = NULL;
   if (kzg_ctx_create_multi(g1, g2, devices, 2, &cfg, &group) != 0) { printf("create_multi: %s\n", kzg_last_error()); return 1; }
