@@ -5,6 +5,8 @@
 // There is NO CPU compute fallback: without a HIP device every entry point
 // fails with KZG_FAIL_NO_DEVICE / KZG_FAIL_HIP.
 #include "engine_internal.hpp"
+#include "msm_comb.cuh"            // this translation unit owns the fixed-base MSM kernels,
+#include "msm_reduce_kernels.cuh"  // the lane-sum trees / encoder, and their launchers
 #include "setup_kernels.cuh"
 
 #include <algorithm>
@@ -137,7 +139,7 @@ static int32_t ws_grow(WsSlot& w, size_t bytes) {
     if (want == bytes || hipMalloc(&w.p, bytes) != hipSuccess) {
       (void)hipGetLastError();
       w.p = nullptr;
-      return fail(KZG_FAIL_HIP, "workspace allocation of " + std::to_string(bytes >> 20) + " MiB failed");
+      return fail(KZG_FAIL_HIP, "workspace allocation (hipMalloc) of " + std::to_string(bytes >> 20) + " MiB failed: out of device memory");
     }
     want = bytes;
   }
@@ -904,6 +906,71 @@ extern "C" int32_t kzg_ctx_create_multi(const uint8_t* g1_lagrange, const uint8_
 }
 
 // ---------------------------------------------------------------------------
+// fixed-base MSM launchers (declared in engine_internal.hpp; the kernels are compiled in this translation unit only)
+// ---------------------------------------------------------------------------
+// The fixed-base MSM alone over `n` scalar vectors on the device: 64 lane sums per (blob, split) unit into
+// partials[unit * 64 + lane].  `scratch`: msm_scratch_bytes(ctx, n) bytes.  `scalars_consumed` (optional): recorded on `st` as
+// soon as d_scalars is no longer read (after the bit-plane transposition; the MSM kernel reads the masks), so that a staging
+// buffer can be refilled while the MSM runs.
+int32_t msm_launch(const kzg_ctx* ctx, bool be_bytes, const uint8_t* d_scalars, uint64_t n, int32_t* d_status, g1_xyzz* partials, uint32_t splits, uint32_t lpb,
+                   void* scratch, hipStream_t st, hipEvent_t scalars_consumed) {
+  if (ctx->msm_override) {
+    int32_t rco = ctx->msm_override->launch(ctx, be_bytes, d_scalars, n, d_status, partials, splits, lpb, scratch, st);
+    if (rco == 0 && scalars_consumed) HIP_TRY(hipEventRecord(scalars_consumed, st));
+    return rco;
+  }
+  uint64_t* masks = reinterpret_cast<uint64_t*>(scratch);
+  {
+    ProfScope ps(ctx, PROF_TRANSPOSE, st);
+    if (be_bytes)
+      hipLaunchKernelGGL((k_comb_transpose<true>), dim3((unsigned)(n * 8)), dim3(512), 0, st, d_scalars, n, masks, d_status);
+    else
+      hipLaunchKernelGGL((k_comb_transpose<false>), dim3((unsigned)(n * 8)), dim3(512), 0, st, d_scalars, n, masks, d_status);
+  }
+  if (scalars_consumed) HIP_TRY(hipEventRecord(scalars_consumed, st));
+  ProfScope ps(ctx, PROF_MSM_FIXED, st);
+  const bool lat = msm_uses_lat(ctx, splits);
+  const uint4* table = lat ? ctx->d_table_lat : ctx->d_table;
+  const CombGeom geom = lat ? ctx->comb_lat : ctx->comb;
+  hipLaunchKernelGGL(k_msm_comb28<false>, dim3((unsigned)msm_units(n, splits, lpb)), dim3(64), 0, st, masks, n, splits, lpb, table, geom, partials,
+                     (const uint4*)(lat ? ctx->d_comb_k_lat : ctx->d_comb_k), (uint64_t*)nullptr);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+// Lane sums of n blobs -> 48-byte encodings.  Two tree stages: the 64 lane sums of every (blob, split) unit, then the units
+// of a blob -- 6 + log2(splits) levels of latency instead of the splits + 5 a sequential walk over the splits costs (a
+// single blob uses up to 256 units on the latency comb).  `partials` must have room for n * splits unit sums after the n * splits * 64 lane sums.
+int32_t msm_finish(const kzg_ctx* ctx, uint64_t n, uint8_t* d_out48, uint8_t* d_out_affine96, const int32_t* d_status, g1_xyzz* partials,
+                                 g1_xyzz* sums, uint32_t splits, uint32_t lpb, hipStream_t st) {
+  ProfScope ps(ctx, PROF_REDUCE_COMPRESS, st);
+  g1_xyzz* unit_sums = (splits == 1) ? sums : partials + (size_t)n * splits * 64;
+  const uint64_t units = msm_units(n, splits, lpb);
+  if (lpb == 32)  // half-wave mode: four blobs per reducing wave
+    hipLaunchKernelGGL(k_msm_reduce_half4, dim3((unsigned)((units + 1) / 2)), dim3(64), 0, st, partials, units, unit_sums, n);
+  else
+    hipLaunchKernelGGL(k_msm_reduce, dim3((unsigned)units), dim3(64), 0, st, partials, units, lpb, unit_sums, units);
+  if (splits > 64) {  // latency shape (a few blobs over up to 256 units each): tree + constant term + encoding in one launch
+    hipLaunchKernelGGL((k_msm_reduce_splits<true>), dim3((unsigned)n), dim3(64), 0, st, unit_sums, splits, n, sums, d_status, d_out48, d_out_affine96);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
+  if (splits > 1)
+    hipLaunchKernelGGL((k_msm_reduce_splits<false>), dim3((unsigned)n), dim3(64), 0, st, unit_sums, splits, n, sums, (const int32_t*)nullptr,
+                       (uint8_t*)nullptr, (uint8_t*)nullptr);
+  hipLaunchKernelGGL(k_g1_compress, dim3(blocks_for(n, 64)), dim3(64), 0, st, sums, n, d_status, d_out48, d_out_affine96);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+// MSM + reduce + compress
+int32_t msm_pipeline(const kzg_ctx* ctx, bool be_bytes, const uint8_t* d_scalars, uint64_t n, uint8_t* d_out48, uint8_t* d_out_affine96, int32_t* d_status,
+                            g1_xyzz* partials, g1_xyzz* sums, uint32_t splits, void* scratch, hipStream_t st) {
+  const uint32_t lpb = msm_lanes_per_blob(ctx, n, splits);
+  int32_t rc = msm_launch(ctx, be_bytes, d_scalars, n, d_status, partials, splits, lpb, scratch, st);
+  if (rc) return rc;
+  return msm_finish(ctx, n, d_out48, d_out_affine96, d_status, partials, sums, splits, lpb, st);
+}
+
+// ---------------------------------------------------------------------------
 // blob_to_kzg_commitment
 // ---------------------------------------------------------------------------
 static int32_t commit_dev_locked(const kzg_ctx* ctx, const void* d_blobs, uint64_t n, void* d_out48, void* d_out_affine96, int32_t* d_status,
@@ -923,7 +990,7 @@ static int32_t commit_dev_locked(const kzg_ctx* ctx, const void* d_blobs, uint64
   HIP_TRY(hipMemsetAsync(d_status, 0, n * sizeof(int32_t), st));
   for (uint64_t base = 0; base < n; base += cn) {
     const uint64_t m = (n - base < cn) ? (n - base) : cn;
-    rc = msm_pipeline<true>(ctx, reinterpret_cast<const uint8_t*>(d_blobs) + base * (uint64_t)KZG_BYTES_PER_BLOB, m,
+    rc = msm_pipeline(ctx, true, reinterpret_cast<const uint8_t*>(d_blobs) + base * (uint64_t)KZG_BYTES_PER_BLOB, m,
                             d_out48 ? reinterpret_cast<uint8_t*>(d_out48) + base * 48 : nullptr,
                             d_out_affine96 ? reinterpret_cast<uint8_t*>(d_out_affine96) + base * 96 : nullptr, d_status + base, partials, sums,
                             splits, msm_scratch, st);
@@ -1051,7 +1118,7 @@ int32_t commit_host(const kzg_ctx* ctx, const uint8_t* blobs, uint64_t n, uint8_
         rc = fail(KZG_FAIL_HIP, "host-to-device copy failed");
         break;
       }
-      rc = msm_launch<true>(ctx, ctx->stage + (size_t)slot * slot_bytes, m, d_status + base, partials, splits, lpb, wslot + partial_bytes + sums_bytes,
+      rc = msm_launch(ctx, true, ctx->stage + (size_t)slot * slot_bytes, m, d_status + base, partials, splits, lpb, wslot + partial_bytes + sums_bytes,
                             comp[slot], ctx->stage_done[slot]);
       if (rc == 0)
         rc = msm_finish(ctx, m, out48 ? d_res + base * 48 : nullptr, out_affine96 ? d_res + base * 96 : nullptr, d_status + base, partials, sums, splits, lpb,
@@ -1091,9 +1158,7 @@ extern "C" int32_t kzg_synth_blobs_dev(const kzg_ctx* ctx, uint64_t seed, uint64
   if (!ctx || (n && !d_blobs)) return fail(KZG_FAIL_ARGUMENT, "null argument");
   if (n == 0) return 0;
   HIP_TRY(hipSetDevice(ctx->device));
-  const uint64_t elems = n * 4096;
-  hipLaunchKernelGGL(k_synth_blobs, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(hip_stream), seed,
-                     first_index, elems, reinterpret_cast<uint8_t*>(d_blobs));
+  launch_synth_blobs(reinterpret_cast<hipStream_t>(hip_stream), seed, first_index, n, reinterpret_cast<uint8_t*>(d_blobs));
   HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -19,9 +19,16 @@
 #include <vector>
 
 #include "../../include/kateth_amd.h"
-#include "blob_kernels.cuh"
-#include "msm_fixed.cuh"
-#include "msm_comb.cuh"
+// Host-side headers only: field / curve types and single-source math, the comb's geometry, SHA-256, the host pairing.  Every
+// KERNEL header is included by exactly one translation unit, which exports host launchers for what the others need (round 5:
+// the library used to carry each kernel once per engine*.hip that included its header):
+//   engine.hip        setup_kernels.cuh, msm_comb.cuh, msm_fixed.cuh   -> msm_launch / msm_finish / msm_pipeline
+//   engine_blob.hip   blob_kernels.cuh (hash, point decoding, scalars) -> launch_challenge*, launch_g1_decompress*, launch_fr_*
+//   engine_proof.hip  poly_kernels.cuh                                 (its only user)
+//   engine_verify.hip verify_kernels.cuh                               (its only user)
+#include "comb_geom.hpp"
+#include "g1.cuh"
+#include "sha256.cuh"
 #include "pairing.hpp"
 
 using namespace kzg;
@@ -336,50 +343,23 @@ uint32_t choose_splits(const kzg_ctx* ctx, uint64_t n);
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static inline unsigned blocks_for(uint64_t n, unsigned per) { return (unsigned)((n + per - 1) / per); }
 
-// Fiat-Shamir challenges of n blobs: up to one workgroup pair per SIMD the two-wave kernel (shorter critical path per
-// SHA-256 block); beyond that the chip is full and the one-lane-per-blob kernel does less total work.
-static inline void launch_challenge(const kzg_ctx* ctx, hipStream_t st, const uint8_t* blobs, const uint8_t* commitments48, uint64_t n, fr_t* z) {
-  if (n == 0) return;
-  ProfScope ps(ctx, PROF_CHALLENGE, st);
-  uint64_t split_max = (uint64_t)ctx->num_cus * 4 * 64 / 2;  // 2 waves per 64 blobs, one wave per SIMD: 32,768 on 256 CUs
-  if (ctx->knobs.challenge_split_max) split_max = ctx->knobs.challenge_split_max;
-  if ((uint64_t)blocks_for(n, 64) <= (uint64_t)ctx->num_cus && !ctx->knobs.challenge_split_max)  // one workgroup per CU
-  {  // four waves per 64 blobs, a SIMD each; 130 KiB of dynamic LDS (two sets of four block schedules)
-    (void)hipFuncSetAttribute((const void*)k_challenge_pair, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SHA_PAIR_LDS_BYTES);
-    hipLaunchKernelGGL(k_challenge_pair, dim3(blocks_for(n, 64)), dim3(256), SHA_PAIR_LDS_BYTES, st, blobs, commitments48, n, z);
-  }
-  else if (n <= split_max)
-    hipLaunchKernelGGL(k_challenge_split, dim3(blocks_for(n, 64)), dim3(128), 0, st, blobs, commitments48, n, z);
-  else
-    hipLaunchKernelGGL(k_challenge, dim3(blocks_for(n, 64)), dim3(64), 0, st, blobs, commitments48, n, z);
-}
-
-// Small batches: challenges of n blobs and decoding of n_a + n_b points in one launch (k_challenge_and_decode).
+// ---- launchers of engine_blob.hip (hash, point decoding, scalar parsing: blob_kernels.cuh) --------------------------------
+// Fiat-Shamir challenges of n blobs (Blob::challenge, src/blob.rs:78-97) into z (plain limbs)
+void launch_challenge(const kzg_ctx* ctx, hipStream_t st, const uint8_t* blobs, const uint8_t* commitments48, uint64_t n, fr_t* z);
+// Small batches: challenges of n blobs and decoding of n_a + n_b points in one launch
+bool fused_prep_fits(const kzg_ctx* ctx, uint64_t n_blobs, uint64_t n_points);
+void launch_challenge_and_decode(const kzg_ctx* ctx, hipStream_t st, const uint8_t* blobs, const uint8_t* commitments48, uint64_t n, fr_t* z, const uint8_t* in_a,
+                                 uint64_t n_a, int32_t* status_a, const uint8_t* in_b, uint64_t n_b, int32_t* status_b, uint4* affine, uint8_t* inf);
+// P1::decompress (src/bls.rs:505-531) of n_a + n_b points (two input arrays, one output array), all of them or the range [first, first + count)
+void launch_g1_decompress(hipStream_t st, const uint8_t* in_a, uint64_t n_a, int32_t* status_a, const uint8_t* in_b, uint64_t n_b, int32_t* status_b, uint4* affine,
+                          uint8_t* inf);
+void launch_g1_decompress_range(hipStream_t st, uint64_t first, uint64_t count, const uint8_t* in_a, uint64_t n_a, int32_t* status_a, const uint8_t* in_b, uint64_t n_b,
+                                int32_t* status_b, uint4* affine, uint8_t* inf);
+// Fr::from_be_slice (src/bls.rs:130-139) for n caller-supplied 32-byte values; plain limbs -> 32 big-endian bytes
+void launch_fr_parse(hipStream_t st, const uint8_t* in32, uint64_t n, fr_t* out_plain, int32_t* status);
+void launch_fr_store_be(hipStream_t st, const fr_t* plain, uint64_t n, const int32_t* status, uint8_t* out32);
+void launch_synth_blobs(hipStream_t st, uint64_t seed, uint64_t first_index, uint64_t n, uint8_t* d_blobs);
 constexpr uint64_t KZG_FUSED_PREP_MAX = 16384;  // the two-wave kernel's limit: 512 hash waves + 512 decode waves (verify), one wave per SIMD on 256 CUs
-// Hash and decode in one launch only while every workgroup gets a CU of its own (the lane-pair kernel's workgroups take a CU
-// each -- four waves, 130 KiB of LDS; in round 3's three-wave form two on one CU shared SIMDs: 4.5 ms instead of 3.7 ms per hash at 12,288 blobs); beyond that the hash
-// runs alone -- still on lane pairs up to one workgroup per CU = 16,384 blobs -- and the points are decoded beside the evaluation.
-static inline bool fused_prep_fits(const kzg_ctx* ctx, uint64_t n_blobs, uint64_t n_points) {
-  if (ctx->knobs.challenge_split_max) return n_blobs <= KZG_FUSED_PREP_MAX;  // tests force the two-wave / one-lane kernels
-  return (uint64_t)blocks_for(n_blobs, 64) + blocks_for(n_points, 256) <= (uint64_t)ctx->num_cus;
-}
-static inline void launch_challenge_and_decode(const kzg_ctx* ctx, hipStream_t st, const uint8_t* blobs, const uint8_t* commitments48, uint64_t n, fr_t* z,
-                                               const uint8_t* in_a, uint64_t n_a, int32_t* status_a, const uint8_t* in_b, uint64_t n_b,
-                                               int32_t* status_b, uint4* affine, uint8_t* inf) {
-  ProfScope ps(ctx, PROF_CHALLENGE, st);
-  const uint32_t sha_wgs = (uint32_t)blocks_for(n, 64);
-  if ((uint64_t)sha_wgs + blocks_for(n_a + n_b, 256) <= (uint64_t)ctx->num_cus && !ctx->knobs.challenge_split_max) {
-    // every wave still gets a SIMD of its own with four hash waves per 64 blobs: the rounds run on lane pairs
-    const uint32_t dec_wgs = (uint32_t)blocks_for(n_a + n_b, 256);
-    (void)hipFuncSetAttribute((const void*)k_challenge_pair_and_decode, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SHA_PAIR_LDS_BYTES);
-    hipLaunchKernelGGL(k_challenge_pair_and_decode, dim3(sha_wgs + dec_wgs), dim3(256), SHA_PAIR_LDS_BYTES, st, blobs, commitments48, n, z, sha_wgs, in_a,
-                       n_a, status_a, in_b, n_b, status_b, affine, inf);
-    return;
-  }
-  const uint32_t dec_wgs = (uint32_t)blocks_for(n_a + n_b, 128);
-  hipLaunchKernelGGL(k_challenge_and_decode, dim3(sha_wgs + dec_wgs), dim3(128), 0, st, blobs, commitments48, n, z, sha_wgs, in_a, n_a, status_a, in_b,
-                     n_b, status_b, affine, inf);
-}
 
 // The comb's half-wave mode: when two blobs per wave is the cheaper shape (engine.hip, msm_shape: from num_CUs x 16 = 4,096
 // blobs per launch on, when that fills whole rounds), a blob takes 32 lanes (each lane owns twice the blocks for the same
@@ -396,63 +376,18 @@ static inline uint64_t msm_units(uint64_t n, uint32_t splits, uint32_t lpb) { re
 // Scratch the fixed-base MSM needs besides the lane sums: the comb's bit-plane masks (the blob transposed, 128 KiB per blob).
 static inline size_t msm_scratch_bytes(const kzg_ctx* ctx, uint64_t n) { return ctx->use_comb ? (size_t)n * KZG_BYTES_PER_BLOB : 0; }
 
+// ---- launchers of engine.hip (fixed-base MSM: msm_comb.cuh, msm_fixed.cuh) ---------------------------------------------------
 // The fixed-base MSM alone over `n` scalar vectors on the device: 64 lane sums per (blob, split) unit into
-// partials[unit * 64 + lane].  `scratch`: msm_scratch_bytes(ctx, n) bytes.  `scalars_consumed` (optional): recorded on `st` as
+// partials[unit * 64 + lane].  `be_bytes`: the scalars are raw blob bytes (big-endian, canonicity checked into d_status) or
+// plain little-endian limbs.  `scratch`: msm_scratch_bytes(ctx, n) bytes.  `scalars_consumed` (optional): recorded on `st` as
 // soon as d_scalars is no longer read (after the bit-plane transposition; the MSM kernel reads the masks), so that a staging
 // buffer can be refilled while the MSM runs.
-template <bool BE_BYTES>
-static int32_t msm_launch(const kzg_ctx* ctx, const uint8_t* d_scalars, uint64_t n, int32_t* d_status, g1_xyzz* partials, uint32_t splits,
-                          uint32_t lpb, void* scratch, hipStream_t st, hipEvent_t scalars_consumed = nullptr) {
-  if (ctx->msm_override) {
-    int32_t rco = ctx->msm_override->launch(ctx, BE_BYTES, d_scalars, n, d_status, partials, splits, lpb, scratch, st);
-    if (rco == 0 && scalars_consumed) HIP_TRY(hipEventRecord(scalars_consumed, st));
-    return rco;
-  }
-  uint64_t* masks = reinterpret_cast<uint64_t*>(scratch);
-  {
-    ProfScope ps(ctx, PROF_TRANSPOSE, st);
-    hipLaunchKernelGGL((k_comb_transpose<BE_BYTES>), dim3((unsigned)(n * 8)), dim3(512), 0, st, d_scalars, n, masks, d_status);
-  }
-  if (scalars_consumed) HIP_TRY(hipEventRecord(scalars_consumed, st));
-  ProfScope ps(ctx, PROF_MSM_FIXED, st);
-  const bool lat = msm_uses_lat(ctx, splits);
-  const uint4* table = lat ? ctx->d_table_lat : ctx->d_table;
-  const CombGeom geom = lat ? ctx->comb_lat : ctx->comb;
-  hipLaunchKernelGGL(k_msm_comb28<false>, dim3((unsigned)msm_units(n, splits, lpb)), dim3(64), 0, st, masks, n, splits, lpb, table, geom, partials,
-                     (const uint4*)(lat ? ctx->d_comb_k_lat : ctx->d_comb_k), (uint64_t*)nullptr);
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
+int32_t msm_launch(const kzg_ctx* ctx, bool be_bytes, const uint8_t* d_scalars, uint64_t n, int32_t* d_status, g1_xyzz* partials, uint32_t splits, uint32_t lpb,
+                   void* scratch, hipStream_t st, hipEvent_t scalars_consumed = nullptr);
 // Lane sums of n blobs -> 48-byte encodings.  Two tree stages: the 64 lane sums of every (blob, split) unit, then the units
-// of a blob -- 6 + log2(splits) levels of latency instead of the splits + 5 a sequential walk over the splits costs (a
-// single blob uses up to 256 units on the latency comb).  `partials` must have room for n * splits unit sums after the n * splits * 64 lane sums.
-static inline int32_t msm_finish(const kzg_ctx* ctx, uint64_t n, uint8_t* d_out48, uint8_t* d_out_affine96, const int32_t* d_status, g1_xyzz* partials,
-                                 g1_xyzz* sums, uint32_t splits, uint32_t lpb, hipStream_t st) {
-  ProfScope ps(ctx, PROF_REDUCE_COMPRESS, st);
-  g1_xyzz* unit_sums = (splits == 1) ? sums : partials + (size_t)n * splits * 64;
-  const uint64_t units = msm_units(n, splits, lpb);
-  if (lpb == 32)  // half-wave mode: four blobs per reducing wave
-    hipLaunchKernelGGL(k_msm_reduce_half4, dim3((unsigned)((units + 1) / 2)), dim3(64), 0, st, partials, units, unit_sums, n);
-  else
-    hipLaunchKernelGGL(k_msm_reduce, dim3((unsigned)units), dim3(64), 0, st, partials, units, lpb, unit_sums, units);
-  if (splits > 64) {  // latency shape (a few blobs over up to 256 units each): tree + constant term + encoding in one launch
-    hipLaunchKernelGGL((k_msm_reduce_splits<true>), dim3((unsigned)n), dim3(64), 0, st, unit_sums, splits, n, sums, d_status, d_out48, d_out_affine96);
-    HIP_TRY(hipGetLastError());
-    return 0;
-  }
-  if (splits > 1)
-    hipLaunchKernelGGL((k_msm_reduce_splits<false>), dim3((unsigned)n), dim3(64), 0, st, unit_sums, splits, n, sums, (const int32_t*)nullptr,
-                       (uint8_t*)nullptr, (uint8_t*)nullptr);
-  hipLaunchKernelGGL(k_g1_compress, dim3(blocks_for(n, 64)), dim3(64), 0, st, sums, n, d_status, d_out48, d_out_affine96);
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
+// of a blob.  `partials` must have room for n * splits unit sums after the n * splits * 64 lane sums.
+int32_t msm_finish(const kzg_ctx* ctx, uint64_t n, uint8_t* d_out48, uint8_t* d_out_affine96, const int32_t* d_status, g1_xyzz* partials, g1_xyzz* sums,
+                   uint32_t splits, uint32_t lpb, hipStream_t st);
 // MSM + reduce + compress
-template <bool BE_BYTES>
-static int32_t msm_pipeline(const kzg_ctx* ctx, const uint8_t* d_scalars, uint64_t n, uint8_t* d_out48, uint8_t* d_out_affine96, int32_t* d_status,
-                            g1_xyzz* partials, g1_xyzz* sums, uint32_t splits, void* scratch, hipStream_t st) {
-  const uint32_t lpb = msm_lanes_per_blob(ctx, n, splits);
-  int32_t rc = msm_launch<BE_BYTES>(ctx, d_scalars, n, d_status, partials, splits, lpb, scratch, st);
-  if (rc) return rc;
-  return msm_finish(ctx, n, d_out48, d_out_affine96, d_status, partials, sums, splits, lpb, st);
-}
+int32_t msm_pipeline(const kzg_ctx* ctx, bool be_bytes, const uint8_t* d_scalars, uint64_t n, uint8_t* d_out48, uint8_t* d_out_affine96, int32_t* d_status,
+                     g1_xyzz* partials, g1_xyzz* sums, uint32_t splits, void* scratch, hipStream_t st);

@@ -1,5 +1,6 @@
 // compute_blob_kzg_proof / compute_kzg_proof entry points
 #include "engine_internal.hpp"
+#include "poly_kernels.cuh"  // this translation unit owns the quotient / evaluation kernels of the proof path
 
 __global__ __launch_bounds__(256) void k_merge_status(int32_t* __restrict__ primary, const int32_t* __restrict__ secondary, uint64_t n) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -104,14 +105,13 @@ static int32_t proof_dev_locked(const kzg_ctx* ctx, const uint8_t* d_blobs, cons
           (void)hipEventRecord(ev_fork[k], side);
           (void)hipStreamWaitEvent(dec, ev_fork[k], 0);
         }
-        hipLaunchKernelGGL(k_g1_decompress, dim3(blocks_for(m, 64)), dim3(64), 0, dec, com, m, cstat, (const uint8_t*)nullptr, (uint64_t)0,
-                           (int32_t*)nullptr, (uint4*)nullptr, (uint8_t*)nullptr);
+        launch_g1_decompress(dec, com, m, cstat, (const uint8_t*)nullptr, (uint64_t)0, (int32_t*)nullptr, (uint4*)nullptr, (uint8_t*)nullptr);
         if (dec != side) (void)hipEventRecord(ev_join[k], dec);
         launch_challenge(ctx, side, blobs, com, m, z);
         if (dec != side) (void)hipStreamWaitEvent(side, ev_join[k], 0);
       }
     } else {
-      hipLaunchKernelGGL(k_fr_parse, dim3(blocks_for(m, 64)), dim3(64), 0, side, d_z32 + base * 32, m, z, cstat);
+      launch_fr_parse(side, d_z32 + base * 32, m, z, cstat);
     }
     {
       ProfScope ps(ctx, PROF_POLY, side);
@@ -131,10 +131,10 @@ static int32_t proof_dev_locked(const kzg_ctx* ctx, const uint8_t* d_blobs, cons
       fr_t* y = reinterpret_cast<fr_t*>(ws + o_y[sl]);
       fr_t* q = reinterpret_cast<fr_t*>(ws + o_q[sl]);
       (void)hipStreamWaitEvent(st, ev_prep[k], 0);
-      rc = msm_pipeline<false>(ctx, reinterpret_cast<const uint8_t*>(q), m, d_out48 ? d_out48 + base * 48 : nullptr,
+      rc = msm_pipeline(ctx, false, reinterpret_cast<const uint8_t*>(q), m, d_out48 ? d_out48 + base * 48 : nullptr,
                                d_out_affine96 ? d_out_affine96 + base * 96 : nullptr, d_status + base, partials, sums, splits, ws + o_msm, st);
       if (rc) break;
-      if (d_y32) hipLaunchKernelGGL(k_fr_store_be, dim3(blocks_for(m, 256)), dim3(256), 0, st, y, m, d_status + base, d_y32 + base * 32);
+      if (d_y32) launch_fr_store_be(st, y, m, d_status + base, d_y32 + base * 32);
       (void)hipEventRecord(ev_done[k], st);
     }
     if (rc == 0 && hipGetLastError() != hipSuccess) rc = fail(KZG_FAIL_HIP, "proof pipeline launch failed");

@@ -505,16 +505,14 @@ static int32_t phase1_items(kzg_verify_session* s, const uint8_t* blobs, const u
     if (beside) {
       (void)hipStreamWaitEvent(side, s->ev_fork, 0);
       ProfScope ps(ctx, PROF_DECODE, side);
-      hipLaunchKernelGGL(k_g1_decompress_range, dim3(blocks_for(beside, 64)), dim3(64), 0, side, (uint64_t)0, beside, prf, n, s->stat + 2 * n, com, n,
-                         s->stat + n, s->aff, s->inf);
+      launch_g1_decompress_range(side, (uint64_t)0, beside, prf, n, s->stat + 2 * n, com, n, s->stat + n, s->aff, s->inf);
     }
     if (decode_here) {
       if (beside < 2 * n) {
         (void)hipEventRecord(s->ev_fork, st);  // re-recorded: the first wait is already enqueued
         (void)hipStreamWaitEvent(side, s->ev_fork, 0);
         ProfScope ps(ctx, PROF_DECODE, side);
-        hipLaunchKernelGGL(k_g1_decompress_range, dim3(blocks_for(2 * n - beside, 64)), dim3(64), 0, side, beside, 2 * n - beside, prf, n,
-                           s->stat + 2 * n, com, n, s->stat + n, s->aff, s->inf);
+        launch_g1_decompress_range(side, beside, 2 * n - beside, prf, n, s->stat + 2 * n, com, n, s->stat + n, s->aff, s->inf);
       }
       (void)hipEventRecord(s->ev_join, side);
     }
@@ -735,8 +733,7 @@ int32_t verify_phase1_host(const kzg_ctx* ctx, const uint8_t* blobs, const uint8
       (void)hipStreamWaitEvent(s->side, s->ev_fork, 0);
       {
         ProfScope ps(ctx, PROF_DECODE, s->side);
-        hipLaunchKernelGGL(k_g1_decompress, dim3(blocks_for(2 * n, 64)), dim3(64), 0, s->side, prf, n, s->stat + 2 * n, com, n, s->stat + n, s->aff,
-                           s->inf);
+        launch_g1_decompress(s->side, prf, n, s->stat + 2 * n, com, n, s->stat + n, s->aff, s->inf);
       }
       (void)hipEventRecord(s->ev_join, s->side);
       for (int r = 0; r < KZG_STAGE_STREAMS; r++) (void)hipStreamWaitEvent(ctx->stage_streams[r], s->ev_fork, 0);  // session initialised, points resident (all of them: the join below is over all)
@@ -884,7 +881,7 @@ int32_t evaluate_blobs_single(const kzg_ctx* ctx, const uint8_t* blobs, const ui
       rc = fail(KZG_FAIL_HIP, "host-to-device copy failed");
       break;
     }
-    hipLaunchKernelGGL(k_fr_parse, dim3(blocks_for(n, 64)), dim3(64), 0, st, d_z32, n, d_z, d_st);
+    launch_fr_parse(st, d_z32, n, d_z, d_st);
     bool wide_groups = n < 4096;
     if (ctx->knobs.eval_group) wide_groups = ctx->knobs.eval_group != 16;
     for (uint64_t k = 0; k < nchunks && rc == 0; k++) {
@@ -909,7 +906,7 @@ int32_t evaluate_blobs_single(const kzg_ctx* ctx, const uint8_t* blobs, const ui
       (void)hipEventRecord(ctx->stage_done[slot], st);
     }
     if (rc) break;
-    hipLaunchKernelGGL(k_fr_store_be, dim3(blocks_for(n, 256)), dim3(256), 0, st, d_y, n, d_st, d_y32);
+    launch_fr_store_be(st, d_y, n, d_st, d_y32);
     if (hipGetLastError() != hipSuccess || hipMemcpyAsync(out_y32, d_y32, (size_t)n * 32, hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipMemcpyAsync(status, d_st, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
       rc = fail(KZG_FAIL_HIP, "evaluation: launch or read-back failed");
@@ -1406,8 +1403,7 @@ int32_t verify_proof_single(const kzg_ctx* ctx, const uint8_t* proof48, const ui
     memcpy(in, proof48, 48);
     memcpy(in + 48, commitment48, 48);
     if (hipMemcpyAsync(s->pts48, in, 96, hipMemcpyHostToDevice, st) != hipSuccess) { rc = fail(KZG_FAIL_HIP, "copy"); break; }
-    hipLaunchKernelGGL(k_g1_decompress, dim3(1), dim3(64), 0, st, s->pts48, (uint64_t)1, s->stat + 2, s->pts48 + 48, (uint64_t)1, s->stat + 1, s->aff,
-                       s->inf);
+    launch_g1_decompress(st, s->pts48, (uint64_t)1, s->stat + 2, s->pts48 + 48, (uint64_t)1, s->stat + 1, s->aff, s->inf);
     if (hipMemcpyAsync(h_stat, s->stat + 1, 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipMemcpyAsync(h_aff, s->aff, sizeof(h_aff), hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipMemcpyAsync(h_inf, s->inf, sizeof(h_inf), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {

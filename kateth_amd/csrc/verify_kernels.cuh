@@ -1,7 +1,7 @@
 // Kernels of verify_blob_kzg_proof_batch (Setup::verify_blob_proof_batch,
 // src/kzg/setup.rs:223-275 and Setup::verify_proof_batch, :115-161).
 #pragma once
-#include "blob_kernels.cuh"
+#include "blob_device.cuh"
 #include "fr29.cuh"
 #include "msm_fixed.cuh"
 

@@ -240,3 +240,33 @@ def test_library_load_leaves_the_environment_alone(lib):
     got = subprocess.run([sys.executable, "-c", "import os, kateth_amd; print(os.environ.get('GPU_MAX_HW_QUEUES'))"], env=base, capture_output=True, text=True,
                          timeout=300, cwd=ROOT)
     assert got.returncode == 0 and got.stdout.strip() == "16", (got.stdout, got.stderr[-300:])
+
+
+def test_every_kernel_is_compiled_once(lib):
+    """round 5: every kernel header is included by exactly one translation unit, which exports host launchers
+    (engine_internal.hpp) -- so no gfx950 kernel symbol appears in two of the library's objects (rounds 1-4: every kernel of
+    blob_kernels / msm_* once per engine*.hip, an 8.9-MB library; now 4.6 MB)"""
+    import __graft_entry__ as g
+
+    bundler, readelf = "/opt/rocm/lib/llvm/bin/clang-offload-bundler", "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not (os.path.exists(bundler) and os.path.exists(readelf)):
+        pytest.skip("ROCm LLVM tools not present")
+    seen = {}
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as tmp:
+        for unit in g.ENGINE_UNITS:
+            obj = os.path.join(g.CSRC, unit + ".o")
+            assert os.path.exists(obj), "build() leaves the objects in-tree"
+            fb, co = os.path.join(tmp, unit + ".fb"), os.path.join(tmp, unit + ".co")
+            subprocess.check_call(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", obj, fb])
+            if os.path.getsize(fb) == 0:
+                continue  # a unit without device code (engine_multi)
+            subprocess.check_call([bundler, "--unbundle", "--type=o", "--input=" + fb, "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
+            notes = subprocess.check_output([readelf, "--notes", co], text=True)
+            for sym in re.findall(r"\.symbol:\s*'?([\w.$@]+?)\.kd'?\s", notes):
+                seen.setdefault(sym, []).append(unit)
+    assert len(seen) >= 45, sorted(seen)
+    twice = {k: v for k, v in seen.items() if len(v) > 1}
+    assert not twice, twice
+    assert any("k_msm_comb28" in k for k in seen) and any("k_challenge_pair" in k for k in seen) and any("k_eval_frac" in k for k in seen)

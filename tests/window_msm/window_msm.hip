@@ -8,6 +8,8 @@
 // Independent cross-checks of the comb (tests/test_gpu_parity.py, tools/gpu_soak_msm.py).  Nothing here is in the product
 // library, and the product sources carry no conditional compilation for it.
 #include "../../kateth_amd/csrc/engine_internal.hpp"
+// the kernel headers this unit instantiates for itself (static kernels: its own copies, the product objects keep theirs)
+#include "../../kateth_amd/csrc/msm_comb.cuh"
 #include "window_msm.cuh"
 
 namespace {
