@@ -337,6 +337,7 @@ EnvKnobs read_env_knobs() {
   {
     EnvKnobs k;
     k.trace = getenv("KATETH_AMD_TRACE") != nullptr;
+    if (const char* e = getenv("KATETH_AMD_HOST_FP")) host_fp_force_portable() = std::string(e) == "portable";  // measurement aid: the host's Fp products without mulx / adx
     if (const char* e = getenv("KATETH_AMD_PROOF_CHUNK")) k.proof_chunk = (uint64_t)atoll(e) > 0 ? (uint64_t)atoll(e) : 0;
     if (const char* e = getenv("KATETH_AMD_PROOF_OVERLAP")) k.proof_overlap = atoi(e) != 0;
     if (const char* e = getenv("KATETH_AMD_EVAL_GROUP")) k.eval_group = atoi(e);

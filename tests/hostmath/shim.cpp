@@ -476,3 +476,57 @@ extern "C" int32_t hm_single_item_lincomb(uint8_t* out48, const uint8_t* k1_be, 
   g1_compress_xyzz(out48, s);
   return 0;
 }
+
+// ---- the host's mulx / adcx / adox Fp product (kateth_amd/csrc/host_fp_mulx.hpp) against the portable loop ------------------
+// returns -1 when this CPU (or architecture) has no mulx path, else the number of disagreements over `count` chained products
+extern "C" int32_t hm_host_mulx_crosscheck(uint64_t seed, int32_t count) {
+#if defined(KZG_HOST_FP_MULX)
+  if (!hostmulx::cpu_ok()) return -1;
+  fp_t x, y;
+  uint64_t st = seed | 1;
+  auto next = [&]() {
+    st ^= st << 13;
+    st ^= st >> 7;
+    st ^= st << 17;
+    return (uint32_t)(st >> 16);
+  };
+  const fp_t p = modulus<FpParams>();
+  auto fresh = [&](fp_t& v) {
+    for (int i = 0; i < 12; i++) v.v[i] = next();
+    v.v[11] &= 0x0fffffffu;  // < 2^380 < p
+  };
+  fresh(x);
+  fresh(y);
+  int32_t bad = 0;
+  for (int32_t it = 0; it < count; it++) {
+    fp_t fast, slow, lazy_fast, lazy_slow;
+    host_fp_force_portable() = false;
+    mont_mul<FpParams>(fast, x, y);
+    mont_mul_lazy<FpParams>(lazy_fast, x, y);
+    host_fp_force_portable() = true;
+    mont_mul<FpParams>(slow, x, y);
+    mont_mul_lazy<FpParams>(lazy_slow, x, y);
+    host_fp_force_portable() = false;
+    if (!bn_eq(fast, slow) || bn_geq(fast, p)) bad++;
+    // lazy results may differ by p between the two paths; both must be < 2p and congruent
+    fp_t a = lazy_fast, b = lazy_slow;
+    if (bn_geq(a, p)) bn_sub(a, a, p);
+    if (bn_geq(b, p)) bn_sub(b, b, p);
+    if (!bn_eq(a, b) || !bn_eq(a, slow)) bad++;
+    x = y;
+    y = fast;
+    if ((it & 255) == 0) fresh(y);
+    if ((it & 1023) == 1) {  // edge operands: 0, 1, p - 1
+      bn_zero(x);
+    } else if ((it & 1023) == 3) {
+      x = p;
+      x.v[0] -= 1;
+    }
+  }
+  return bad;
+#else
+  (void)seed;
+  (void)count;
+  return -1;
+#endif
+}

@@ -58,6 +58,25 @@ def test_field_ops(hm, fn, mod, nb):
         assert inv == (pow(a, -1, mod) if a else 0)
 
 
+def test_host_mulx_product_matches_portable(hm):
+    """the generated mulx / adcx / adox Montgomery product the host's Fp arithmetic takes on x86-64 CPUs with BMI2 + ADX
+    (kateth_amd/csrc/host_fp_mulx.hpp, tools/gen_host_mulx.py) against the portable unsigned-__int128 loop it replaces: canonical
+    and lazy forms, 60,000 chained products with the edge operands 0 and p - 1 mixed in; and the committed header is what the
+    generator writes"""
+    import subprocess
+    import sys
+
+    bad = hm.hm_host_mulx_crosscheck(ctypes.c_uint64(0x5EED5), 60000)
+    if bad == -1:
+        pytest.skip("this CPU has no BMI2 + ADX (the portable path is the only one)")
+    assert bad == 0
+    root = os.path.dirname(os.path.dirname(HERE))
+    hdr = os.path.join(root, "kateth_amd", "csrc", "host_fp_mulx.hpp")
+    before = open(hdr).read()
+    subprocess.check_call([sys.executable, os.path.join(root, "tools", "gen_host_mulx.py")])
+    assert open(hdr).read() == before, "kateth_amd/csrc/host_fp_mulx.hpp is not what tools/gen_host_mulx.py generates"
+
+
 def test_fp_sqrt(hm):
     rnd = random.Random(5)
     for _ in range(10):
