@@ -385,12 +385,12 @@ KZG_HD void dbl_mod(bn<F::N>& r, const bn<F::N>& a) {
 // Montgomery multiplication, finely integrated product scanning.
 // r = a*b*2^(-32N) mod m ; inputs < m, output < m.
 // ---------------------------------------------------------------------------
-#if !defined(__HIP_DEVICE_COMPILE__)
-// test hook: true sends the host's Fp products through the portable loop even where the mulx path is available
+// test / measurement hook (host only): true sends the host's Fp products through the portable loop even where the mulx path is available
 inline bool& host_fp_force_portable() {
   static bool force = false;
   return force;
 }
+#if !defined(__HIP_DEVICE_COMPILE__)
 // host instantiation: the same value representation (little-endian limbs, radix 2^(32N)) viewed
 // as N/2 64-bit limbs, CIOS with unsigned __int128 -- ~3x faster than the 32-bit path on a CPU;
 // only the once-per-call pairing and the tests run here.
