@@ -645,7 +645,7 @@ KZG_HD void from_mont(bn<F::N>& r, const bn<F::N>& a) {
 // The exponents used here are public constants (p-2, (p+1)/4, r-2), so the
 // data-dependent branch is on public data only.
 template <class F, class EXP>
-KZG_HD_NOINLINE void mont_pow_const(bn<F::N>& r, const bn<F::N>& a, EXP expo) {
+KZG_HD void mont_pow_const_inl(bn<F::N>& r, const bn<F::N>& a, EXP expo) {
   bn<F::N> acc = mont_one<F>();
   bool started = false;
   for (int i = F::N * 32 - 1; i >= 0; i--) {
@@ -659,6 +659,11 @@ KZG_HD_NOINLINE void mont_pow_const(bn<F::N>& r, const bn<F::N>& a, EXP expo) {
     }
   }
   r = acc;
+}
+
+template <class F, class EXP>
+KZG_HD_NOINLINE void mont_pow_const(bn<F::N>& r, const bn<F::N>& a, EXP expo) {
+  mont_pow_const_inl<F, EXP>(r, a, expo);
 }
 
 struct FpInvExp {

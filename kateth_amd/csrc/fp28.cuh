@@ -328,6 +328,10 @@ KZG_HD_NOINLINE void xyzz28_dbl(g1_xyzz28& p) { xyzz28_dbl_inl(p); }
 
 // p += q, both XYZZ accumulators under the invariant; complete   (add-2008-s).  _inl: for the lane-sum trees, whose lone waves
 // would otherwise pass both operands through scratch memory on every level.
+// DBL_INL: the P + P case doubles inline too, so that the accumulator's address is never taken: no scratch at all on the latency
+// chains of the single-item calls (lane-sum trees, encoder).  Kernels whose register budget is tight keep the out-of-line doubling
+// (scratch is then allocated but touched only when two equal points meet).
+template <bool DBL_INL = false>
 KZG_HD void xyzz28_add_complete_inl(g1_xyzz28& p, const g1_xyzz28& q) {
   if (q.inf) return;
   if (p.inf) {
@@ -342,10 +346,14 @@ KZG_HD void xyzz28_add_complete_inl(g1_xyzz28& p, const g1_xyzz28& q) {
   f28_sub_4p(u2, u2, u1);  // P: limbs < 3*2^28, value < 6p
   f28_sub_4p(s2, s2, s1);  // R
   if (f28_is_zero(u2)) {
-    if (f28_is_zero(s2))
-      xyzz28_dbl(p);
-    else
+    if (f28_is_zero(s2)) {
+      if constexpr (DBL_INL)
+        xyzz28_dbl_inl(p);
+      else
+        xyzz28_dbl(p);
+    } else {
       xyzz28_set_inf(p);
+    }
     return;
   }
   f28_sqr(pp, u2);
@@ -368,7 +376,7 @@ KZG_HD void xyzz28_add_complete_inl(g1_xyzz28& p, const g1_xyzz28& q) {
   f28_neg_4p(ns1, s1);
   f28_mul2(p.y, s2, pp, ns1, ppp);  // Y3 = R (Q - X3) - S1 PPP
 }
-KZG_HD_NOINLINE void xyzz28_add_complete(g1_xyzz28& p, const g1_xyzz28& q) { xyzz28_add_complete_inl(p, q); }
+KZG_HD_NOINLINE void xyzz28_add_complete(g1_xyzz28& p, const g1_xyzz28& q) { xyzz28_add_complete_inl<false>(p, q); }
 
 // accumulator -> the 12 x 32-limb XYZZ format of g1.cuh (2^384 Montgomery, canonical)
 KZG_HD void xyzz28_to_xyzz(g1_xyzz& r, const g1_xyzz28& p) {

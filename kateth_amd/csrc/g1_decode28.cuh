@@ -72,12 +72,25 @@ KZG_HD_NOINLINE void f28_inv_fermat(fp28& r, const fp28& a) {
 }
 // 1/a in the 2^392-Montgomery domain (a: N-form; 0 -> 0): safegcd on the canonical residue (modinv30.cuh), then one
 // product by R'^3:  (a R')^-1 R'^3 / R' = a^-1 R'.  ~20 k instead of ~200 k VALU instructions.
+// FERMAT_INL: the fallback power (never taken: 45 batches exceed the proven bound of 37) is inlined as well, so that a kernel
+// whose only out-of-line callee it would be needs no scratch memory (the encoder at the end of every single-item call).
+template <bool FERMAT_INL = false>
 KZG_HD void f28_inv(fp28& r, const fp28& a) {
   fp_t c, ci;
   f28_to_bn(c, a);
   canonicalize<FpParams>(c);
-  if (!modinv30<FpInv30>(ci, c)) {
-    f28_inv_fermat(r, a);
+  bool ok;
+  if constexpr (FERMAT_INL)
+    ok = modinv30_inl<FpInv30>(ci, c);
+  else
+    ok = modinv30<FpInv30>(ci, c);
+  if (!ok) {
+    if constexpr (FERMAT_INL) {
+      const uint8_t sched[2 * KZG_FP_INV_SCHED_LEN] = KZG_FP_INV_SCHED;
+      f28_pow_sched(r, a, sched, KZG_FP_INV_SCHED_LEN, KZG_FP_INV_FIRST_DIGIT_INDEX);
+    } else {
+      f28_inv_fermat(r, a);
+    }
     return;
   }
   fp28 t, k;
@@ -88,37 +101,44 @@ KZG_HD void f28_inv(fp28& r, const fp28& a) {
   f28_mul(r, t, k);
 }
 
-// blst_p1_compress (src/bls.rs:499) of an XYZZ point given in the 12 x 32-bit-limb format (canonical 2^384-Montgomery):
-// same bytes as g1_compress_xyzz (g1.cuh); the inversion and the five products around it run in the radix-2^28 field.
+// blst_p1_compress (src/bls.rs:499) of an XYZZ point given in the 12 x 32-bit-limb format (canonical 2^384-Montgomery), as
+// twelve 32-bit WORDS holding the 48 output bytes in memory order (word q = bytes 4q .. 4q + 3, i.e. the big-endian limbs
+// byte-swapped for a little-endian store): same bytes as g1_compress_xyzz (g1.cuh); the inversion and the five products around it
+// run in the radix-2^28 field.  Everything inline and no byte array: the encoder kernels keep the point, the intermediate values
+// and the output in registers (round 5: out of line and through a 48-byte stack buffer they took 592 B of scratch per lane).
 // `out_affine24` (optional): the same point as blst_p1_affine -- x || y, each 12 x 32-bit little-endian limbs of the
 // canonical 2^384-Montgomery residue (the byte image of blst's 6 x 64-bit limbs); infinity = all zero.
-KZG_HD_NOINLINE void g1_compress_xyzz28(uint8_t* out48, uint32_t* out_affine24, const g1_xyzz& p) {
+template <bool WANT_AFFINE>
+KZG_HD void g1_encode_xyzz28_words(uint32_t* out12, uint32_t* out_affine24, const g1_xyzz& p) {
   if (xyzz_is_inf(p)) {
-    out48[0] = 0xC0;
-    for (int i = 1; i < 48; i++) out48[i] = 0;
-    if (out_affine24)
+    out12[0] = 0xC0u;  // byte 0 = 0xC0, the rest zero
+    KZG_UNROLL_FULL
+    for (int i = 1; i < 12; i++) out12[i] = 0;
+    if (WANT_AFFINE) {
+      KZG_UNROLL_FULL
       for (int i = 0; i < 24; i++) out_affine24[i] = 0;
+    }
     return;
   }
   fp28 k, X, Y, ZZ, ZZZ, t, ti, a;
   KZG_UNROLL_FULL
   for (int i = 0; i < F28_N; i++) k.l[i] = f28_r400_limb(i);
   // v * 2^384 read as an integer, times 2^400 / 2^392  ->  v * 2^392
-  f28_from_bn(X, p.x);
-  f28_mul(X, X, k);
-  f28_from_bn(Y, p.y);
-  f28_mul(Y, Y, k);
   f28_from_bn(ZZ, p.zz);
   f28_mul(ZZ, ZZ, k);
   f28_from_bn(ZZZ, p.zzz);
   f28_mul(ZZZ, ZZZ, k);
   f28_mul(t, ZZ, ZZZ);
-  f28_inv(ti, t);
+  f28_inv<true>(ti, t);
+  f28_from_bn(X, p.x);
+  f28_mul(X, X, k);
   f28_mul(a, ti, ZZZ);  // 1 / ZZ
   f28_mul(X, X, a);
+  f28_from_bn(Y, p.y);
+  f28_mul(Y, Y, k);
   f28_mul(a, ti, ZZ);   // 1 / ZZZ
   f28_mul(Y, Y, a);
-  if (out_affine24) {
+  if (WANT_AFFINE) {
     fp_t xm, ym;
     f28_to_fp(xm, X);
     f28_to_fp(ym, Y);
@@ -138,9 +158,24 @@ KZG_HD_NOINLINE void g1_compress_xyzz28(uint8_t* out48, uint32_t* out_affine24, 
   canonicalize<FpParams>(xp);
   f28_to_bn(yp, Y);
   canonicalize<FpParams>(yp);
-  fp_to_be_bytes_plain(out48, xp);
-  out48[0] |= 0x80;
-  if (fp_is_lex_larger_plain(yp)) out48[0] |= 0x20;
+  uint32_t top = xp.v[11] | 0x80000000u;                 // compressed flag (bit 7 of byte 0 = bit 31 of the top limb)
+  if (fp_is_lex_larger_plain(yp)) top |= 0x20000000u;    // sign flag
+  out12[0] = __builtin_bswap32(top);
+  KZG_UNROLL_FULL
+  for (int i = 1; i < 12; i++) out12[i] = __builtin_bswap32(xp.v[11 - i]);
+}
+// the same as 48 bytes (host tests, callers that want bytes)
+KZG_HD_NOINLINE void g1_compress_xyzz28(uint8_t* out48, uint32_t* out_affine24, const g1_xyzz& p) {
+  uint32_t w[12], aff[24];
+  g1_encode_xyzz28_words<true>(w, aff, p);
+  for (int q = 0; q < 12; q++) {
+    out48[4 * q] = (uint8_t)w[q];
+    out48[4 * q + 1] = (uint8_t)(w[q] >> 8);
+    out48[4 * q + 2] = (uint8_t)(w[q] >> 16);
+    out48[4 * q + 3] = (uint8_t)(w[q] >> 24);
+  }
+  if (out_affine24)
+    for (int q = 0; q < 24; q++) out_affine24[q] = aff[q];
 }
 
 // ---- Jacobian ladder for the subgroup test ----------------------------------------------------------------------------

@@ -150,7 +150,7 @@ KZG_HD void modinv30_normalize(s30<M::NL>& r, int32_t sign) {
 // r = a^-1 mod m for a canonical plain residue a (0 -> 0).  Returns false if g did not reach 0 within MAX_BATCHES (never
 // observed; the callers then fall back to the Fermat power).
 template <class M>
-KZG_HD_NOINLINE bool modinv30(bn<M::NB>& r, const bn<M::NB>& a) {
+KZG_HD bool modinv30_inl(bn<M::NB>& r, const bn<M::NB>& a) {
   constexpr int NL = M::NL, NB = M::NB;
   constexpr uint32_t M30 = (1u << 30) - 1u;
   s30<NL> f, g, d, e;
@@ -194,6 +194,12 @@ KZG_HD_NOINLINE bool modinv30(bn<M::NB>& r, const bn<M::NB>& a) {
   return nz_last == 0;
 }
 
+// out of line: what every caller but the single-item encoder uses (its operands pass through memory; _inl keeps them in registers)
+template <class M>
+KZG_HD_NOINLINE bool modinv30(bn<M::NB>& r, const bn<M::NB>& a) {
+  return modinv30_inl<M>(r, a);
+}
+
 // Montgomery-domain inverses (radix 2^384 / 2^256): (a R)^-1 * R^3 / R = a^-1 R.  0 -> 0.
 KZG_HD void fp_inv(fp_t& r, const fp_t& a) {
   fp_t t, k;
@@ -205,6 +211,18 @@ KZG_HD void fp_inv(fp_t& r, const fp_t& a) {
   KZG_UNROLL_FULL
   for (int i = 0; i < 12; i++) k.v[i] = r3[i];
   fp_mul(r, t, k);
+}
+// the same with every callee inline (operands never pass through memory): for kernels on the latency chain of single-item calls
+KZG_HD void fr_inv_inl(fr_t& r, const fr_t& a) {
+  fr_t t, k;
+  if (!modinv30_inl<FrInv30>(t, a)) {  // never taken: MAX_BATCHES exceeds the proven bound
+    mont_pow_const_inl<FrParams>(r, a, FrInvExp());
+    return;
+  }
+  constexpr uint32_t r3[8] = KZG_FR_R3;
+  KZG_UNROLL_FULL
+  for (int i = 0; i < 8; i++) k.v[i] = r3[i];
+  fr_mul(r, t, k);
 }
 KZG_HD void fr_inv(fr_t& r, const fr_t& a) {
   fr_t t, k;

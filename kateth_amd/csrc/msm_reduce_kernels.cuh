@@ -28,7 +28,7 @@ static __global__ __launch_bounds__(64) void k_msm_reduce(const g1_xyzz* __restr
     __syncthreads();
     if ((lane & m) == 0) {
       const g1_xyzz28 other = lds[(lane + step) >> 1];
-      xyzz28_add_complete_inl(acc, other);
+      xyzz28_add_complete_inl<true>(acc, other);
     }
     __syncthreads();
   }
@@ -61,7 +61,7 @@ static __global__ __launch_bounds__(64) void k_msm_reduce_half4(const g1_xyzz* _
     g1_xyzz28 other;
     xyzz28_from_xyzz(acc, a);
     xyzz28_from_xyzz(other, b);
-    xyzz28_add_complete_inl(acc, other);
+    xyzz28_add_complete_inl<true>(acc, other);
   }
 #pragma unroll 1
   for (int step = 1; step < 16; step <<= 1) {
@@ -70,7 +70,7 @@ static __global__ __launch_bounds__(64) void k_msm_reduce_half4(const g1_xyzz* _
     __syncthreads();
     if ((lane & m) == 0) {
       const g1_xyzz28 other = lds[(lane + step) >> 1];
-      xyzz28_add_complete_inl(acc, other);
+      xyzz28_add_complete_inl<true>(acc, other);
     }
     __syncthreads();
   }
@@ -85,23 +85,27 @@ static __global__ __launch_bounds__(64) void k_msm_reduce_half4(const g1_xyzz* _
 // blst_p1_affine image (so that a caller that wants the reference's `P1` back -- Commitment = Proof = P1,
 // src/kzg/mod.rs:9-10 -- needs no square root).  An item whose status is non-zero gets zero bytes.  Either output pointer may
 // be null.  (The comb MSM's constant term K is already in the sum: one lane per blob starts from it, msm_comb.cuh.)
-__device__ __noinline__ void g1_finish_item(const g1_xyzz& sum, uint64_t b, const int32_t* __restrict__ status, uint8_t* __restrict__ out48,
-                                            uint8_t* __restrict__ out_affine96) {
-  uint8_t tmp[48];
-  uint32_t aff[24];
+__device__ __forceinline__ void g1_finish_item(const g1_xyzz& sum, uint64_t b, const int32_t* __restrict__ status, uint8_t* __restrict__ out48,
+                                               uint8_t* __restrict__ out_affine96) {
+  uint32_t w[12], aff[24];
   if (status != nullptr && status[b] != 0) {
-    for (int q = 0; q < 48; q++) tmp[q] = 0;
+#pragma unroll
+    for (int q = 0; q < 12; q++) w[q] = 0;
+#pragma unroll
     for (int q = 0; q < 24; q++) aff[q] = 0;
+  } else if (out_affine96) {
+    g1_encode_xyzz28_words<true>(w, aff, sum);  // inversion in the radix-2^28 field (g1_decode28.cuh); all in registers
   } else {
-    g1_compress_xyzz28(tmp, out_affine96 ? aff : nullptr, sum);  // inversion in the radix-2^28 field (g1_decode28.cuh)
+    g1_encode_xyzz28_words<false>(w, aff, sum);
   }
   if (out48) {
     uint32_t* o = reinterpret_cast<uint32_t*>(out48 + b * 48);
-    for (int q = 0; q < 12; q++)
-      o[q] = (uint32_t)tmp[4 * q] | ((uint32_t)tmp[4 * q + 1] << 8) | ((uint32_t)tmp[4 * q + 2] << 16) | ((uint32_t)tmp[4 * q + 3] << 24);
+#pragma unroll
+    for (int q = 0; q < 12; q++) o[q] = w[q];
   }
   if (out_affine96) {
     uint32_t* o = reinterpret_cast<uint32_t*>(out_affine96 + b * 96);
+#pragma unroll
     for (int q = 0; q < 24; q++) o[q] = aff[q];
   }
 }
@@ -133,7 +137,7 @@ static __global__ __launch_bounds__(64) void k_msm_reduce_splits(const g1_xyzz* 
     const g1_xyzz in = unit_sums[b * splits + u];
     g1_xyzz28 other;
     xyzz28_from_xyzz(other, in);
-    xyzz28_add_complete_inl(acc, other);
+    xyzz28_add_complete_inl<true>(acc, other);
   }
 #pragma unroll 1
   for (int step = 1; step < 64 && (uint32_t)step < splits; step <<= 1) {
@@ -142,7 +146,7 @@ static __global__ __launch_bounds__(64) void k_msm_reduce_splits(const g1_xyzz* 
     __syncthreads();
     if ((t & m) == 0) {
       const g1_xyzz28 other = lds[(t + step) >> 1];
-      xyzz28_add_complete_inl(acc, other);
+      xyzz28_add_complete_inl<true>(acc, other);
     }
     __syncthreads();
   }

@@ -46,7 +46,7 @@ static __global__ __launch_bounds__(64) void k_poly_root_inverse(const fr_t* __r
   if (bn_is_zero(zn)) {  // z is a 4096th root of unity: inverse of 4096 / z
     fr_mul(r, z, f);
   } else {
-    fr_inv(r, zn);
+    fr_inv_inl(r, zn);
   }
   inv_root[2 * b] = r;
   fr_mul(f, f, zn);  // (z^4096 - 1) / 4096, Montgomery (zero for an in-domain z: y is the matching element then)

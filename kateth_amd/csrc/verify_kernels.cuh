@@ -767,7 +767,7 @@ static __global__ __launch_bounds__(64) void k_var_fold(const g1_xyzz28* __restr
     __syncthreads();
     if ((lane & m) == 0) {
       const g1_xyzz28 other = lds[(lane + step) >> 1];
-      xyzz28_add_complete_inl(acc, other);  // inlined: the out-of-line adder passes both operands through scratch on every level
+      xyzz28_add_complete_inl<true>(acc, other);  // inlined: the out-of-line adder passes both operands through scratch on every level
     }
     __syncthreads();
   }
@@ -795,8 +795,8 @@ static __global__ __launch_bounds__(64) void k_var_windows(const g1_xyzz28* __re
     const uint32_t idx = lane * per + k;
     if (idx < g.half) {
       g1_xyzz28 b = B[idx];
-      xyzz28_add_complete_inl(run, b);
-      xyzz28_add_complete_inl(tot, run);
+      xyzz28_add_complete_inl<true>(run, b);
+      xyzz28_add_complete_inl<true>(tot, run);
       owned++;
     }
   }
@@ -809,7 +809,7 @@ static __global__ __launch_bounds__(64) void k_var_windows(const g1_xyzz28* __re
     g1_xyzz28 v = buf[cur][lane];
     if (lane + off < 64) {
       g1_xyzz28 o = buf[cur][lane + off];
-      xyzz28_add_complete_inl(v, o);
+      xyzz28_add_complete_inl<true>(v, o);
     }
     buf[cur ^ 1][lane] = v;
     __syncthreads();
@@ -822,7 +822,7 @@ static __global__ __launch_bounds__(64) void k_var_windows(const g1_xyzz28* __re
   else
     xyzz28_set_inf(X);
   // each of the lane's `owned` suffix sums gains X: tot += owned * X  (owned <= per, tiny)
-  for (uint32_t k = 0; k < owned; k++) xyzz28_add_complete_inl(tot, X);
+  for (uint32_t k = 0; k < owned; k++) xyzz28_add_complete_inl<true>(tot, X);
 #pragma unroll 1
   for (int step = 1; step < 64; step <<= 1) {
     const int m = 2 * step - 1;
@@ -831,7 +831,7 @@ static __global__ __launch_bounds__(64) void k_var_windows(const g1_xyzz28* __re
     if ((lane & m) == 0) {
       g1_xyzz28 other = lds[(lane + step) >> 1];
       g1_xyzz28 mine = tot;
-      xyzz28_add_complete_inl(mine, other);
+      xyzz28_add_complete_inl<true>(mine, other);
       tot = mine;
     }
     __syncthreads();
@@ -867,7 +867,7 @@ static __global__ __launch_bounds__(256) void k_var_bitsums(const g1_xyzz28* __r
     const uint32_t d = ((di >> b) << (b + 1u)) | (1u << b) | (di & low_mask);  // the di-th number with bit b set
     if (d > limit) break;  // d grows with i
     const g1_xyzz28 t = B[(uint64_t)(d - 1u) * per + k];
-    xyzz28_add_complete_inl(acc, t);  // inlined: the out-of-line adder passes both operands through scratch on every step
+    xyzz28_add_complete_inl<true>(acc, t);  // inlined: the out-of-line adder passes both operands through scratch on every step
   }
 #pragma unroll 1
   for (uint32_t step = 128; step >= 1; step >>= 1) {
@@ -875,7 +875,7 @@ static __global__ __launch_bounds__(256) void k_var_bitsums(const g1_xyzz28* __r
     __syncthreads();
     if (threadIdx.x < step) {
       const g1_xyzz28 other = lds[threadIdx.x];
-      xyzz28_add_complete_inl(acc, other);
+      xyzz28_add_complete_inl<true>(acc, other);
     }
     __syncthreads();
   }
