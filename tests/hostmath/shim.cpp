@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #define KZG_FP28_CHECK 1
 #include "../../kateth_amd/csrc/fp28.cuh"
+#include "../../kateth_amd/csrc/fp30.cuh"
 #include "../../kateth_amd/csrc/fr29.cuh"
 #include "../../kateth_amd/csrc/g1_decode28.cuh"
 #include "../../kateth_amd/csrc/modinv30.cuh"
@@ -529,4 +530,85 @@ extern "C" int32_t hm_host_mulx_crosscheck(uint64_t seed, int32_t count) {
   (void)count;
   return -1;
 #endif
+}
+
+// ---- signed radix-2^30 Fp of the fixed-base MSM hot loop (kateth_amd/csrc/fp30.cuh) ------------------------------------------
+// limbs in, limbs out (13 x int32): Python builds C-form, L-form and extreme operands itself and checks value and ranges.
+// op 0: a*b, 1: a^2, 2: a*b + c*d, 3: carry pass, 4: wide carry pass, 5: pack -> unpack, 6: f30_to_fp (12 words out),
+// 7: f30_from_bn (a13 = 12 words in), 8: is_zero(a) -> out[0], 9: fp_to_packed30 -> unpack (a13 = 12 words: canonical x*2^384)
+extern "C" void hm_f30_op(int op, int32_t* out13, const int32_t* a13, const int32_t* b13, const int32_t* c13, const int32_t* d13) {
+  fp30 a, b, c, d, r;
+  for (int i = 0; i < 13; i++) {
+    a.l[i] = a13[i];
+    b.l[i] = b13[i];
+    c.l[i] = c13[i];
+    d.l[i] = d13[i];
+    r.l[i] = 0;
+  }
+  switch (op) {
+    case 0: f30_mul(r, a, b); break;
+    case 1: f30_sqr(r, a); break;
+    case 2: f30_mul2(r, a, b, c, d); break;
+    case 3: r = a; f30_carry(r); break;
+    case 4: r = a; f30_carry<true>(r); break;
+    case 5: {
+      uint32_t w[12];
+      f30_pack(w, a);
+      f30_unpack(r, w);
+      break;
+    }
+    case 6: {
+      fp_t v;
+      f30_to_fp(v, a);
+      for (int i = 0; i < 12; i++) out13[i] = (int32_t)v.v[i];
+      out13[12] = 0;
+      return;
+    }
+    case 7: {
+      fp_t v;
+      for (int i = 0; i < 12; i++) v.v[i] = (uint32_t)a13[i];
+      f30_from_bn(r, v);
+      break;
+    }
+    case 8: r.l[0] = f30_is_zero(a) ? 1 : 0; break;
+    case 9: {
+      fp_t v;
+      for (int i = 0; i < 12; i++) v.v[i] = (uint32_t)a13[i];
+      uint32_t w[12];
+      fp_to_packed30(w, v);
+      f30_unpack(r, w);
+      break;
+    }
+    default: r = a;
+  }
+  for (int i = 0; i < 13; i++) out13[i] = r.l[i];
+}
+// sum of +-points through xyzz30_madd (table-format entries: fp_to_packed30 / f30_load_entry), as k_msm_comb30 adds them;
+// doublings > 0: the sum is doubled that many times through xyzz30_dbl at the end (the Horner step between bit planes)
+static int g_fp30_slow_calls = 0;
+extern "C" int32_t hm_f30_slow_calls() { return g_fp30_slow_calls; }
+extern "C" int32_t hm_g1_sum30(uint8_t* out48, const uint8_t* pts48, const uint8_t* signs, int n, int force_complete, int doublings) {
+  g1_xyzz30 acc;
+  xyzz30_set_inf(acc);
+  for (int i = 0; i < n; i++) {
+    fp_t x, y;
+    bool inf;
+    int32_t st = g1_uncompress(x, y, inf, pts48 + 48 * i);
+    if (st) return st;
+    if (inf) continue;
+    uint32_t wx[12], wy[12];
+    fp_to_packed30(wx, x);
+    fp_to_packed30(wy, y);
+    fp30 x2, y2;
+    f30_load_entry(x2, y2, wx, wy, signs[i] != 0);
+    if (force_complete || acc.inf || !xyzz30_madd_fast(acc, x2, y2)) {
+      g_fp30_slow_calls++;
+      xyzz30_madd_complete(acc, x2, y2);
+    }
+  }
+  for (int k = 0; k < doublings; k++) xyzz30_dbl(acc);
+  g1_xyzz r;
+  xyzz30_to_xyzz(r, acc);
+  g1_compress_xyzz(out48, r);
+  return 0;
 }

@@ -357,6 +357,137 @@ def test_fp28_madd_complete(hm):
     assert hm.hm_f28_violations() == 0
 
 
+# ---- signed radix-2^30 Fp (kateth_amd/csrc/fp30.cuh): the fixed-base MSM's field since round 5 -----------------------------------
+F30_N, F30_H = 13, 1 << 29
+
+
+def _c30(v):
+    """centred digits of an integer: limbs 0..11 in [-2^29, 2^29), the rest in limb 12"""
+    out = []
+    for _ in range(F30_N - 1):
+        l = v & ((1 << 30) - 1)
+        if l >= F30_H:
+            l -= 1 << 30
+        out.append(l)
+        v = (v - l) >> 30
+    out.append(v)
+    return out
+
+
+def _v30(limbs):
+    return sum(int(x) << (30 * i) for i, x in enumerate(limbs))
+
+
+def _f30(hm, op, a, b=None, c=None, d=None):
+    arr = lambda l: (ctypes.c_int32 * 13)(*(l if l is not None else [0] * 13))  # noqa: E731
+    out = (ctypes.c_int32 * 13)()
+    hm.hm_f30_op(op, out, arr(a), arr(b), arr(c), arr(d))
+    return list(out)
+
+
+def test_fp30_field_ops(hm):
+    """13 centred 30-bit limbs, Montgomery radix 2^390, against Python integers -- with every column also formed in 128 bits by
+    the checked build: products of C-forms, of one lazy (L-form) operand, squarings, double products; the extremes of every
+    operand form (all limbs at +-(2^29 + 2), +-(2^30 + 4)); both carry passes; the packed table format; conversions"""
+    rnd = random.Random(30)
+    Rm = 1 << 390
+    before = hm.hm_f28_violations()
+
+    def ok_product(r, want_times_R):
+        v = _v30(r)
+        assert (v * Rm - want_times_R) % P == 0
+        assert abs(v) < 0.54 * P and all(-F30_H <= x < F30_H for x in r[:12]) and abs(r[12]) < 1 << 22
+
+    for _ in range(200):
+        x, y, z, w = (rnd.randrange(-3 * P, 3 * P) for _ in range(4))
+        a, b, c, d = _c30(x), _c30(y), _c30(z), _c30(w)
+        ok_product(_f30(hm, 0, a, b), x * y)
+        ok_product(_f30(hm, 1, a), x * x)
+        ok_product(_f30(hm, 2, a, b, c, d), x * y + z * w)
+        lazy = [p_ - q_ for p_, q_ in zip(a, c)]  # L-form: an unreduced difference
+        ok_product(_f30(hm, 0, lazy, b), (x - z) * y)
+        ok_product(_f30(hm, 0, b, lazy), (x - z) * y)
+    for sa in (1, -1):
+        for sb in (1, -1):
+            a = [sa * (F30_H + 2)] * 12 + [sa * (1 << 21)]
+            b = [sb * (F30_H + 2)] * 12 + [sb * (1 << 21)]
+            lazy = [sa * (2 * F30_H + 4)] * 12 + [sa * (1 << 22)]
+            ok_product(_f30(hm, 0, a, b), _v30(a) * _v30(b))
+            ok_product(_f30(hm, 1, a), _v30(a) ** 2)
+            ok_product(_f30(hm, 0, lazy, b), _v30(lazy) * _v30(b))
+            ok_product(_f30(hm, 2, a, b, b, a), 2 * _v30(a) * _v30(b))
+            ok_product(_f30(hm, 2, a, b, [-t for t in b], a), 0)
+    # carry passes: value preserved, limbs back in range
+    for _ in range(100):
+        l = [rnd.randrange(-(1 << 31) + (1 << 29) + 1, (1 << 31) - (1 << 29)) for _ in range(12)] + [rnd.randrange(-(1 << 24), 1 << 24)]
+        r = _f30(hm, 3, l)
+        assert _v30(r) == _v30(l) and all(abs(t) <= F30_H + 2 for t in r[:12])
+        wide = [rnd.choice([(1 << 31) - 1, -(1 << 31) + 3, rnd.randrange(-(1 << 31) + 3, 1 << 31)]) for _ in range(12)] + [rnd.randrange(-(1 << 24), 1 << 24)]
+        r = _f30(hm, 4, wide)
+        assert _v30(r) == _v30(wide) and all(abs(t) <= F30_H + 2 for t in r[:12])
+    # packed table format, conversions
+    for v in [0, 1, P - 1, (P - 1) // 2, (P + 1) // 2] + [rnd.randrange(P) for _ in range(60)]:
+        c = _c30(v)
+        assert _f30(hm, 5, c) == c
+        words = [(v >> (32 * i)) & 0xFFFFFFFF for i in range(12)]
+        as_i32 = [w - (1 << 32) if w >= 1 << 31 else w for w in words] + [0]
+        assert _v30(_f30(hm, 7, as_i32)) == v
+        x = v  # read v as x * 2^384 (canonical Montgomery form of field.cuh): the table format holds x * 2^390
+        got = _v30(_f30(hm, 9, as_i32))
+        assert 0 <= got < P and (got - v * (1 << 6)) % P == 0
+        back = _f30(hm, 6, _c30(got))  # x * 2^390 -> canonical x * 2^384
+        assert sum((t & 0xFFFFFFFF) << (32 * i) for i, t in enumerate(back[:12])) == x
+        neg = _f30(hm, 6, _c30(got - 2 * P))  # any representative
+        assert sum((t & 0xFFFFFFFF) << (32 * i) for i, t in enumerate(neg[:12])) == x
+    for k in (-3, -1, 0, 1, 2):
+        assert _f30(hm, 8, _c30(k * P))[0] == 1
+        assert _f30(hm, 8, _c30(k * P + 1))[0] == 0
+    assert hm.hm_f28_violations() == before
+
+
+def test_fp30_madd_complete(hm):
+    """the hot-loop adder in the signed 2^30 representation, fed with packed table entries: long random signed sums, P + P, P - P,
+    leading / trailing cancellation, an accumulator that meets its own affine image, Horner doublings"""
+    rnd = random.Random(31)
+    g = bls.G1_GEN
+    pts = [bls.g1_mul(g, rnd.randrange(1, R)) for _ in range(48)]
+    enc = [bls.g1_compress(p) for p in pts]
+    out = ctypes.create_string_buffer(48)
+    before = hm.hm_f28_violations()
+
+    def run(idx, signs, force=0, dbl=0):
+        assert hm.hm_g1_sum30(out, b"".join(enc[i] for i in idx), bytes(signs), len(idx), force, dbl) == 0
+        want = None
+        for i, s in zip(idx, signs):
+            want = bls.g1_add(want, bls.g1_neg(pts[i]) if s else pts[i])
+        want = bls.g1_mul(want, 1 << dbl) if want is not None else None
+        assert out.raw == bls.g1_compress(want), (idx, signs)
+
+    slow0 = hm.hm_f30_slow_calls()
+    run(list(range(48)), [rnd.randrange(2) for _ in range(48)])
+    assert hm.hm_f30_slow_calls() == slow0 + 1  # only the first add (identity accumulator) left the hot path
+    run(list(range(48)), [rnd.randrange(2) for _ in range(48)], force=1)  # generic case through the complete adder
+    run(list(range(48)), [rnd.randrange(2) for _ in range(48)], dbl=31)   # 31 Horner doublings, as a lane of the G = 8 comb does
+    run([0, 0], [0, 0])
+    run([0, 0], [1, 1])
+    run([0, 0], [0, 1])
+    run([0, 0, 1], [0, 1, 0])
+    run([0, 0, 1], [0, 1, 0], dbl=3)
+    run([1, 2, 3, 3], [0, 0, 0, 0])
+    run([1, 2, 1, 2], [0, 0, 1, 1])
+    ab = bls.g1_add(pts[4], pts[5])
+    assert hm.hm_g1_sum30(out, enc[4] + enc[5] + bls.g1_compress(ab), bytes([0, 0, 0]), 3, 0, 0) == 0
+    assert out.raw == bls.g1_compress(bls.g1_mul(ab, 2))
+    assert hm.hm_g1_sum30(out, enc[4] + enc[5] + bls.g1_compress(ab), bytes([0, 0, 1]), 3, 0, 0) == 0
+    assert out.raw == bls.g1_compress(None)
+    assert hm.hm_g1_sum30(out, enc[4] + enc[5] + bls.g1_compress(ab) + enc[6], bytes([1, 1, 1, 0]), 4, 0, 2) == 0
+    assert out.raw == bls.g1_compress(bls.g1_mul(bls.g1_add(bls.g1_neg(bls.g1_mul(ab, 2)), pts[6]), 4))
+    for _ in range(8):
+        n = rnd.randrange(1, 40)
+        run([rnd.randrange(48) for _ in range(n)], [rnd.randrange(2) for _ in range(n)], dbl=rnd.randrange(4))
+    assert hm.hm_f28_violations() == before
+
+
 def _f29(hm, op, a, b=0, c=0, d=0):
     out = ctypes.create_string_buffer(32)
     hm.hm_f29_op(op, out, *(int(v).to_bytes(32, "little") for v in (a, b, c, d)))
