@@ -261,11 +261,11 @@ def pmc_traffic(workload, n, window_bits):
     return None
 
 
-PMC_KERNEL = {"commit": "k_msm_comb28", "proof": "k_msm_comb28", "verify": "k_challenge"}
+PMC_KERNEL = {"commit": "k_msm_comb30", "proof": "k_msm_comb30", "verify": "k_challenge"}
 # the kernels of ONE call of each workload (exact base names), for the per-call instruction count
 CALL_KERNELS = {
-    "commit": ("k_comb_transpose", "k_msm_comb28", "k_msm_reduce", "k_msm_reduce_half4", "k_msm_reduce_splits", "k_g1_compress"),
-    "proof": ("k_comb_transpose", "k_msm_comb28", "k_msm_reduce", "k_msm_reduce_half4", "k_msm_reduce_splits", "k_g1_compress", "k_challenge", "k_challenge_split",
+    "commit": ("k_comb_transpose", "k_msm_comb30", "k_msm_reduce", "k_msm_reduce_half4", "k_msm_reduce_splits", "k_g1_compress"),
+    "proof": ("k_comb_transpose", "k_msm_comb30", "k_msm_reduce", "k_msm_reduce_half4", "k_msm_reduce_splits", "k_g1_compress", "k_challenge", "k_challenge_split",
               "k_challenge_pair", "k_challenge_and_decode", "k_challenge_pair_and_decode", "k_g1_decompress", "k_poly_root_inverse", "k_poly", "k_merge_status"),
     # batches above 16,384 triples (the child's own setup -- commit + prove of the triples in chunks of 16,384 -- launches
     # k_challenge_pair* and k_g1_decompress, which a verification of this size does not)
@@ -332,7 +332,7 @@ def live_pmc(args, workload, n, counters, timeout_s=200):
 def traffic_from_pmc(pmc, workload):
     """roofline.traffic: HBM bytes per launch of the workload's dominant kernel = FETCH_SIZE (KiB) x 1024 x c + WRITE_SIZE (KiB)
     x 1024 with the guide's gfx950 correction c = 2 for wide coalesced streaming reads (k_challenge: every lane streams its blob)
-    and c = 1 for k_msm_comb28, whose reads are 96-byte gathers of table entries (the count matches the known gather bytes at
+    and c = 1 for k_msm_comb30, whose reads are 96-byte gathers of table entries (the count matches the known gather bytes at
     c = 1, profiles/r02/pmc_traffic.json)."""
     if "error" in pmc or "FETCH_SIZE" not in pmc or "WRITE_SIZE" not in pmc:
         return {"error": pmc.get("error", "counters missing")}

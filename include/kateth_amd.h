@@ -363,7 +363,7 @@ int32_t kzg_selftest_field_mul(const kzg_ctx* ctx, uint64_t lanes, uint64_t iter
  * launch of the timed kernel classes (below) is bracketed by HIP events on the
  * stream it is launched on.  end() synchronises those events and returns the
  * summed milliseconds and the number of launches of the fixed-base MSM kernel
- * (k_msm_comb28).  A profiling interval must not overlap calls still being
+ * (k_msm_comb30).  A profiling interval must not overlap calls still being
  * enqueued from other threads (their unfinished event pairs are skipped).
  */
 int32_t kzg_profile_begin(const kzg_ctx* ctx);

@@ -14,7 +14,7 @@ struct CombGeom {
   uint32_t lpg;   // lanes per group = 64 / G
   uint32_t ep64;  // table entries per 64 points (one group): sum over the blocks of 2^(t-1)
   uint32_t epg;   // entries per group = 64 * ep64
-  uint32_t fair;  // s > 0: the two waves of a SIMD trade issue priority every 2^s shader cycles (k_msm_comb28); 0: hardware default (oldest first)
+  uint32_t fair;  // s > 0: the two waves of a SIMD trade issue priority every 2^s shader cycles (k_msm_comb30); 0: hardware default (oldest first)
 };
 
 KZG_HD uint32_t comb_tbits(uint32_t nb, uint32_t r) { return nb == 3u ? (r == 0u ? 22u : 21u) : 64u / nb; }

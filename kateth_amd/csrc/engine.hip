@@ -268,10 +268,10 @@ extern "C" int32_t kzg_profile_begin(const kzg_ctx* ctx) {
   return 0;
 }
 
-static const char* const PROF_NAMES[PROF_KINDS] = {"k_msm_comb28", "k_challenge*", "k_eval_frac", "k_g1_decompress", "k_poly",
+static const char* const PROF_NAMES[PROF_KINDS] = {"k_msm_comb30", "k_challenge*", "k_eval_frac", "k_g1_decompress", "k_poly",
                                                     "k_var_* (two lincombs)", "k_msm_reduce* + k_g1_compress", "k_comb_transpose"};
 
-extern "C" const char* kzg_ctx_msm_kernel_name(const kzg_ctx* ctx) { return (ctx && ctx->msm_override) ? ctx->msm_override->kernel_name : "k_msm_comb28"; }
+extern "C" const char* kzg_ctx_msm_kernel_name(const kzg_ctx* ctx) { return (ctx && ctx->msm_override) ? ctx->msm_override->kernel_name : "k_msm_comb30"; }
 extern "C" int32_t kzg_ctx_plane_groups(const kzg_ctx* ctx) {
   if (!ctx || !ctx->use_comb) return 0;
   std::lock_guard<std::mutex> guard(ctx->lock);
@@ -501,7 +501,7 @@ static int32_t comb_build_table(const kzg_ctx* ctx, const CombGeom& cg, uint4** 
       const uint64_t count = (uint64_t)nq * cg.ep64;
       const uint64_t nthreads = (count + KN - 1) / KN;
       hipLaunchKernelGGL(k_table_normalize<KN>, dim3((unsigned)((nthreads + 63) / 64)), dim3(64), 0, st, d_tmp, count, d_table,
-                         (uint64_t)grp * cg.epg + (uint64_t)q0 * cg.ep64, true, d_inf_seen);
+                         (uint64_t)grp * cg.epg + (uint64_t)q0 * cg.ep64, TABLE_FMT_PACKED30, d_inf_seen);
       HIP_TRY(hipGetLastError());
       if (cancel) HIP_TRY(hipStreamSynchronize(st));  // background build: a pass at a time, so that a cancel is seen within one pass
     }
@@ -558,7 +558,7 @@ static int32_t comb_build_tables(const kzg_ctx* ctx, uint32_t c, uint32_t G, Com
       x.v[q] = h[q];
       y.v[q] = h[12 + q];
     }
-    // One lane per blob STARTS from the constant term (k_msm_comb28).  That lane doubles its accumulator H - 1 times on
+    // One lane per blob STARTS from the constant term (k_msm_comb30).  That lane doubles its accumulator H - 1 times on
     // its way down the planes, so it is given [c0 / 2^(H-1)] S: one point per table geometry (main comb, latency comb).
     auto constant_for = [&](uint32_t H, uint4** d_out) -> int32_t {
       const uint32_t c0p[8] = KZG_FR_COMB_C0_PLAIN;
@@ -580,13 +580,9 @@ static int32_t comb_build_tables(const kzg_ctx* ctx, uint32_t c, uint32_t G, Com
       }
       fp_t kx, ky;
       if (!xyzz_to_affine(kx, ky, acc)) return 0;  // the identity: nothing to start from
-      fp_to_r392(kx, kx);  // the table's format: k_msm_comb28 loads K like an entry
-      fp_to_r392(ky, ky);
-      uint32_t hk[24];
-      for (int q = 0; q < 12; q++) {
-        hk[q] = kx.v[q];
-        hk[12 + q] = ky.v[q];
-      }
+      uint32_t hk[24];  // the table's format (fp30.cuh: packed centred 30-bit digits of x * 2^390): k_msm_comb30 loads K like an entry
+      fp_to_packed30(hk, kx);
+      fp_to_packed30(hk + 12, ky);
       HIP_TRY(hipMalloc(d_out, 96));
       HIP_TRY(hipMemcpyAsync(*d_out, hk, 96, hipMemcpyHostToDevice, st));
       HIP_TRY(hipStreamSynchronize(st));  // hk is a stack buffer
@@ -933,7 +929,7 @@ int32_t msm_launch(const kzg_ctx* ctx, bool be_bytes, const uint8_t* d_scalars, 
   const bool lat = msm_uses_lat(ctx, splits);
   const uint4* table = lat ? ctx->d_table_lat : ctx->d_table;
   const CombGeom geom = lat ? ctx->comb_lat : ctx->comb;
-  hipLaunchKernelGGL(k_msm_comb28<false>, dim3((unsigned)msm_units(n, splits, lpb)), dim3(64), 0, st, masks, n, splits, lpb, table, geom, partials,
+  hipLaunchKernelGGL(k_msm_comb30<false>, dim3((unsigned)msm_units(n, splits, lpb)), dim3(64), 0, st, masks, n, splits, lpb, table, geom, partials,
                      (const uint4*)(lat ? ctx->d_comb_k_lat : ctx->d_comb_k), (uint64_t*)nullptr);
   HIP_TRY(hipGetLastError());
   return 0;

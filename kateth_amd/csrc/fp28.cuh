@@ -164,7 +164,7 @@ KZG_HD void f28_to_fp(fp_t& r, const fp28& a) {
   f28_to_bn(r, t);
   canonicalize<FpParams>(r);
 }
-// canonical x*2^384 -> canonical x*2^392 as 12 x 32 limbs (the table format read by k_msm_comb28)
+// canonical x*2^384 -> canonical x*2^392 as 12 x 32 limbs (the format of the test-only window tables and of the variable-base MSM's decoded points)
 KZG_HD void fp_to_r392(fp_t& r, const fp_t& a) {
   fp_t k;
   constexpr uint32_t t[12] = KZG_FP_R392_PLAIN;

@@ -1,7 +1,7 @@
 // Fair VALU issue between the waves that share a SIMD.
 //
 // gfx950's instruction arbiter serves the OLDEST ready wave first.  For kernels whose waves run the whole launch in one
-// round at two waves per SIMD (k_msm_comb28 at 4,096 blobs, k_g1_decompress at 131,072 points) that starves the younger wave:
+// round at two waves per SIMD (k_msm_comb30 at 4,096 blobs, k_g1_decompress at 131,072 points) that starves the younger wave:
 // measured per wave (tools/gpu_wave_times.py), the older wave of every pair ran at its solo rate and left after 60 % of
 // the launch, and the younger one finished the rest alone at 5.3 instead of 4.1 cycles per instruction (the SIMD's shared rate).
 // issue_fair_tick() makes the waves trade priority every 2^shift shader cycles, keyed on the parity of the wave's slot

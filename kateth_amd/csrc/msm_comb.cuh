@@ -24,11 +24,12 @@
 //
 // Work decomposition: one wave per (blob, split), or per PAIR of blobs from num_CUs x 16 blobs per launch on (half-wave
 // mode: 32 lanes per blob); lane = (plane group, block owner).  The hot loop is the radix-2^28 mixed addition
-// (xyzz28_madd_fast, fp28.cuh) with the next table entry gathered while the current addition runs, the masks
+// (xyzz30_madd_fast, fp30.cuh: signed radix 2^30 since round 5; the table holds packed centred digits) with the next table entry gathered while the current addition runs, the masks
 // of a lane's next four chunks fetched by one 32-byte load, and the two waves of a SIMD trading issue priority
 // (issue_fair.cuh) so that they finish together.
 #pragma once
 #include "comb_geom.hpp"
+#include "fp30.cuh"
 #include "issue_fair.cuh"
 #include "msm_fixed.cuh"
 
@@ -98,7 +99,7 @@ static __global__ __launch_bounds__(512) void k_comb_transpose(const uint8_t* __
   }
 }
 
-// lane-walker of k_msm_comb28: position = (plane h counting down, block counter s, chunk q, block-in-chunk r)
+// lane-walker of k_msm_comb30: position = (plane h counting down, block counter s, chunk q, block-in-chunk r)
 struct CombWalker {
   uint32_t h, s, q, r;
 };
@@ -111,7 +112,7 @@ struct CombWalker {
 // TIMED: instantiated only by the test-only library (tests/window_msm): every unit records {wall start, wall end, cycles,
 // hw id} into wave_times (tools/gpu_wave_times.py); the product instantiates <false> and passes nullptr.
 template <bool TIMED>
-static __global__ __launch_bounds__(64, 2) void k_msm_comb28(const uint64_t* __restrict__ masks, uint64_t n, uint32_t splits, uint32_t lpb,
+static __global__ __launch_bounds__(64, 2) void k_msm_comb30(const uint64_t* __restrict__ masks, uint64_t n, uint32_t splits, uint32_t lpb,
                                                              const uint4* __restrict__ table, CombGeom g, g1_xyzz* __restrict__ partials,
                                                              const uint4* __restrict__ comb_k, uint64_t* __restrict__ wave_times) {
   const int lane = threadIdx.x;
@@ -141,17 +142,17 @@ static __global__ __launch_bounds__(64, 2) void k_msm_comb28(const uint64_t* __r
   const uint32_t total = g.H * bpo;
   const uint32_t nb = g.nb;
 
-  g1_xyzz28 acc;
-  xyzz28_set_inf(acc);
+  g1_xyzz30 acc;
+  xyzz30_set_inf(acc);
   // The recoding's constant term K = [c0] * (sum of the setup points) is the STARTING VALUE of one lane per blob -- lane 0 of
   // the blob's first unit, plane group 0 -- so no later step has to add it.  The lane doubles its accumulator H - 1 times on
   // its way down the planes: comb_k holds [c0 / 2^(H-1)] * sum (affine, table format; null when it is the identity).
   if (comb_k != nullptr && l == 0u && split == 0u) {
     fp_t kx, ky;
     load_affine96(kx, ky, comb_k, 0);
-    f28_from_bn(acc.x, kx);
-    f28_from_bn(acc.y, ky);
-    acc.zz = f28_one();
+    f30_unpack(acc.x, kx.v);
+    f30_unpack(acc.y, ky.v);
+    acc.zz = f30_one();
     acc.zzz = acc.zz;
     acc.inf = 0;
   }
@@ -228,8 +229,8 @@ static __global__ __launch_bounds__(64, 2) void k_msm_comb28(const uint64_t* __r
 #pragma unroll 1
   for (uint32_t t = 0; t < total; t++) {
     if (g.fair) issue_fair_tick_low(g.fair);
-    fp28 cx, cy;
-    f28_load_entry(cx, cy, nx, ny, nneg);
+    fp30 cx, cy;
+    f30_load_entry(cx, cy, nx.v, ny.v, nneg);
     const bool cneg = nneg, cdbl = ndbl;
     const uint32_t cidx = nidx;
     if (t + 1u < total) {
@@ -241,24 +242,24 @@ static __global__ __launch_bounds__(64, 2) void k_msm_comb28(const uint64_t* __r
       }
     }
     if (cdbl && !acc.inf) {  // Horner step between two planes: out of line, on a copy (63 times per lane at G = 4)
-      g1_xyzz28 tmp = acc;
-      xyzz28_dbl(tmp);
+      g1_xyzz30 tmp = acc;
+      xyzz30_dbl(tmp);
       acc = tmp;
     }
     bool done = false;
-    if (!acc.inf) done = xyzz28_madd_fast(acc, cx, cy);
+    if (!acc.inf) done = xyzz30_madd_fast(acc, cx, cy);
     if (!done) {
-      g1_xyzz28 tmp = acc;
+      g1_xyzz30 tmp = acc;
       fp_t rx, ry;
       load_affine96(rx, ry, tgrp, cidx);
-      fp28 sx, sy;  // separate objects: the call takes their address
-      f28_load_entry(sx, sy, rx, ry, cneg);
-      xyzz28_madd_complete(tmp, sx, sy);
+      fp30 sx, sy;  // separate objects: the call takes their address
+      f30_load_entry(sx, sy, rx.v, ry.v, cneg);
+      xyzz30_madd_complete(tmp, sx, sy);
       acc = tmp;
     }
   }
   g1_xyzz out;
-  xyzz28_to_xyzz(out, acc);  // back to canonical 2^384-Montgomery limbs for k_msm_reduce
+  xyzz30_to_xyzz(out, acc);  // back to canonical 2^384-Montgomery limbs for k_msm_reduce
   partials[unit * 64 + lane] = out;
   if (TIMED) {
     if (wave_times && lane == 0) {

@@ -1,6 +1,7 @@
 // Context-creation kernels: what Setup::load_json does after parsing
 // (src/kzg/setup.rs:52-81) plus the batch normaliser of the fixed-base table build (msm_comb.cuh).
 #pragma once
+#include "fp30.cuh"
 #include "fr29.cuh"
 #include "msm_fixed.cuh"
 
@@ -24,13 +25,14 @@ static __global__ __launch_bounds__(64) void k_setup_g1(const uint8_t* __restric
 }
 
 // thread: normalises KN consecutive XYZZ entries with one shared inversion (Montgomery's trick on zz*zzz) and writes affine
-// table entries; r392 selects the Montgomery radix of the stored coordinates (2^392 for the radix-2^28 MSM kernel, 2^384
-// otherwise).  An entry at infinity (a vanishing subset sum: impossible for the ceremony, possible for a degenerate setup
+// table entries; fmt selects the stored form of the coordinates (TABLE_FMT_*: packed centred 30-bit digits of x * 2^390 for the
+// comb kernel, x * 2^392 for the radix-2^28 test kernels, x * 2^384 otherwise).  An entry at infinity (a vanishing subset sum: impossible for the ceremony, possible for a degenerate setup
 // such as repeated points) has no affine form: it is kept out of the shared inversion, stored as zeros and reported through
 // *inf_seen, and the caller rejects the setup (P1::lincomb, src/bls.rs:406-437, would accept it -- DESIGN.md section 2).
+constexpr int TABLE_FMT_R384 = 0, TABLE_FMT_R392 = 1, TABLE_FMT_PACKED30 = 2;
 template <int KN>
 static __global__ __launch_bounds__(64) void k_table_normalize(const g1_xyzz* __restrict__ tmp, uint64_t count, uint4* __restrict__ table, uint64_t table_off,
-                                                              bool r392, uint32_t* __restrict__ inf_seen) {
+                                                              int fmt, uint32_t* __restrict__ inf_seen) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t first = t * KN;
   if (first >= count) return;
@@ -73,9 +75,15 @@ static __global__ __launch_bounds__(64) void k_table_normalize(const g1_xyzz* __
       fp_mul(x, e.x, a);
       fp_mul(a, wi, e.zz);  // 1/zzz
       fp_mul(y, e.y, a);  // an entry at infinity has x = y = 0 and stays (0, 0)
-      if (r392) {  // table of the radix-2^28 MSM kernels: coordinates times 2^392 instead of 2^384
+      if (fmt == TABLE_FMT_R392) {  // operands of the radix-2^28 adder (test-only window kernels): coordinates times 2^392 instead of 2^384
         fp_to_r392(x, x);
         fp_to_r392(y, y);
+      } else if (fmt == TABLE_FMT_PACKED30) {  // the comb table (fp30.cuh): x * 2^390 as thirteen centred 30-bit digits packed into 48 bytes
+        fp_t px, py;
+        fp_to_packed30(px.v, x);
+        fp_to_packed30(py.v, y);
+        x = px;
+        y = py;
       }
       store_affine96(table, table_off + first + k, x, y);
     }

@@ -214,7 +214,7 @@ def test_product_sources_have_one_msm_path():
             text = open(os.path.join(csrc, name)).read()
             assert "KZG_TEST_WINDOW_MSM" not in text and "k_msm_fixed28" not in text, name
     syms = subprocess.check_output(["strings", kzg.library_path()], text=True)
-    assert "k_msm_comb28" in syms and "k_msm_fixed" not in syms and "kzg_test_read_wave_times" not in syms
+    assert "k_msm_comb30" in syms and "k_msm_fixed" not in syms and "kzg_test_read_wave_times" not in syms
 
 
 def test_library_load_leaves_the_environment_alone(lib):
@@ -269,4 +269,4 @@ def test_every_kernel_is_compiled_once(lib):
     assert len(seen) >= 45, sorted(seen)
     twice = {k: v for k, v in seen.items() if len(v) > 1}
     assert not twice, twice
-    assert any("k_msm_comb28" in k for k in seen) and any("k_challenge_pair" in k for k in seen) and any("k_eval_frac" in k for k in seen)
+    assert any("k_msm_comb30" in k for k in seen) and any("k_challenge_pair" in k for k in seen) and any("k_eval_frac" in k for k in seen)

@@ -64,7 +64,7 @@ def test_native_library_is_loaded(engine):
     assert engine.window_bits == 8 and engine.table_bytes > 0
     # the product library carries ONE fixed-base MSM kernel (the 32-bit-limb one lives in the test-only build)
     syms = subprocess.check_output(["strings", kateth_amd.library_path()], text=True)
-    assert "k_msm_comb28" in syms and "k_msm_fixedILb" not in syms
+    assert "k_msm_comb30" in syms and "k_msm_fixedILb" not in syms
 
 
 def test_commitment_known_answers(engine):
@@ -812,7 +812,7 @@ def test_comb_and_window_table_kernels_agree_at_scale(torch_cuda, monkeypatch, w
             monkeypatch.setenv(k, v)
         s = kateth_amd.Setup.load_json(TRUSTED_SETUP, window_bits=8, lib_path=lib)
         try:
-            assert s.msm_kernel_name == {0: "k_msm_comb28", 1: "k_msm_fixed28", 2: "k_msm_fixed"}[len(outs)]
+            assert s.msm_kernel_name == {0: "k_msm_comb30", 1: "k_msm_fixed28", 2: "k_msm_fixed"}[len(outs)]
             if not outs:
                 s.synth_blobs_dev(0x5CA1E, 0, n, d_blobs.data_ptr())
             d_c = torch.empty(n * 48, dtype=torch.uint8, device="cuda")
@@ -1450,7 +1450,7 @@ def test_bench_rank_launcher_two_real_engine_ranks_on_one_card(workload):
     rec = json.loads(out.stdout.strip().splitlines()[-1])
     assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0
     assert rec["config"]["blobs_per_gpu"] == 96 and rec["config"]["backend"] == "gloo"
-    assert rec["roofline"]["kernel"] == ("k_challenge*" if workload == "verify" else "k_msm_comb28")
+    assert rec["roofline"]["kernel"] == ("k_challenge*" if workload == "verify" else "k_msm_comb30")
     # a rendezvous that disagrees with --gpus must fail loudly instead of silently running one rank
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], capture_output=True, text=True, timeout=120,
                          env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))

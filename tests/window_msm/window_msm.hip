@@ -17,7 +17,7 @@ namespace {
 struct WindowState {
   MsmGeom geom{};
   bool radix28 = true;
-  uint64_t* d_wave_times = nullptr;  // per-unit timestamps of the last k_msm_comb28 launch that fitted
+  uint64_t* d_wave_times = nullptr;  // per-unit timestamps of the last k_msm_comb30 launch that fitted
   uint64_t wave_times_cap = 0;
 };
 WindowState* state_of(const kzg_ctx* ctx) { return reinterpret_cast<WindowState*>(ctx->override_state); }
@@ -109,7 +109,7 @@ int32_t timed_comb_launch(const kzg_ctx* ctx, bool be_bytes, const uint8_t* d_sc
   ProfScope ps(ctx, PROF_MSM_FIXED, st);
   const bool lat = msm_uses_lat(ctx, splits);
   const uint64_t units = msm_units(n, splits, lpb);
-  hipLaunchKernelGGL(k_msm_comb28<true>, dim3((unsigned)units), dim3(64), 0, st, masks, n, splits, lpb, lat ? ctx->d_table_lat : ctx->d_table,
+  hipLaunchKernelGGL(k_msm_comb30<true>, dim3((unsigned)units), dim3(64), 0, st, masks, n, splits, lpb, lat ? ctx->d_table_lat : ctx->d_table,
                      lat ? ctx->comb_lat : ctx->comb, partials, (const uint4*)(lat ? ctx->d_comb_k_lat : ctx->d_comb_k), units <= ws->wave_times_cap ? ws->d_wave_times : (uint64_t*)nullptr);
   HIP_TRY(hipGetLastError());
   return 0;
@@ -125,7 +125,7 @@ void override_destroy(kzg_ctx* ctx) {
 
 const MsmOverride OVR_WINDOW28 = {"k_msm_fixed28", true, 0, window_build, window_launch, override_destroy};
 const MsmOverride OVR_WINDOW32 = {"k_msm_fixed", true, 0, window_build, window_launch, override_destroy};
-const MsmOverride OVR_TIMED_COMB = {"k_msm_comb28", false, 0, nullptr, timed_comb_launch, override_destroy};
+const MsmOverride OVR_TIMED_COMB = {"k_msm_comb30", false, 0, nullptr, timed_comb_launch, override_destroy};
 MsmOverride g_ovr_slots[2];  // adds_per_blob depends on the window: one mutable copy per kind (contexts of one process use one geometry at a time in the tests)
 
 const MsmOverride* choose_override(kzg_ctx* ctx, uint32_t window_bits) {
@@ -164,7 +164,7 @@ struct Registrar {
 }  // namespace
 
 // {wall-clock start, wall-clock end (100 MHz ticks), shader cycles, XCC_ID << 32 | HW_ID} of each unit of the most recent
-// k_msm_comb28 launch that fitted the buffer
+// k_msm_comb30 launch that fitted the buffer
 extern "C" int32_t kzg_test_read_wave_times(const kzg_ctx* ctx, uint64_t* out, uint64_t units) {
   const WindowState* ws = ctx ? state_of(ctx) : nullptr;
   if (!ws || !ws->d_wave_times || units > ws->wave_times_cap) return fail(KZG_FAIL_ARGUMENT, "no wave-time buffer");

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-wave timing of one k_msm_comb28 launch (TEST-ONLY build, tests/window_msm/libkateth_amd_window_msm.so): where does
+"""Per-wave timing of one k_msm_comb30 launch (TEST-ONLY build, tests/window_msm/libkateth_amd_window_msm.so): where does
 the difference between the kernel's duration and its waves' mean duration come from?  Prints, per XCD, the number of waves,
 their mean/min/max duration and the shader clock they saw (cycles per microsecond of the 100 MHz wall clock).
 usage: gpu_wave_times.py [n] [window_bits]"""
