@@ -93,6 +93,39 @@ __global__ __launch_bounds__(64, 2) void k_madd30(uint32_t* out, const fp_t* pts
   out[t] = x;
 }
 
+// the same with PRE-UNPACKED table entries: 13 + 13 int32 digits = 104 bytes per entry instead of 96 (no alignbit / bfe per limb;
+// the negation stays) -- what a wider table entry would buy (second half)
+__global__ __launch_bounds__(64, 2) void k_madd30_unpacked(uint32_t* out, const int32_t* pts, uint32_t npts, uint32_t iters) {
+  g1_xyzz30 acc; xyzz30_set_inf(acc);
+  const uint32_t t = blockIdx.x * 64 + threadIdx.x;
+  auto load = [&](fp30& x2, fp30& y2, uint32_t k, bool neg) {
+    const int32_t* e = pts + 26 * k;
+    const uint32_t m = neg ? 0xffffffffu : 0u, one = neg ? 1u : 0u;
+#pragma unroll
+    for (int i = 0; i < 13; i++) {
+      x2.l[i] = e[i];
+      y2.l[i] = (int32_t)(((uint32_t)e[13 + i] ^ m) + one);
+    }
+  };
+#pragma unroll 1
+  for (uint32_t it = 0; it < iters; it++) {
+    const uint32_t k = (it * 7u + t) % npts;
+    const bool neg = ((it * 0x9e3779b9u + t) >> 13) & 1u;
+    fp30 x2, y2;
+    load(x2, y2, k, neg);
+    if (acc.inf || !xyzz30_madd_fast(acc, x2, y2)) {
+      g1_xyzz30 tmp = acc;
+      fp30 sx, sy;
+      load(sx, sy, k, neg);
+      xyzz30_madd_complete(tmp, sx, sy);
+      acc = tmp;
+    }
+  }
+  g1_xyzz r; xyzz30_to_xyzz(r, acc);
+  uint32_t x = 0; for (int q = 0; q < 12; q++) x ^= r.x.v[q] ^ r.y.v[q] ^ r.zz.v[q];
+  out[t] = x;
+}
+
 template <class F> float timeit(F launch) {
   hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
   launch(); CHECK(hipDeviceSynchronize());
@@ -122,6 +155,14 @@ int main(int argc, char** argv) {
       fp_to_packed30(h30[2 * k].v, ax); fp_to_packed30(h30[2 * k + 1].v, ay);
     }
   }
+  int32_t h30u[26 * npts];
+  for (uint32_t k = 0; k < npts; k++) {
+    fp30 ux, uy;
+    f30_unpack(ux, h30[2 * k].v);
+    f30_unpack(uy, h30[2 * k + 1].v);
+    for (int i = 0; i < 13; i++) { h30u[26 * k + i] = ux.l[i]; h30u[26 * k + 13 + i] = uy.l[i]; }
+  }
+  int32_t* d30u; CHECK(hipMalloc(&d30u, sizeof(h30u))); CHECK(hipMemcpy(d30u, h30u, sizeof(h30u), hipMemcpyHostToDevice));
   fp_t *d28, *d30; CHECK(hipMalloc(&d28, sizeof(h28))); CHECK(hipMalloc(&d30, sizeof(h30)));
   CHECK(hipMemcpy(d28, h28, sizeof(h28), hipMemcpyHostToDevice)); CHECK(hipMemcpy(d30, h30, sizeof(h30), hipMemcpyHostToDevice));
   const double n = (double)waves * 64 * iters;
@@ -139,17 +180,21 @@ int main(int argc, char** argv) {
   uint32_t c28[64]; CHECK(hipMemcpy(c28, out, sizeof(c28), hipMemcpyDeviceToHost));
   r[7] = na / timeit([&] { k_madd30<<<waves, 64>>>(out, d30, npts, ai); }) / 1e6;
   uint32_t c30[64]; CHECK(hipMemcpy(c30, out, sizeof(c30), hipMemcpyDeviceToHost));
-  int same = 1; for (int i = 0; i < 64; i++) same &= c28[i] == c30[i];
+  r[8] = na / timeit([&] { k_madd30_unpacked<<<waves, 64>>>(out, d30u, npts, ai); }) / 1e6;
+  uint32_t c30u[64]; CHECK(hipMemcpy(c30u, out, sizeof(c30u), hipMemcpyDeviceToHost));
+  int same = 1; for (int i = 0; i < 64; i++) same &= c28[i] == c30[i] && c30u[i] == c30[i];
   printf("product        fp28 %7.2f G/s   fp30 %7.2f G/s  (%+.1f %%)\n", r[0], r[1], 100 * (r[1] / r[0] - 1));
   printf("squaring       fp28 %7.2f G/s   fp30 %7.2f G/s  (%+.1f %%)\n", r[2], r[3], 100 * (r[3] / r[2] - 1));
   printf("double product fp28 %7.2f G/s   fp30 %7.2f G/s  (%+.1f %%)\n", r[4], r[5], 100 * (r[5] / r[4] - 1));
   printf("sub + carry pass (fp30 only) %7.2f G/s\n", r[9]);
   printf("mixed addition fp28 %7.3f G/s   fp30 %7.3f G/s  (%+.1f %%)   results %s\n", r[6], r[7], 100 * (r[7] / r[6] - 1), same ? "IDENTICAL" : "DIFFER");
+  printf("mixed addition fp30, pre-unpacked 104-byte entries %7.3f G/s  (%+.1f %% over packed 96-byte entries)\n", r[8], 100 * (r[8] / r[7] - 1));
   FILE* js = fopen(argc > 1 ? argv[1] : "fp30_bench.json", "w");
   fprintf(js, "{\"device\": \"%s\", \"waves\": %u, \"waves_per_simd\": 2, \"g_per_s\": {\"product_fp28\": %.3f, \"product_fp30\": %.3f, \"squaring_fp28\": %.3f, "
           "\"squaring_fp30\": %.3f, \"double_product_fp28\": %.3f, \"double_product_fp30\": %.3f, \"sub_and_carry_fp30\": %.3f, \"mixed_addition_fp28\": %.4f, "
-          "\"mixed_addition_fp30\": %.4f}, \"mixed_addition_gain\": %.4f, \"same_results\": %s}\n",
-          prop.gcnArchName, waves, r[0], r[1], r[2], r[3], r[4], r[5], r[9], r[6], r[7], r[7] / r[6] - 1, same ? "true" : "false");
+          "\"mixed_addition_fp30\": %.4f, \"mixed_addition_fp30_unpacked_104B_entries\": %.4f}, \"mixed_addition_gain\": %.4f, \"unpacked_entry_gain_over_packed\": %.4f, "
+          "\"same_results\": %s}\n",
+          prop.gcnArchName, waves, r[0], r[1], r[2], r[3], r[4], r[5], r[9], r[6], r[7], r[8], r[7] / r[6] - 1, r[8] / r[7] - 1, same ? "true" : "false");
   fclose(js);
   return same ? 0 : 1;
 }
