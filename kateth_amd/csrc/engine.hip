@@ -163,13 +163,14 @@ int32_t ws_reserve(const kzg_ctx* ctx, size_t bytes, hipStream_t st) {
   return rc;
 }
 
-// A call takes the lowest slot whose previous user has completed; when every slot is busy, the slots in turn.  A slot's users on
-// different streams are ordered by its event.
+// A call takes the lowest slot whose previous user has completed or was enqueued on the call's own stream (stream order already
+// puts this call behind it: a second slot would buy nothing and cost its allocation); when every slot is busy with other streams'
+// calls, the slots in turn.  A slot's users on different streams are ordered by its event.
 int32_t ws_begin(const kzg_ctx* ctx, hipStream_t st) {
   uint32_t pick = (uint32_t)KZG_WS_SLOTS;
   for (uint32_t k = 0; k < (uint32_t)KZG_WS_SLOTS && pick == (uint32_t)KZG_WS_SLOTS; k++) {
     const WsSlot& w = ctx->wss[k];
-    if (!w.ev) {
+    if (!w.ev || !w.used || w.last_st == st) {  // never used, or its last user is ahead of this call on the same stream
       pick = k;
     } else {
       const hipError_t q = hipEventQuery(w.ev);
@@ -193,6 +194,8 @@ int32_t ws_end(const kzg_ctx* ctx, hipStream_t st) {
   WsSlot& w = ctx->wss[ctx->ws_cur];
   if (!w.ev) HIP_TRY(hipEventCreateWithFlags(&w.ev, hipEventDisableTiming));
   HIP_TRY(hipEventRecord(w.ev, st));
+  w.last_st = st;
+  w.used = true;
   return 0;
 }
 
@@ -344,6 +347,7 @@ EnvKnobs read_env_knobs() {
     k.verify_serial = getenv("KATETH_AMD_VERIFY_SERIAL") != nullptr;
     k.single_via_batch = getenv("KATETH_AMD_SINGLE_VIA_BATCH") != nullptr;
     if (const char* e = getenv("KATETH_AMD_VAR_MSM")) k.var_msm_classic = std::string(e) == "classic";
+    if (const char* e = getenv("KATETH_AMD_VAR_GLV")) k.var_glv = atoi(e) != 0;
     if (const char* e = getenv("KATETH_AMD_VERIFY_STREAMS")) k.verify_streams = (uint32_t)atoi(e) <= (uint32_t)KZG_STAGE_STREAMS ? (uint32_t)atoi(e) : 0u;
     if (const char* e = getenv("KATETH_AMD_VERIFY_CHUNK")) k.verify_chunk = (uint64_t)atoll(e) > 0 ? (uint64_t)atoll(e) : 0;
     k.comb_full_wave = getenv("KATETH_AMD_COMB_FULL_WAVE") != nullptr;
@@ -642,8 +646,15 @@ static int32_t ctx_build(kzg_ctx* ctx, const uint8_t* g1_lagrange, const uint8_t
       h[q] = gx[q];
       h[12 + q] = gy[q];
     }
-    HIP_TRY(hipMalloc(&ctx->d_gen_affine, 96));
-    HIP_TRY(hipMemcpy(ctx->d_gen_affine, h, 96, hipMemcpyHostToDevice));
+    const uint32_t px[12] = KZG_FP_G1PHIX_R392, py[12] = KZG_FP_G1PHIY_R392;  // [z^2]G = (beta Gx, -Gy): the generator term's second GLV point
+    uint32_t h2[48];
+    for (int q = 0; q < 24; q++) h2[q] = h[q];
+    for (int q = 0; q < 12; q++) {
+      h2[24 + q] = px[q];
+      h2[36 + q] = py[q];
+    }
+    HIP_TRY(hipMalloc(&ctx->d_gen_affine, 192));
+    HIP_TRY(hipMemcpy(ctx->d_gen_affine, h2, 192, hipMemcpyHostToDevice));
   }
   // ---- G1 Lagrange points: decompress, subgroup check, BRP -----------------
   uint8_t* d_in = nullptr;

@@ -118,6 +118,8 @@ struct EnvKnobs {
   int eval_group = 0;            // KATETH_AMD_EVAL_GROUP: 16 | 64 (0 = automatic)
   bool verify_serial = false;    // KATETH_AMD_VERIFY_SERIAL
   bool single_via_batch = false; // KATETH_AMD_SINGLE_VIA_BATCH: a single-item verification takes the batch machinery (the cross-check of the host lincomb)
+  bool var_glv = false;          // KATETH_AMD_VAR_GLV=1: both lincombs of a batch of >= 32,768 items take their scalars GLV-split (built, measured and
+                                 // NOT adopted in round 5: +0.2 ms per 65,536 triples, profiles/r05/verify_glv_rejected.json; kept as an independent cross-check)
   bool var_msm_classic = false;  // KATETH_AMD_VAR_MSM=classic: c = 8 with per-bucket partials for every batch size (cross-check of the flat path)
   uint64_t verify_chunk = 0;     // KATETH_AMD_VERIFY_CHUNK: blobs per host-buffer staging chunk (0 = default)
   uint32_t verify_streams = 0;   // KATETH_AMD_VERIFY_STREAMS: compute streams the host-buffer verification rotates its chunks over (1..4; 0 = default)
@@ -159,6 +161,8 @@ struct WsSlot {
   void* p = nullptr;
   size_t bytes = 0;
   hipEvent_t ev = nullptr;  // recorded after the last enqueued user of the slot; the next user's stream waits on it
+  hipStream_t last_st = nullptr;  // the stream of that user: a call on the SAME stream is ordered behind it anyway and reuses the slot
+  bool used = false;
 };
 // Extension point for the TEST-ONLY library (tests/window_msm/window_msm.hip = the product objects + one more translation
 // unit): an alternative fixed-base MSM -- round 1's window-table kernels as independent cross-checks of the comb, and a
@@ -231,8 +235,9 @@ struct kzg_ctx {
   EnvKnobs knobs;  // read once at kzg_ctx_create
   // workspace (grown on demand, guarded by lock)
   mutable std::mutex lock;
-  // KZG_WS_SLOTS workspaces for commitment / proof calls: a call takes the LOWEST slot whose previous user has completed (a
-  // caller that runs one call at a time lives in slot 0, and only slot 0 is ever allocated), else the slots in turn; its
+  // KZG_WS_SLOTS workspaces for commitment / proof calls: a call takes the LOWEST slot whose previous user has completed or ran
+  // on the call's own stream (a caller that runs one call at a time, or queues its calls on one stream, lives in slot 0, and only
+  // slot 0 is ever allocated), else the slots in turn; its
   // stream waits for the previous user of ITS slot only, so calls enqueued on several streams run side by side (one call's
   // hash and quotient kernels in the shadow of the other's MSM) instead of queueing behind one shared buffer.  Each slot
   // grows by itself, to the largest call it has served.

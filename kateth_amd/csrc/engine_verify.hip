@@ -30,6 +30,9 @@ struct kzg_verify_session {
   fr_t* z = nullptr;       // [n] plain
   fr_t* y = nullptr;       // [n] plain
   fr_t* scal = nullptr;    // [2n+1] plain: r_i*z_i (n), r_i (n), -sum r_i*y_i
+  bool glv = false;        // n >= 32,768: both lincombs on GLV-split scalars (use_glv)
+  fr_t* glv_b = nullptr;   // [2 (2n+1)]: k1 | k2 of scal
+  fr_t* glv_a = nullptr;   // [2n]: k1 | k2 of the r_i
   int32_t* stat = nullptr;   // [3n] blob / commitment / proof status
   uint32_t* leaves = nullptr;  // transcript: n leaves, ceil(n / 16) mid digests, ceil(n / 256) nodes
   uint32_t* mids = nullptr;
@@ -84,10 +87,27 @@ extern "C" void kzg_verify_session_destroy(kzg_verify_session* s) {
 // 65,536 items 17.9 / 18.7) the FLAT path: c = 13, 20 windows, 4,096 buckets
 // per full window = enough buckets for one thread each (no fold), 37 % fewer bucket additions, the top window's <= 232
 // magnitudes handled with 16 threads per bucket, and bit sums instead of running sums (k_var_bitsums).
-static VarGeom choose_var_geom(const kzg_ctx* ctx, uint64_t nterms) {
+// GLV (glv.cuh, round 5; KATETH_AMD_VAR_GLV=1 -- measured and NOT the default): both lincombs take their scalars split at z^2 --
+// twice the terms, 128-bit scalars: c = 13, TEN windows (nine full + bits 117..127: both halves are < z^2 = 0.673 * 2^128, so a
+// raw top digit <= 1,378, + 1 carry, never negated: 1,379 magnitudes with three times a full window's load each -> 3 threads per
+// bucket), i.e. the same bucket additions, 130 bit sums instead of 260 and a Horner loop of 130 steps on the host.  Why it lost
+// (15.04 against 14.83 ms per 65,536 triples, profiles/r05/verify_glv_rejected.json): the bit sums are ONE round of latency-bound
+// workgroups whether there are 260 or 130 of them, and half the windows means half as many bucket THREADS with chains twice as
+// long (A: 40,960 threads x 32 entries instead of 81,920 x 16 on a chip with 131,072 lanes at this register budget): the bucket
+// kernels went from 1.13 / 0.53 ms to 1.43 / 1.26 ms, against 0.1 ms saved in the host's Horner loops.
+static bool use_glv(const kzg_ctx* ctx, uint64_t n_items) { return n_items >= 32768 && !ctx->knobs.var_msm_classic && ctx->knobs.var_glv; }
+static VarGeom choose_var_geom(const kzg_ctx* ctx, uint64_t nterms, bool glv = false) {
   VarGeom g;
   g.top_n = 0;
   g.ktop = 1;
+  if (glv) {
+    g.c = 13u;
+    g.W = 10u;
+    g.half = 1u << 12;
+    g.top_n = 1380u;  // both halves are below z^2 = 0.673 * 2^128: raw top digit <= 1,378, + 1 carry
+    g.ktop = 3u;      // 1,379 used buckets with 4,096 / 1,379 = 2.97 times a full window's load each: three threads per bucket
+    return g;
+  }
   if (nterms >= 32768 && !ctx->knobs.var_msm_classic) {
     g.c = 13u;
     g.W = 20u;  // 19 full windows + bits 247..254: a scalar < r has a raw top digit <= r >> 247 = 231, + 1 carry, never negated
@@ -166,10 +186,10 @@ struct MsmVarLayout {
   uint32_t nb = 0, K = 1;
   size_t o_counts = 0, o_offsets = 0, o_cursors = 0, o_entries = 0, o_part = 0, o_bsum = 0, o_win = 0, total = 0;
 };
-static MsmVarLayout msm_var_layout(const kzg_ctx* ctx, uint64_t nterms) {
+static MsmVarLayout msm_var_layout(const kzg_ctx* ctx, uint64_t nterms, bool glv = false) {
   MsmVarLayout L;
   if (nterms == 0) return L;
-  L.g = choose_var_geom(ctx, nterms);
+  L.g = choose_var_geom(ctx, nterms, glv);
   L.nb = L.g.W * L.g.half;
   size_t off = 0;
   auto take = [&](size_t bytes) {
@@ -217,14 +237,17 @@ struct MsmVarJob {
 //                          filtered here (their flags may not exist yet); they are all-zero entries that the bucket chains skip.
 //                          `lean`: the scan kernel that fits beside two decoder waves (flat path).
 //   msm_var_accumulate  -- bucket sums and bit / window sums: needs the decoded POINTS.
+// `glv`: the scalars are the 128-bit halves of a GLV split (k_glv_split): terms [0, split) on points [0, split), terms [split, nterms)
+// on the [z^2]-images at second_base + (t - split) (k_glv_points).
 static int32_t msm_var_sort(const kzg_ctx* ctx, MsmVarJob& job, const uint8_t* d_inf, const fr_t* d_scalars, uint64_t nterms, hipStream_t st,
-                            uint8_t* prealloc, bool lean) {
+                            uint8_t* prealloc, bool lean, bool glv = false, uint64_t split = 0, uint64_t second_base = 0) {
   job.active = false;
   job.st = st;
   job.nterms = nterms;
   job.trace = ctx->knobs.trace;
   if (nterms == 0) return 0;
-  job.L = msm_var_layout(ctx, nterms);
+  if (!glv) split = nterms;
+  job.L = msm_var_layout(ctx, nterms, glv);
   const MsmVarLayout& L = job.L;
   const VarGeom g = L.g;
   job.g = g;
@@ -247,7 +270,7 @@ static int32_t msm_var_sort(const kzg_ctx* ctx, MsmVarJob& job, const uint8_t* d
   HIP_TRY(hipMemsetAsync(counts, 0, (size_t)(nb + 1) * 4, st));
   hipLaunchKernelGGL(k_var_count, dim3(blocks_for(nterms, 256)), dim3(256), 0, st, d_scalars, d_inf, nterms, g, counts);
   if (g.top_n) {
-    if (nb > 1024u * 80u || g.top_n * g.ktop > g.half) return fail(KZG_FAIL_ARGUMENT, "flat MSM geometry out of range");
+    if (nb > 1024u * 80u || g.top_n * g.ktop > g.half + 64u) return fail(KZG_FAIL_ARGUMENT, "flat MSM geometry out of range");
     if (lean)
       hipLaunchKernelGGL(k_var_scan_lean, dim3(1), dim3(256), 0, st, counts, nb, (nb / 256u + 3u) & ~3u, offsets, cursors);  // nb = 20 * 4096 = 256 * 320
     else
@@ -255,7 +278,7 @@ static int32_t msm_var_sort(const kzg_ctx* ctx, MsmVarJob& job, const uint8_t* d
   } else {
     hipLaunchKernelGGL(k_var_scan, dim3(1), dim3(1024), 0, st, counts, nb, offsets, cursors);
   }
-  hipLaunchKernelGGL(k_var_scatter, dim3(blocks_for(nterms, 256)), dim3(256), 0, st, d_scalars, d_inf, nterms, g, cursors, entries);
+  hipLaunchKernelGGL(k_var_scatter, dim3(blocks_for(nterms, 256)), dim3(256), 0, st, d_scalars, d_inf, nterms, g, cursors, entries, split, second_base);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -337,7 +360,7 @@ static void scan_first_error(const int32_t* st, uint64_t n, int32_t* idx, int32_
 
 // ---- session set-up -----------------------------------------------------------------------------------------------
 struct SessionLayout {
-  size_t o_aff, o_inf, o_z, o_y, o_scal, o_stat, o_leaves, o_mids, o_nodes, o_pts, o_msm_a, o_msm_b, o_rpow, o_ysum, total;
+  size_t o_aff, o_inf, o_z, o_y, o_scal, o_glv_b, o_glv_a, o_stat, o_leaves, o_mids, o_nodes, o_pts, o_msm_a, o_msm_b, o_rpow, o_ysum, total;
 };
 static SessionLayout session_layout(const kzg_ctx* ctx, uint64_t n) {
   SessionLayout L{};
@@ -348,18 +371,21 @@ static SessionLayout session_layout(const kzg_ctx* ctx, uint64_t n) {
     off = align_up(off + bytes, 256);
     return o;
   };
-  L.o_aff = take((2 * n + 1) * 96);
+  const bool glv = use_glv(ctx, n);
+  L.o_aff = take((glv ? 2 : 1) * (2 * n + 1) * 96);  // GLV: the [z^2]-images behind the points
   L.o_inf = take(2 * n + 1);
   L.o_z = take(n * 32 + 32);
   L.o_y = take(n * 32 + 32);
   L.o_scal = take((2 * n + 1) * 32);
+  L.o_glv_b = take(glv ? 2 * (2 * n + 1) * 32 : 0);
+  L.o_glv_a = take(glv ? 2 * n * 32 : 0);
   L.o_stat = take(3 * n * 4 + 4);
   L.o_leaves = take(n * 32 + 32);
   L.o_mids = take((n / 16 + 1) * 32 + 32);
   L.o_nodes = take(groups * 32 + 32);
   L.o_pts = take(2 * n * 48 + 48);
-  L.o_msm_a = take(msm_var_layout(ctx, n).total + 256);
-  L.o_msm_b = take(msm_var_layout(ctx, 2 * n + 1).total + 256);
+  L.o_msm_a = take((glv ? msm_var_layout(ctx, 2 * n, true) : msm_var_layout(ctx, n)).total + 256);
+  L.o_msm_b = take((glv ? msm_var_layout(ctx, 2 * (2 * n + 1), true) : msm_var_layout(ctx, 2 * n + 1)).total + 256);
   L.o_rpow = take(64 * 32);
   L.o_ysum = take(((n + 255) / 256 + 1) * 32);
   L.total = off;
@@ -443,6 +469,9 @@ static int32_t session_acquire(const kzg_ctx* ctx, uint64_t n, hipStream_t st, k
   s->z = (fr_t*)(s->buf + L.o_z);
   s->y = (fr_t*)(s->buf + L.o_y);
   s->scal = (fr_t*)(s->buf + L.o_scal);
+  s->glv = use_glv(ctx, n);
+  s->glv_b = (fr_t*)(s->buf + L.o_glv_b);
+  s->glv_a = (fr_t*)(s->buf + L.o_glv_a);
   s->stat = (int32_t*)(s->buf + L.o_stat);
   s->leaves = (uint32_t*)(s->buf + L.o_leaves);
   s->mids = (uint32_t*)(s->buf + L.o_mids);
@@ -454,6 +483,7 @@ static int32_t session_acquire(const kzg_ctx* ctx, uint64_t n, hipStream_t st, k
   s->ysum = (fr_t*)(s->buf + L.o_ysum);
   // generator term, cleared flags and statuses
   if (hipMemcpyAsync(s->aff + (2 * n) * 6, ctx->d_gen_affine, 96, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+      (s->glv && hipMemcpyAsync(s->aff + ((2 * n + 1) + 2 * n) * 6, ctx->d_gen_affine + 6, 96, hipMemcpyDeviceToDevice, st) != hipSuccess) ||  // [z^2]G
       hipMemsetAsync(s->inf, 0, 2 * n + 1, st) != hipSuccess || hipMemsetAsync(s->stat, 0, 3 * n * 4 + 4, st) != hipSuccess) {
     kzg_verify_session_destroy(s);
     return fail(KZG_FAIL_HIP, "verify session init failed");
@@ -514,6 +544,8 @@ static int32_t phase1_items(kzg_verify_session* s, const uint8_t* blobs, const u
         ProfScope ps(ctx, PROF_DECODE, side);
         launch_g1_decompress_range(side, beside, 2 * n - beside, prf, n, s->stat + 2 * n, com, n, s->stat + n, s->aff, s->inf);
       }
+      if (s->glv)  // the [z^2]-images of the 2n decoded points, right behind the decoder on its stream (one product per point)
+        hipLaunchKernelGGL(k_glv_points, dim3(blocks_for(2 * n, 64)), dim3(64), 0, side, s->aff, 2 * n, 2 * n + 1);
       (void)hipEventRecord(s->ev_join, side);
     }
   }
@@ -735,6 +767,7 @@ int32_t verify_phase1_host(const kzg_ctx* ctx, const uint8_t* blobs, const uint8
         ProfScope ps(ctx, PROF_DECODE, s->side);
         launch_g1_decompress(s->side, prf, n, s->stat + 2 * n, com, n, s->stat + n, s->aff, s->inf);
       }
+      if (s->glv) hipLaunchKernelGGL(k_glv_points, dim3(blocks_for(2 * n, 64)), dim3(64), 0, s->side, s->aff, 2 * n, 2 * n + 1);
       (void)hipEventRecord(s->ev_join, s->side);
       for (int r = 0; r < KZG_STAGE_STREAMS; r++) (void)hipStreamWaitEvent(ctx->stage_streams[r], s->ev_fork, 0);  // session initialised, points resident (all of them: the join below is over all)
       for (uint64_t k = 0; k < nchunks && rc == 0; k++) {
@@ -992,6 +1025,7 @@ static int32_t p2_scalars(kzg_verify_session* s, const uint8_t* roots32, uint64_
   if (hipMemcpyAsync(s->rpow2, rpow2, sizeof(rpow2), hipMemcpyHostToDevice, st) != hipSuccess) return fail(KZG_FAIL_HIP, "copy");  // pageable source: staged before the call returns
   hipLaunchKernelGGL(k_batch_scalars, dim3(nblk), dim3(256), 0, st, s->rpow2, s->z, s->y, n, first_index, s->scal + n, s->scal, s->ysum);
   hipLaunchKernelGGL(k_batch_ysum_finish, dim3(1), dim3(256), 0, st, s->ysum, nblk, s->scal + 2 * n);
+  if (s->glv) hipLaunchKernelGGL(k_glv_split, dim3(blocks_for(2 * n + 1, 256)), dim3(256), 0, st, s->scal, n, s->glv_b, s->glv_a);
   if (hipGetLastError() != hipSuccess) return fail(KZG_FAIL_HIP, "verify phase 2 launch failed");
   return 0;
 }
@@ -1006,6 +1040,17 @@ static int32_t p2_sort(kzg_verify_session* s, Phase2& p2, bool beside_decoder) {
   (void)hipStreamWaitEvent(s->aux, s->ev_aux, 0);
   const uint8_t* inf = beside_decoder ? nullptr : s->inf;
   int32_t rc = 0;
+  if (s->glv) {  // (points at infinity are all-zero entries, theirs and their images': the bucket chains skip them, no flags needed)
+    {
+      ProfScope psb(ctx, PROF_VAR_MSM, s->st);
+      rc = msm_var_sort(ctx, p2.jb, nullptr, s->glv_b, 2 * (2 * n + 1), s->st, s->msm_b, beside_decoder, true, 2 * n + 1, 2 * n + 1);
+    }
+    if (rc == 0) {
+      ProfScope psa(ctx, PROF_VAR_MSM, s->aux);
+      rc = msm_var_sort(ctx, p2.ja, nullptr, s->glv_a, 2 * n, s->aux, s->msm_a, beside_decoder, true, n, 2 * n + 1);
+    }
+    return rc;
+  }
   {
     ProfScope psb(ctx, PROF_VAR_MSM, s->st);
     rc = msm_var_sort(ctx, p2.jb, inf, s->scal, 2 * n + 1, s->st, s->msm_b, beside_decoder);

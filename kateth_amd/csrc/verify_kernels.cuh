@@ -3,6 +3,7 @@
 #pragma once
 #include "blob_device.cuh"
 #include "fr29.cuh"
+#include "glv.cuh"
 #include "msm_fixed.cuh"
 
 namespace kzg {
@@ -664,14 +665,54 @@ static __global__ __launch_bounds__(256, 8) void k_var_scan_lean(const uint32_t*
   }
 }
 
+// An entry names the POINT of its term: term t uses point t, or -- GLV, the second half of a lincomb's terms (t >= split) -- point
+// second_base + (t - split), the [z^2]-image of point t - split (k_glv_points).  Without GLV split = nterms.
 static __global__ __launch_bounds__(256) void k_var_scatter(const fr_t* __restrict__ scalars, const uint8_t* __restrict__ inf, uint64_t nterms,
-                                                     VarGeom g, uint32_t* __restrict__ cursors, uint32_t* __restrict__ entries) {
+                                                     VarGeom g, uint32_t* __restrict__ cursors, uint32_t* __restrict__ entries, uint64_t split,
+                                                     uint64_t second_base) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= nterms || (inf && inf[t])) return;
+  const uint32_t point = (uint32_t)(t < split ? t : second_base + (t - split));
   var_digits(scalars[t], g, [&](uint32_t j, uint32_t d, bool neg) {
     const uint32_t pos = atomicAdd(&cursors[(uint64_t)j * g.half + (d - 1)], 1u);
-    entries[pos] = ((uint32_t)t << 1) | (neg ? 1u : 0u);
+    entries[pos] = (point << 1) | (neg ? 1u : 0u);
   });
+}
+
+// ---- GLV (glv.cuh): scalars split at z^2, points mapped by [z^2](x, y) = (beta x, -y) ------------------------------------------
+// scal = the batch scalars as k_batch_scalars / k_batch_ysum_finish leave them: [r_i z_i (n) | r_i (n) | -sum r_i y_i (1)], plain.
+// out_b (2 (2n + 1)): lincomb B's terms  [k1 of all 2n + 1 | k2 of all 2n + 1];  out_a (2n): lincomb A's  [k1 of r_i | k2 of r_i].
+static __global__ __launch_bounds__(256) void k_glv_split(const fr_t* __restrict__ scal, uint64_t n, fr_t* __restrict__ out_b, fr_t* __restrict__ out_a) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t nt = 2 * n + 1;
+  if (t >= nt) return;
+  fr_t k1, k2;
+  glv_split(k1, k2, scal[t]);
+  out_b[t] = k1;
+  out_b[nt + t] = k2;
+  if (t >= n && t < 2 * n) {
+    out_a[t - n] = k1;
+    out_a[t] = k2;  // n + (t - n)
+  }
+}
+// points [0, npts) of `aff` (x * 2^392, y * 2^392, canonical; all zero = infinity or a rejected input) -> their [z^2]-images
+// (beta x, -y) at [phi_off, phi_off + npts)
+static __global__ __launch_bounds__(64) void k_glv_points(uint4* __restrict__ aff, uint64_t npts, uint64_t phi_off) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= npts) return;
+  fp_t x, y;
+  load_affine96(x, y, aff, t);
+  if (!(bn_is_zero(x) && bn_is_zero(y))) {
+    fp28 a, b;
+    f28_from_bn(a, x);
+    KZG_UNROLL_FULL
+    for (int i = 0; i < F28_N; i++) b.l[i] = f28_beta_limb(i);
+    f28_mul(a, a, b);  // beta x * 2^392, N-form
+    f28_to_bn(x, a);
+    canonicalize<FpParams>(x);
+    fp_neg(y, y);      // p - y: y is canonical and non-zero on this curve's group (no point of order two)
+  }
+  store_affine96(aff, phi_off + t, x, y);
 }
 
 // thread = (bucket, k of K): entries lo+k, lo+k+K, ... of the bucket's sorted list.  Points are affine in the

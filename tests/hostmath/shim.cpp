@@ -14,6 +14,7 @@
 #include "../../kateth_amd/csrc/modinv30.cuh"
 #include "../../kateth_amd/csrc/sha256.cuh"
 #include "../../kateth_amd/csrc/multi_split.hpp"
+#include "../../kateth_amd/csrc/glv.cuh"
 
 using namespace kzg;
 
@@ -611,4 +612,16 @@ extern "C" int32_t hm_g1_sum30(uint8_t* out48, const uint8_t* pts48, const uint8
   xyzz30_to_xyzz(r, acc);
   g1_compress_xyzz(out48, r);
   return 0;
+}
+
+// ---- GLV split of a scalar (kateth_amd/csrc/glv.cuh): k (32 B little-endian) -> k1 || k2 (32 B each, little-endian) -------------
+extern "C" void hm_glv_split(uint8_t* out64, const uint8_t* k32) {
+  fr_t k, k1, k2;
+  load_le(k, k32);
+  glv_split(k1, k2, k);
+  for (int i = 0; i < 8; i++)
+    for (int b = 0; b < 4; b++) {
+      out64[4 * i + b] = (uint8_t)(k1.v[i] >> (8 * b));
+      out64[32 + 4 * i + b] = (uint8_t)(k2.v[i] >> (8 * b));
+    }
 }

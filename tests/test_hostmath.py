@@ -488,6 +488,27 @@ def test_fp30_madd_complete(hm):
     assert hm.hm_f28_violations() == before
 
 
+def test_glv_split_of_a_scalar(hm):
+    """glv.cuh: k = k1 + k2 z^2 with k1 < z^2 < 2^128 and k2 = floor(k / z^2) < 2^128, for random scalars, the extremes of the field,
+    multiples of z^2 and their neighbours (the Barrett estimate is corrected up to twice); and [z^2]P = (beta x, -y) on the curve"""
+    rnd = random.Random(0x61F)
+    Z = 0xD201000000010000
+    Z2 = Z * Z
+    out = ctypes.create_string_buffer(64)
+    cases = [0, 1, Z2 - 1, Z2, Z2 + 1, R - 1, R - 2, (R - 1) // 2, 5 * Z2 - 1, (Z2 - 1) * Z2, (Z2 - 2) * Z2 + Z2 - 1]
+    cases += [rnd.randrange(R) for _ in range(3000)] + [rnd.randrange(Z2) * Z2 + rnd.choice([0, 1, Z2 - 1]) for _ in range(300)]
+    for k in cases:
+        if k >= R:  # the engine's scalars are canonical (k2 = floor(k / z^2) < z^2 needs k < r < z^4)
+            continue
+        hm.hm_glv_split(out, k.to_bytes(32, "little"))
+        k1, k2 = int.from_bytes(out.raw[:32], "little"), int.from_bytes(out.raw[32:], "little")
+        assert k1 == k % Z2 and k2 == k // Z2, hex(k)
+        assert k1 < 1 << 128 and k2 < 1 << 128
+    beta = 0x5F19672FDF76CE51BA69C6076A0F77EADDB3A93BE6F89688DE17D813620A00022E01FFFFFFFEFFFE
+    pt = bls.g1_mul(bls.G1_GEN, 0xABCDEF)
+    assert bls.g1_mul(pt, Z2) == (beta * pt[0] % P, (-pt[1]) % P)
+
+
 def _f29(hm, op, a, b=0, c=0, d=0):
     out = ctypes.create_string_buffer(32)
     hm.hm_f29_op(op, out, *(int(v).to_bytes(32, "little") for v in (a, b, c, d)))
