@@ -353,8 +353,14 @@ class Setup {
     if (blobs.size() != commitments.size() || commitments.size() != proofs.size() || blobs.size() != blob_lens.size())
       throw std::logic_error("assertion `left == right` failed");  // src/kzg/setup.rs:256-257 panics
     const size_t n = blobs.size();
+    // the reference's `collect` stops at the FIRST blob that fails, whatever its error (src/kzg/setup.rs:259-262): a short blob
+    // never reaches the engine, so the blobs before it get Blob::from_slice's element check (src/blob.rs:32-34) here
     for (size_t i = 0; i < n; i++)
-      if (blob_lens[i] != BLOB_BYTES) throw Error(ErrorKind::BlobInvalidLen);
+      if (blob_lens[i] != BLOB_BYTES) {
+        for (size_t j = 0; j < i; j++)
+          if (has_noncanonical_element(blobs[j])) throw Error(ErrorKind::BlobInvalidFieldElement);
+        throw Error(ErrorKind::BlobInvalidLen);
+      }
     std::vector<uint8_t> flat(n * BLOB_BYTES), cs(n * 48), ps(n * 48);
     for (size_t i = 0; i < n; i++) {
       std::copy(blobs[i], blobs[i] + BLOB_BYTES, flat.begin() + i * BLOB_BYTES);
@@ -375,6 +381,19 @@ class Setup {
   }
 
   const kzg_ctx* raw() const { return ctx_.get(); }
+
+  // some 32-byte big-endian element of a full-length blob is >= r (host side, error path only)
+  static bool has_noncanonical_element(const uint8_t* blob) {
+    static const uint8_t r_be[32] = {0x73, 0xed, 0xa7, 0x53, 0x29, 0x9d, 0x7d, 0x48, 0x33, 0x39, 0xd8, 0x08, 0x09, 0xa1, 0xd8, 0x05,
+                                     0x53, 0xbd, 0xa4, 0x02, 0xff, 0xfe, 0x5b, 0xfe, 0xff, 0xff, 0xff, 0xff, 0x00, 0x00, 0x00, 0x01};
+    for (size_t e = 0; e < KZG_FIELD_ELEMENTS_PER_BLOB; e++) {
+      const uint8_t* p = blob + 32 * e;
+      int cmp = 0;
+      for (int k = 0; k < 32 && cmp == 0; k++) cmp = (p[k] > r_be[k]) - (p[k] < r_be[k]);
+      if (cmp >= 0) return true;
+    }
+    return false;
+  }
 
  private:
   struct Deleter {

@@ -244,6 +244,13 @@ def _buf(data) -> bytes:
     return bytes(bytearray(data))
 
 
+def _has_noncanonical_element(blob: bytes) -> bool:
+    """Blob::from_slice's per-element check (src/blob.rs:32-34 -> src/bls.rs:110-120): some 32-byte big-endian element >= r.
+    Host side, error path only: the mirror needs it to name the FIRST failing blob when a later one has the wrong length."""
+    r = _R.to_bytes(32, "big")
+    return any(blob[k:k + 32] >= r for k in range(0, len(blob) - len(blob) % 32, 32))
+
+
 def _unhex(s: str) -> bytes:
     """`Bytes` deserialiser (src/bytes.rs:30-37): optional 0x prefix."""
     return bytes.fromhex(s[2:] if s.startswith("0x") else s)
@@ -671,9 +678,14 @@ class Setup:
         assert len(blobs) == len(commitments), "assertion `left == right` failed"
         assert len(commitments) == len(proofs), "assertion `left == right` failed"
         n = len(blobs)
-        # first-error-wins order of the reference: blobs, then commitments, then proofs
-        for b in blobs:
+        # first-error-wins order of the reference: blobs (in index order: `collect` stops at the FIRST blob that fails, whatever its
+        # error -- src/kzg/setup.rs:259-262), then commitments, then proofs.  A short blob never reaches the engine (the ABI takes n
+        # blobs of 131,072 bytes), so the blobs BEFORE it are checked here the way Blob::from_slice checks them (src/blob.rs:26-37):
+        # (blob 0 non-canonical, blob 1 short) is InvalidFieldElement, not InvalidLen
+        for i, b in enumerate(blobs):
             if len(b) != BYTES_PER_BLOB:
+                if any(_has_noncanonical_element(_buf(e)) for e in blobs[:i]):
+                    raise KzgError(BlobError("InvalidFieldElement"))
                 raise KzgError(BlobError("InvalidLen"))
         for c in list(commitments) + list(proofs):
             if len(c) != 48:

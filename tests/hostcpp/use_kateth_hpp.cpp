@@ -40,6 +40,22 @@ int main(int argc, char** argv) {
     } catch (const kateth::Error& e) {
       if (e.kind != kateth::ErrorKind::BlobInvalidLen) return 4;
     }
+    // first-error order of verify_blob_proof_batch (src/kzg/setup.rs:259-262: the FIRST failing blob decides): blob 0 non-canonical
+    // and blob 1 short is InvalidFieldElement; blob 0 fine and blob 1 short is InvalidLen
+    {
+      std::vector<uint8_t> nc(rb.to_bytes());
+      for (int k = 0; k < 32; k++) nc[k] = 0xff;  // element 0 >= r
+      for (int variant = 0; variant < 2; variant++) {
+        std::vector<const uint8_t*> bl = {variant == 0 ? nc.data() : rb.to_bytes().data(), rb.to_bytes().data()};
+        std::vector<size_t> lens = {kateth::Blob::BYTES, kateth::Blob::BYTES - 1};
+        try {
+          setup.verify_blob_proof_batch(bl, lens, {rc, rc}, {rp, rp});
+          return 10;
+        } catch (const kateth::Error& e) {
+          if (e.kind != (variant == 0 ? kateth::ErrorKind::BlobInvalidFieldElement : kateth::ErrorKind::BlobInvalidLen)) return 11;
+        }
+      }
+    }
     // the same over a GROUP context (the device listed twice: two members on the card): every batch is sharded behind the same methods
     auto group = kateth::Setup<4096, 65>::load_multi(g1.data(), g2.data(), {0, 0}, 8);
     if (group.members() != 2 || setup.members() != 1) return 7;

@@ -55,3 +55,34 @@ def test_p1_image_compresses_like_the_oracle():
             img = (x * (1 << 384) % bls.P).to_bytes(48, "little") + (y * (1 << 384) % bls.P).to_bytes(48, "little")
             assert kateth_amd.P1(img).compress() == bls.g1_compress(q)
     assert kateth_amd.P1(bytes(96)).compress() == bls.g1_compress(None) and kateth_amd.P1(bytes(96)).is_inf()
+
+
+def test_batch_verification_names_the_first_failing_blob(oracle_setup):
+    """src/kzg/setup.rs:259-262: the blobs are parsed in index order and `collect` stops at the FIRST one that fails -- so
+    (blob 0 non-canonical, blob 1 short) is InvalidFieldElement, (blob 0 fine, blob 1 short) InvalidLen, (blob 0 short, blob 1
+    non-canonical) InvalidLen.  A short blob never reaches the engine (the C ABI takes n full blobs): the host mirror decides, and
+    must decide like the reference (the oracle restates it).  No GPU needed: the decision falls before any library call."""
+    from oracle.pyref.setup import KzgError as OracleKzgError
+
+    good = (7).to_bytes(32, "big") * 4096
+    noncanonical = R.to_bytes(32, "big") + good[32:]
+    short = good[:-1]
+    c = bls.g1_compress(bls.G1_GEN)
+    mirror = object.__new__(kateth_amd.Setup)  # no context: every case below is decided on the host
+    mirror._h, mirror._lib = None, None
+
+    def kind_of(fn):
+        try:
+            fn()
+        except (kateth_amd.KzgError, OracleKzgError) as err:
+            inner = err
+            while hasattr(inner, "inner"):
+                inner = inner.inner
+            return getattr(inner, "kind", None) or str(inner)
+        return "no error"
+
+    for blobs, want in (([noncanonical, short], "InvalidFieldElement"), ([good, short], "InvalidLen"), ([short, noncanonical], "InvalidLen"),
+                        ([good, noncanonical, short], "InvalidFieldElement"), ([short], "InvalidLen")):
+        cs, ps = [c] * len(blobs), [c] * len(blobs)
+        assert want in kind_of(lambda: mirror.verify_blob_proof_batch(blobs, cs, ps)), (want, len(blobs))
+        assert want in kind_of(lambda: oracle_setup.verify_blob_proof_batch(blobs, cs, ps)), (want, len(blobs))
