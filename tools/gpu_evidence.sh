@@ -1,10 +1,11 @@
 #!/bin/bash
-# Round-4 evidence besides tools/gpu_profile_r04.sh: host-buffer rates, the library-default budget, proofs with one and two calls
-# in flight, the criterion-equivalent single-item table, the host-buffer proof call's timeline (kernels + PCIe copies).
-# Outputs under gpurun_out/r04/; copied into profiles/r04/ by hand (see the commit that added them).
+# usage: tools/gpu_evidence.sh <tag>   (e.g. r05).  Evidence besides tools/gpu_profile.sh: host-buffer rates, the library-default
+# budget, proofs with one, two and three calls in flight, the criterion-equivalent single-item table, the host-buffer proof call's
+# timeline (kernels + PCIe copies), the group path.  Outputs under gpurun_out/<tag>/; copied into profiles/<tag>/ by hand.
 set -o pipefail
+TAG=${1:?usage: gpu_evidence.sh <tag>}
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r04
+O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
 python tools/gpu_hostapi_bench.py 4096 0 > $O/hostapi_n4096.json 2> $O/evidence.err
@@ -21,4 +22,7 @@ rm -rf $O/hp_trace
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_proof -- python3 $R/bench.py --workload proof --in-flight 1 --steps 5 --warmup 2 --no-cpu-baseline --no-live-traffic --blocking-setup > $O/trace_proof.log 2>&1
 cp $(find $O/trace_proof -name "*kernel_stats.csv" | head -1) $O/trace_proof4096_kernel_stats.csv
 rm -rf $O/trace_proof
+python bench.py --group 2 --batch 2048 --steps 10 --warmup 3 > $O/group2_commit.json 2>> $O/evidence.err
+python bench.py --group 2 --batch 2048 --workload proof --steps 10 --warmup 3 > $O/group2_proof.json 2>> $O/evidence.err
+python bench.py --group 2 --batch 32768 --workload verify --steps 5 --warmup 2 > $O/group2_verify.json 2>> $O/evidence.err
 echo evidence done

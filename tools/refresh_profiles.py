@@ -1,13 +1,18 @@
 #!/usr/bin/env python3
-"""Copies the summaries of the last tools/gpu_profile_r04.sh run (gpurun_out/r04/prof/), the last default bench line and the
-kernel timelines from gpurun_out/ into profiles/r04/ and computes pmc_traffic.json from the counters."""
+"""usage: refresh_profiles.py <tag>   (e.g. r05)
+Copies the summaries of the last `tools/gpu_profile.sh <tag>` run (gpurun_out/<tag>/prof/), the last default bench line
+(gpurun_out/<tag>/bench_default.json) and the kernel timelines into profiles/<tag>/ and computes pmc_traffic.json from the
+counters.  One script for every round (rounds 3 and 4 each had a copy)."""
 import json
 import os
 import shutil
+import sys
 
+TAG = sys.argv[1]
+MSM = "k_msm_comb30"  # the fixed-base MSM kernel (k_msm_comb28 until round 4)
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))) + "/"
-P = R + "gpurun_out/r04/prof/"
-D = R + "profiles/r04/"
+P = R + "gpurun_out/%s/prof/" % TAG
+D = R + "profiles/%s/" % TAG
 os.makedirs(D, exist_ok=True)
 new = json.load(open(P + "summary_pmc.json"))
 KiB = 1024.0
@@ -28,10 +33,10 @@ def hbm(run, kern, corr=1.0):
 
 
 out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (KiB per dispatch), separate passes, per launch; correction x2 on FETCH_SIZE for the wide coalesced streaming "
-               "readers (k_challenge, k_eval_frac) as MI355X_MICROARCH.md prescribes, x1 for gathers (k_msm_comb28: matches the known gather bytes) and for the point decoder"}
-c = hbm("pmc_commit", "k_msm_comb28")
+               "readers (k_challenge, k_eval_frac) as MI355X_MICROARCH.md prescribes, x1 for gathers (the fixed-base MSM kernel: matches the known gather bytes) and for the point decoder"}
+c = hbm("pmc_commit", MSM)
 alg_c = 131120 * 4096
-out["commit_n4096_c22"] = dict(c, kernel="k_msm_comb28", algorithmic_bytes_per_launch=alg_c, hbm_bytes_per_launch=c["hbm_bytes"], over_algorithmic=c["hbm_bytes"] / alg_c,
+out["commit_n4096_c22"] = dict(c, kernel=MSM, algorithmic_bytes_per_launch=alg_c, hbm_bytes_per_launch=c["hbm_bytes"], over_algorithmic=c["hbm_bytes"] / alg_c,
                                known_gather_bytes=49152 * 4096 * 96)
 alg_v = 131168 * 65536
 ch, ev, dc = hbm("pmc_verify", "k_challenge", 2.0), hbm("pmc_verify", "k_eval_frac", 2.0), hbm("pmc_verify", "k_g1_decompress_range")
@@ -54,8 +59,8 @@ for a, b in (("default", "bench_default_kernel_stats.csv"), ("commit", "trace_co
     if os.path.exists(P + "summary_trace_%s_kernel_stats.csv" % a):
         shutil.copy(P + "summary_trace_%s_kernel_stats.csv" % a, D + b)
 for src, dst in ((P + "timeline_verify.txt", "verify65536_kernel_timeline.txt"), (P + "timeline_proof2.txt", "proof4096_two_calls_in_flight_kernel_timeline.txt"),
-                 (P + "timeline_proof3.txt", "proof4096_three_calls_in_flight_kernel_timeline.txt"),
-                 (R + "gpurun_out/bench_default.json", "bench_default.json")):
+                 (P + "timeline_proof3.txt", "proof4096_three_calls_in_flight_kernel_timeline.txt"), (P + "timeline_proof.txt", "proof4096_kernel_timeline.txt"),
+                 (R + "gpurun_out/%s/bench_default.json" % TAG, "bench_default.json")):
     if os.path.exists(src):
         shutil.copy(src, D + dst)
 for w in ("default", "commit", "proof", "proof2", "proof3", "verify"):
@@ -72,5 +77,5 @@ if os.path.exists(D + "bench_default.json"):
           [(round(m["value"]), m.get("valu_issue_frac"), m.get("value_two_calls_in_flight") or m.get("value_three_calls_in_flight")) for m in d["secondary_metrics"]], d["extra"]["single_blob_latency_ms"])
 print("decoder WRITE_SIZE per launch (bytes):", dc["WRITE_SIZE_bytes"], " verify call HBM / algorithmic:", out["verify_n65536_c22"]["call_over_algorithmic"])
 print("commit traffic / algorithmic:", out["commit_n4096_c22"]["over_algorithmic"])
-for run, kern in (("pmc_commit_sq", "k_msm_comb28"), ("pmc_verify_sq", "k_challenge"), ("pmc_verify_sq", "k_eval_frac"), ("pmc_verify_sq", "k_g1_decompress_range")):
+for run, kern in (("pmc_commit_sq", MSM), ("pmc_verify_sq", "k_challenge"), ("pmc_verify_sq", "k_eval_frac"), ("pmc_verify_sq", "k_g1_decompress_range")):
     print(run, kern, "SQ_INSTS_VALU per launch:", per(run, kern, "SQ_INSTS_VALU"))

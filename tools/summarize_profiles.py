@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Condenses the rocprofv3 outputs of tools/gpu_profile_r02.sh: the kernel-stats CSV of the traced run and, per PMC pass,
+"""Condenses the rocprofv3 outputs of tools/gpu_profile.sh: the kernel-stats CSV of the traced run and, per PMC pass,
 per-kernel per-launch counter averages (launch counts included) -> <dir>/summary_*.{csv,json}."""
 import collections
 import csv
