@@ -250,7 +250,7 @@ def pmc_traffic(workload, n, window_bits):
     """HBM bytes per launch of the workload's dominant kernel from the COMMITTED rocprofv3 PMC passes (profiles/r0N/
     pmc_traffic.json): the fallback when the live passes (live_pmc_traffic) are switched off or fail.  None when no profile of
     this (workload, batch, class) configuration has been recorded."""
-    for rel in (("profiles", "r04", "pmc_traffic.json"), ("profiles", "r03", "pmc_traffic.json"), ("profiles", "r02", "pmc_traffic.json"), ("profiles", "r01", "pmc_traffic.json")):
+    for rel in (("profiles", "r05", "pmc_traffic.json"), ("profiles", "r04", "pmc_traffic.json"), ("profiles", "r03", "pmc_traffic.json"), ("profiles", "r02", "pmc_traffic.json"), ("profiles", "r01", "pmc_traffic.json")):
         try:
             rec = json.load(open(os.path.join(ROOT, *rel)))
         except (OSError, ValueError):
