@@ -72,3 +72,9 @@ void launch_synth_blobs(hipStream_t st, uint64_t seed, uint64_t first_index, uin
   if (elems == 0) return;
   hipLaunchKernelGGL(k_synth_blobs, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, st, seed, first_index, elems, d_blobs);
 }
+
+void warm_code_object_blob() {
+  hipFuncAttributes a;
+  (void)hipFuncGetAttributes(&a, (const void*)k_synth_blobs);
+  (void)hipGetLastError();
+}

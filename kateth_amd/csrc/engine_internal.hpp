@@ -348,6 +348,13 @@ uint32_t choose_splits(const kzg_ctx* ctx, uint64_t n);
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static inline unsigned blocks_for(uint64_t n, unsigned per) { return (unsigned)((n + per - 1) / per); }
 
+// Every translation unit carries its kernels in a code object of its own, which the HIP runtime loads at the unit's FIRST launch --
+// behind whatever the runtime is doing then: with KZG_CFG_BUILD_ASYNC that is the background thread's 96- / 192-GiB allocation, and the
+// first commitment after kzg_ctx_create waited 1.5-4.7 s for it (profiles/r05/first_use_regression.json).  kzg_ctx_create therefore
+// touches one kernel of every unit (hipFuncGetAttributes) before it starts the background build.
+void warm_code_object_blob();    // engine_blob.hip
+void warm_code_object_proof();   // engine_proof.hip
+void warm_code_object_verify();  // engine_verify.hip
 // ---- launchers of engine_blob.hip (hash, point decoding, scalar parsing: blob_kernels.cuh) --------------------------------
 // Fiat-Shamir challenges of n blobs (Blob::challenge, src/blob.rs:78-97) into z (plain limbs)
 void launch_challenge(const kzg_ctx* ctx, hipStream_t st, const uint8_t* blobs, const uint8_t* commitments48, uint64_t n, fr_t* z);

@@ -276,3 +276,9 @@ extern "C" int32_t kzg_compute_proof_batch_affine(const kzg_ctx* ctx, const uint
   if (!ctx || (n && (!blobs || !z32 || !out_proof_affine96 || !out_y32 || !status))) return fail(KZG_FAIL_ARGUMENT, "null argument");
   return (is_group(ctx) ? multi_proof : proof_host)(ctx, blobs, z32, 32, false, n, nullptr, out_proof_affine96, out_y32, status);
 }
+
+void warm_code_object_proof() {
+  hipFuncAttributes a;
+  (void)hipFuncGetAttributes(&a, (const void*)k_poly_root_inverse);
+  (void)hipGetLastError();
+}

@@ -1475,3 +1475,9 @@ int32_t verify_proof_single(const kzg_ctx* ctx, const uint8_t* proof48, const ui
   if (rc) return rc;
   return kzg_verify_batch_finish(ctx, partial, 1, ok);
 }
+
+void warm_code_object_verify() {
+  hipFuncAttributes a;
+  (void)hipFuncGetAttributes(&a, (const void*)k_batch_ysum_finish);
+  (void)hipGetLastError();
+}
