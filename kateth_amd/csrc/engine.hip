@@ -720,6 +720,11 @@ static int32_t ctx_create_with(const uint8_t* g1_lagrange, const uint8_t* g2_mon
     error_publish(keep);
     return rc;
   }
+  // every unit's code object in, now -- with KZG_CFG_BUILD_ASYNC BEFORE the background thread's allocation holds the runtime
+  // (engine_internal.hpp); this unit's own was loaded by the setup kernels above
+  warm_code_object_blob();
+  warm_code_object_proof();
+  warm_code_object_verify();
   *out = ctx;
   return 0;
 }
@@ -853,16 +858,6 @@ int32_t ctx_create_single(const uint8_t* g1_lagrange, const uint8_t* g2_monomial
               ladder[0].c, ladder[0].G);
     int32_t rc = ctx_create_with(g1_lagrange, g2_monomial, device, 8, 16, &ctx);
     if (rc) return rc;
-    // every unit's code object in, BEFORE the background thread's allocation holds the runtime (engine_internal.hpp); this unit's was
-    // loaded by the setup kernels above
-    warm_code_object_blob();
-    warm_code_object_proof();
-    warm_code_object_verify();
-    {
-      hipFuncAttributes a;
-      (void)hipFuncGetAttributes(&a, (const void*)k_msm_comb30<false>);
-      (void)hipGetLastError();
-    }
     {
       std::lock_guard<std::mutex> guard(ctx->build_mu);
       ctx->build_running = true;
