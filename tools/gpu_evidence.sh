@@ -22,6 +22,7 @@ rm -rf $O/hp_trace
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_proof -- python3 $R/bench.py --workload proof --in-flight 1 --steps 5 --warmup 2 --no-cpu-baseline --no-live-traffic --blocking-setup > $O/trace_proof.log 2>&1
 cp $(find $O/trace_proof -name "*kernel_stats.csv" | head -1) $O/trace_proof4096_kernel_stats.csv
 rm -rf $O/trace_proof
+cd $R
 python bench.py --group 2 --batch 2048 --steps 10 --warmup 3 > $O/group2_commit.json 2>> $O/evidence.err
 python bench.py --group 2 --batch 2048 --workload proof --steps 10 --warmup 3 > $O/group2_proof.json 2>> $O/evidence.err
 python bench.py --group 2 --batch 32768 --workload verify --steps 5 --warmup 2 > $O/group2_verify.json 2>> $O/evidence.err
