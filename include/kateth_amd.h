@@ -15,7 +15,8 @@
  * A kzg_ctx is immutable after creation and may be used from several host
  * threads at once, matching `&self` + `Arc<Setup>` in the reference
  * (src/kzg/setup.rs:323): commitment and proof calls hold an internal lock only
- * while they enqueue and take the context's three GPU workspaces in turn, so calls
+ * while they enqueue and take one of the context's three GPU workspaces (the lowest
+ * one whose last user has completed or ran on the call's own stream), so calls
  * enqueued on several streams run side by side; every verification call takes its
  * own pooled session (device scratch + streams) and runs beside the others; the
  * host-buffer calls additionally serialise on the staging arena.  A context

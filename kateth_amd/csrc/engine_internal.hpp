@@ -218,7 +218,7 @@ struct kzg_ctx {
   CombGeom comb_lat{};
   uint4* d_table_lat = nullptr;
   // the comb's constant term K = [(2^256-1)/2] * (sum of the setup points) as the STARTING VALUE of one lane per blob: that lane
-  // doubles its accumulator H - 1 times, so the stored point is [c0 / 2^(H-1)] S (affine, table format: 2^392-Montgomery, 96 B;
+  // doubles its accumulator H - 1 times, so the stored point is [c0 / 2^(H-1)] S (affine, table format: packed centred 30-bit digits of x * 2^390, 96 B -- fp30.cuh;
   // null = identity), one per table geometry
   uint4* d_comb_k = nullptr;
   uint4* d_comb_k_lat = nullptr;
@@ -226,7 +226,7 @@ struct kzg_ctx {
   uint4* d_bases_brp = nullptr;  // 4096 affine Lagrange points, BRP order
   fr_t* d_roots_brp = nullptr;   // 4096 roots of unity, Montgomery, BRP order
   uint32_t* d_eval_tab = nullptr;  // 256 hexes x twenty 9-limb slots in radix-2^29 limbs (layout: fr29.cuh; k_eval_frac, verify_kernels.cuh)
-  uint4* d_gen_affine = nullptr; // G1 generator, affine, 2^392-Montgomery (96 B): a term of batch verification's second lincomb
+  uint4* d_gen_affine = nullptr; // G1 generator and its [z^2]-image (GLV cross-check path), affine, 2^392-Montgomery (2 x 96 B): a term of batch verification's second lincomb
   host::pairing_ctx* pairing = nullptr;  // host: Frobenius constants + Miller lines of G2 and [tau]_2
   uint64_t table_bytes = 0;
   uint32_t num_cus = 256;

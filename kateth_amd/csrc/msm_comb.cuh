@@ -23,7 +23,7 @@
 // mask = bit k of 64 consecutive scalars; it also performs Blob::from_slice's canonicity check, src/blob.rs:26-37).
 //
 // Work decomposition: one wave per (blob, split), or per PAIR of blobs from num_CUs x 16 blobs per launch on (half-wave
-// mode: 32 lanes per blob); lane = (plane group, block owner).  The hot loop is the radix-2^28 mixed addition
+// mode: 32 lanes per blob); lane = (plane group, block owner).  The hot loop is the mixed addition
 // (xyzz30_madd_fast, fp30.cuh: signed radix 2^30 since round 5; the table holds packed centred digits) with the next table entry gathered while the current addition runs, the masks
 // of a lane's next four chunks fetched by one 32-byte load, and the two waves of a SIMD trading issue priority
 // (issue_fair.cuh) so that they finish together.
