@@ -103,7 +103,8 @@ typedef struct kzg_ctx kzg_ctx;
  * than the 96-GiB table (2.4 % slower than the 192-GiB one), whatever the device has free -- unless flags carries
  * KZG_CFG_TABLE_MAX, which lifts the cap (bench.py opts in; 192 GiB on an idle MI355X).  An explicit window_bits /
  * plane_groups is honoured as given and fails if it cannot be built.  PRECEDENCE, one rule: a non-zero field of kzg_config
- * beats the environment (KATETH_AMD_WINDOW_BITS, KATETH_AMD_COMB_GROUPS), which beats the automatic choice.
+ * beats the environment (KATETH_AMD_WINDOW_BITS, KATETH_AMD_COMB_GROUPS, KATETH_AMD_TABLE_BUDGET_GIB -- an operator's cap on
+ * the automatic choice of an unconfigured drop-in, e.g. 16 for the 12.9-GB table), which beats the automatic choice.
  * kzg_ctx_window_bits / kzg_ctx_plane_groups / kzg_ctx_table_bytes report what was built.
  */
 #define KZG_CFG_TABLE_MAX 0x1   /* flags: the automatic choice may take the largest table the device has room for (192 GiB) */

@@ -833,6 +833,9 @@ int32_t ctx_create_single(const uint8_t* g1_lagrange, const uint8_t* g2_monomial
   if (G_fixed && !(G_fixed == 1 || G_fixed == 2 || G_fixed == 4 || G_fixed == 8 || G_fixed == 16))
     return fail(KZG_FAIL_ARGUMENT, "plane groups must be 1, 2, 4, 8 or 16");
   size_t budget = cfg ? (size_t)cfg->table_budget_bytes : 0;
+  if (budget == 0 && !(flags & KZG_CFG_TABLE_MAX))
+    if (const char* e = getenv("KATETH_AMD_TABLE_BUDGET_GIB"))  // an operator's cap on an unconfigured drop-in (the same precedence rule: a field beats the variable)
+      if (atof(e) > 0) budget = (size_t)(atof(e) * (double)GiB);
   if (budget == 0) budget = (flags & KZG_CFG_TABLE_MAX) ? ~(size_t)0 : 100 * GiB;
   // candidates (class, plane groups), fastest first
   const TableChoice full[4] = {{22, 8, 8 * GROUP22_BYTES + 40 * GiB}, {22, 4, 4 * GROUP22_BYTES + 40 * GiB}, {16, 16, 21 * GiB}, {8, 16, 0}};

@@ -390,6 +390,21 @@ def test_automatic_choice_respects_the_budget(torch_cuda):
         assert (s.window_bits, s.plane_groups) == (8, 16)
     finally:
         s.close()
+    # the operator's cap on an unconfigured drop-in (round 5): KATETH_AMD_TABLE_BUDGET_GIB, beaten by an explicit field
+    os.environ["KATETH_AMD_TABLE_BUDGET_GIB"] = "16"
+    try:
+        s = kateth_amd.Setup.load_json(TRUSTED_SETUP)
+        try:
+            assert (s.window_bits, s.plane_groups) == ((16, 16) if free >= 21 << 30 else (8, 16))
+        finally:
+            s.close()
+        s = kateth_amd.Setup.load_json(TRUSTED_SETUP, table_budget_bytes=1 << 30)
+        try:
+            assert (s.window_bits, s.plane_groups) == (8, 16)
+        finally:
+            s.close()
+    finally:
+        del os.environ["KATETH_AMD_TABLE_BUDGET_GIB"]
     if free >= 136 << 30:
         s = kateth_amd.Setup.load_json(TRUSTED_SETUP)
         try:
