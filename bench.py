@@ -52,7 +52,7 @@ METRIC = {
     "verify": "blobs/sec for verify_blob_kzg_proof_batch (n=4096 field elements per blob)",
 }
 DEFAULT_BATCH = {"commit": 4096, "proof": 4096, "verify": 65536}
-DTYPE = "u32 limbs (381-bit Fp / 255-bit Fr Montgomery integer arithmetic; 28/29-bit radix in the hot loops)"
+DTYPE = "u32 limbs (381-bit Fp / 255-bit Fr Montgomery integer arithmetic; signed 30-bit limbs on v_mad_i64_i32 in the fixed-base MSM, 28/29-bit radix in the other hot loops)"
 
 
 def parse():
