@@ -11,13 +11,16 @@
 // centred values, limbs <= 2^30): worst column 2^62.92 < 2^63 (tools/exp/fp30_model.py runs the extremes).  Signed values
 // also make a subtraction what it is (no multiple of p to add), and a centred quotient keeps every product in (-0.53 p, 0.53 p)
 // whatever came in, so values never grow.  What it costs: v_mad_i64_i32 instead of v_mad_u64_u32 (same issue slot), a rounding
-// add per output column (the carry of a centred digit is round(A / 2^30), not floor), and a carry pass before a value that
-// came out of an addition goes into a squaring or into a second lazy position (four per mixed addition instead of one).
-// Net per mixed addition: -460 multiplies, +190 other instructions (DESIGN.md section 5.3 has the tally and the measurement).
+// add per output column (the carry of a centred digit is round(A / 2^30), not floor), and a value that came out of an addition
+// has limbs too wide for a squaring or for a second lazy position.  A carry pass (f30_carry) repairs that; the hot loop does
+// not need one: its three differences are INJECTED into the product that feeds them (f30_mul_inj: the subtrahend's limbs join
+// the columns the digits are cut from, one multiply-add per limb -- what the subtraction cost anyway -- and the difference
+// comes out C-form).  DESIGN.md section 5.3 has the tally and the measurements.
 //
 // Value = sum l[i] * 2^(30 i).  "C-form": limbs 0..11 in [-2^29 - 2, 2^29 + 2], limb 12 small (|value| < 2^385);
 // "L-form": one sum/difference of two C-forms (limbs 0..11 within +-(2^30 + 4)).  A product takes C x C, or L x C; a squaring
-// and a double product (f30_mul2) take C-forms only.  Every product's output is C-form with |value| < 0.53 p.
+// and a double product (f30_mul2) take C-forms only.  Every product's output is C-form with |value| < 0.53 p (+ what was
+// injected).
 // The CPU test build (KZG_FP28_CHECK) forms every column in 128 bits as well and aborts on a violated bound.
 #pragma once
 #include "fp30_consts.cuh"
@@ -99,8 +102,12 @@ KZG_HD int32_t f30_sbfe(uint32_t x) {
 
 // ---- Montgomery products ------------------------------------------------------------------------------------------------
 // r = (a*b [+ c*d]) / 2^390 mod p, C-form, |r| < 0.53 p.  Operand forms: see the header.  r may alias an operand.
-template <bool SQR, bool TWO>
-KZG_HD void f30_mul_core_c(fp30& r, const fp30& a, const fp30& b, const fp30& c, const fp30& d) {
+// INJECTION (C0, C1 != 0): r = (a*b [+ c*d]) / 2^390 + C0 * inj0 + C1 * inj1, the integer sum, with their limbs added into the
+// columns the result's digits are cut from -- so a difference like P = X2 ZZ1 / 2^390 - X1 comes out of the product ALREADY
+// C-form (centred digits), for one multiply-add per limb where a separate subtraction costs one instruction per limb too and a
+// carry pass four more.  inj0 / inj1: any limbs within +-2^31 (C- or L-form); |r| < 0.53 p + |C0 inj0| + |C1 inj1|.
+template <bool SQR, bool TWO, int C0 = 0, int C1 = 0>
+KZG_HD void f30_mul_core_c(fp30& r, const fp30& a, const fp30& b, const fp30& c, const fp30& d, const fp30& inj0, const fp30& inj1) {
   constexpr int N_ = F30_N;
   int32_t q[N_];
   int32_t a2[N_];
@@ -140,6 +147,8 @@ KZG_HD void f30_mul_core_c(fp30& r, const fp30& a, const fp30& b, const fp30& c,
     } else {
       KZG_UNROLL_FULL
       for (int i = i0; i <= i1; i++) F30_MAC(A, q[i], f30_p(k - i));
+      if (C0 != 0) F30_MAC(A, inj0.l[k - N_], C0);
+      if (C1 != 0) F30_MAC(A, inj1.l[k - N_], C1);
       if (k < 2 * N_ - 1) {
         r.l[k - N_] = f30_sbfe(F30_LO(A));  // r may alias an operand: limb k-13 of every operand was last read in column k-1
         F30_SHIFT_ROUND(A);                 // (A - digit) / 2^30
@@ -157,8 +166,9 @@ namespace kzg {
 #if defined(__HIP_DEVICE_COMPILE__)
 // Device version: every column is issued as explicit v_mad_i64_i32 chains that START from the carry of the previous column
 // (rdx_mont.cuh has the reasons).  Same arithmetic as f30_mul_core_c, which the CPU tests run.
-template <bool SQR, bool TWO, int K>
-KZG_HD void f30_column(int64_t& A, int32_t* q, fp30& r, const fp30& a, const int32_t* a2, const fp30& b, const fp30& c, const fp30& d) {
+template <bool SQR, bool TWO, int C0, int C1, int K>
+KZG_HD void f30_column(int64_t& A, int32_t* q, fp30& r, const fp30& a, const int32_t* a2, const fp30& b, const fp30& c, const fp30& d,
+                       const fp30& inj0, const fp30& inj1) {
   constexpr int N_ = F30_N;
   constexpr int i0 = (K < N_) ? 0 : K - N_ + 1;
   constexpr int i1 = (K < N_) ? K : N_ - 1;
@@ -211,20 +221,29 @@ KZG_HD void f30_column(int64_t& A, int32_t* q, fp30& r, const fp30& a, const int
     mad30_chain<1, true>::run(A, &q[K], &p0);
     A >>= 30;
   } else {
-    int32_t qs[cnt], ps[cnt];
+    constexpr int ninj = (C0 != 0 ? 1 : 0) + (C1 != 0 ? 1 : 0);  // injected limbs ride at the end of the reduction chain
+    int32_t qs[cnt + ninj], ps[cnt + ninj];
     KZG_UNROLL_FULL
     for (int t = 0; t < cnt; t++) {
       qs[t] = q[i0 + t];
       ps[t] = f30_p(K - i0 - t);
     }
-    mad30_chain<cnt, true>::run(A, qs, ps);
+    if constexpr (C0 != 0) {
+      qs[cnt] = inj0.l[K - N_];
+      ps[cnt] = C0;
+    }
+    if constexpr (C1 != 0) {
+      qs[cnt + ninj - 1] = inj1.l[K - N_];
+      ps[cnt + ninj - 1] = C1;
+    }
+    mad30_chain<cnt + ninj, true>::run(A, qs, ps);
     r.l[K - N_] = f30_sbfe((uint32_t)A);
     A = (A + (int64_t)F30_H) >> 30;
   }
-  if constexpr (K + 1 < 2 * N_ - 1) f30_column<SQR, TWO, K + 1>(A, q, r, a, a2, b, c, d);
+  if constexpr (K + 1 < 2 * N_ - 1) f30_column<SQR, TWO, C0, C1, K + 1>(A, q, r, a, a2, b, c, d, inj0, inj1);
 }
-template <bool SQR, bool TWO>
-KZG_HD void f30_mul_core(fp30& r, const fp30& a, const fp30& b, const fp30& c, const fp30& d) {
+template <bool SQR, bool TWO, int C0 = 0, int C1 = 0>
+KZG_HD void f30_mul_core(fp30& r, const fp30& a, const fp30& b, const fp30& c, const fp30& d, const fp30& inj0, const fp30& inj1) {
   constexpr int N_ = F30_N;
   int32_t q[N_];
   int32_t a2[N_];
@@ -232,20 +251,28 @@ KZG_HD void f30_mul_core(fp30& r, const fp30& a, const fp30& b, const fp30& c, c
     KZG_UNROLL_FULL
     for (int i = 0; i < N_; i++) a2[i] = a.l[i] << 1;
   }
+  int32_t top = 0;  // the injected values' limb 12 joins the carry out of column 24 (read before r.l[12] is written: r may alias)
+  if (C0 != 0) top += C0 * inj0.l[N_ - 1];
+  if (C1 != 0) top += C1 * inj1.l[N_ - 1];
   int64_t A = 0;
-  f30_column<SQR, TWO, 0>(A, q, r, a, a2, b, c, d);
-  r.l[N_ - 1] = (int32_t)A;  // column 25 holds only the carry
+  f30_column<SQR, TWO, C0, C1, 0>(A, q, r, a, a2, b, c, d, inj0, inj1);
+  r.l[N_ - 1] = (int32_t)A + top;  // column 25 holds only the carry
 }
 #else
-template <bool SQR, bool TWO>
-KZG_HD void f30_mul_core(fp30& r, const fp30& a, const fp30& b, const fp30& c, const fp30& d) {
-  f30_mul_core_c<SQR, TWO>(r, a, b, c, d);
+template <bool SQR, bool TWO, int C0 = 0, int C1 = 0>
+KZG_HD void f30_mul_core(fp30& r, const fp30& a, const fp30& b, const fp30& c, const fp30& d, const fp30& inj0, const fp30& inj1) {
+  f30_mul_core_c<SQR, TWO, C0, C1>(r, a, b, c, d, inj0, inj1);
 }
 #endif
 
-KZG_HD void f30_mul(fp30& r, const fp30& a, const fp30& b) { f30_mul_core<false, false>(r, a, b, a, b); }   // C x C or L x C
-KZG_HD void f30_sqr(fp30& r, const fp30& a) { f30_mul_core<true, false>(r, a, a, a, a); }                   // C
-KZG_HD void f30_mul2(fp30& r, const fp30& a, const fp30& b, const fp30& c, const fp30& d) { f30_mul_core<false, true>(r, a, b, c, d); }  // all C
+KZG_HD void f30_mul(fp30& r, const fp30& a, const fp30& b) { f30_mul_core<false, false>(r, a, b, a, b, a, a); }   // C x C or L x C
+KZG_HD void f30_sqr(fp30& r, const fp30& a) { f30_mul_core<true, false>(r, a, a, a, a, a, a); }                   // C
+KZG_HD void f30_mul2(fp30& r, const fp30& a, const fp30& b, const fp30& c, const fp30& d) { f30_mul_core<false, true>(r, a, b, c, d, a, a); }  // all C
+// with injection (f30_mul_core_c's header): r = a b / 2^390 + C0 i0, and r = a^2 / 2^390 + C0 i0 + C1 i1, C-form
+template <int C0>
+KZG_HD void f30_mul_inj(fp30& r, const fp30& a, const fp30& b, const fp30& i0) { f30_mul_core<false, false, C0, 0>(r, a, b, a, b, i0, i0); }
+template <int C0, int C1>
+KZG_HD void f30_sqr_inj2(fp30& r, const fp30& a, const fp30& inj0, const fp30& inj1) { f30_mul_core<true, false, C0, C1>(r, a, a, a, a, inj0, inj1); }
 
 // ---- limb-wise operations ---------------------------------------------------------------------------------------------------
 KZG_HD void f30_sub(fp30& r, const fp30& a, const fp30& b) {
@@ -421,16 +448,24 @@ KZG_HD void f30_load_entry(fp30& x, fp30& y, const uint32_t* wx, const uint32_t*
 }
 
 // ---- XYZZ accumulator ---------------------------------------------------------------------------------------------------------
-// Invariant between additions: every coordinate C-form, |value| < 3 p.
+// The accumulator stands for the point s * (x / zz, y / zzz) with s = -1 when yneg is set: the fast addition leaves the NEGATED
+// sum behind (its last product is then a sum of two products instead of a difference, which would need a negated operand) and
+// flips the flag; an entry to add is therefore loaded with the sign xyzz30_entry_neg() gives.  Doubling and the complete addition
+// work on the raw coordinates and keep the flag.
+// Invariant between additions: y, zz, zzz C-form, |value| < 0.53 p; x L-form (a sum of two C-forms), |value| < 3.3 p.
 struct g1_xyzz30 {
   fp30 x, y, zz, zzz;
   uint32_t inf;
+  uint32_t yneg;
 };
 KZG_HD void xyzz30_set_inf(g1_xyzz30& p) {
   KZG_UNROLL_FULL
   for (int i = 0; i < F30_N; i++) p.x.l[i] = p.y.l[i] = p.zz.l[i] = p.zzz.l[i] = 0;
   p.inf = 1;
+  p.yneg = 0;
 }
+// the sign to load a table entry with (f30_load_entry's neg) so that the raw coordinates add it with the accumulator's sign
+KZG_HD bool xyzz30_entry_neg(const g1_xyzz30& p, bool neg) { return neg != (p.yneg != 0u); }
 
 // p = 2 * (x, y), (x, y) finite, both C-form   (mdbl-2008-s-1, a = 0)
 KZG_HD void xyzz30_mdbl(g1_xyzz30& p, const fp30& x, const fp30& y) {
@@ -463,32 +498,27 @@ KZG_HD void xyzz30_mdbl(g1_xyzz30& p, const fp30& x, const fp30& y) {
   p.inf = 0;
 }
 
-// p += (x2, y2) for a FINITE accumulator p and the generic case; x2, y2 C-form (a table entry, y2 possibly negated).
-// Returns false -- with p untouched -- when x2 * ZZ1 == X1 (mod p) may hold (P + P or P + (-P); 15 * 2^-30 of all calls are
-// false alarms); the caller then runs xyzz30_madd_complete.  madd-2008-s with Y3 = (R (Q - X3) - Y1 PPP) / 2^390 as ONE
-// reduction: 6 products + 2 squarings + 1 double product, four carry passes.
+// p += +-(x2, .) for a FINITE accumulator p and the generic case; x2, y2 C-form: a table entry, y2 with the sign
+// xyzz30_entry_neg() asked for.  Returns false -- with p untouched -- when x2 * ZZ1 == X1 (mod p) may hold (P + P or P + (-P);
+// 15 * 2^-30 of all calls are false alarms); the caller then runs xyzz30_madd_complete.
+// madd-2008-s, 6 products + 2 squarings + 1 double product and NO carry pass: the three differences are injected into the
+// products that feed them (f30_mul_inj) and come out C-form --
+//   P = X2 ZZ1 - X1,  R = Y2 ZZZ1 - Y1,  V = R^2 - PPP - 3 Q = X3 - Q;   X3 = V + Q (L-form: only ever a product's first operand
+//   or an injected value);  -Y3 = R V + Y1 PPP as ONE reduction: the raw result is the negated sum, the flag says so.
 KZG_HD bool xyzz30_madd_fast(g1_xyzz30& p, const fp30& x2, const fp30& y2) {
-  fp30 u2, r, pp, ppp;
-  f30_mul(u2, x2, p.zz);       // U2
-  f30_mul(r, y2, p.zzz);       // S2
-  f30_sub(u2, u2, p.x);        // P = U2 - X1 (L-form)
-  f30_carry(u2);               // C-form: it is squared
-  if (f30_maybe_zero(u2)) return false;
-  f30_sub(r, r, p.y);          // R = S2 - Y1
-  f30_carry(r);
-  f30_sqr(pp, u2);             // PP
-  f30_mul(ppp, u2, pp);        // PPP
-  f30_mul(p.zz, p.zz, pp);     // ZZ3
-  f30_mul(p.zzz, p.zzz, ppp);  // ZZZ3
-  f30_mul(pp, p.x, pp);        // Q = X1 PP (X1 and PP are dead from here)
-  f30_sqr(p.x, r);             // R^2
-  KZG_UNROLL_FULL
-  for (int i = 0; i < F30_N; i++) p.x.l[i] = p.x.l[i] - ppp.l[i] - 2 * pp.l[i];  // X3 = R^2 - PPP - 2Q: limbs in [-2^31 + 3, 2^31 - 1]
-  f30_carry<true>(p.x);
-  f30_sub(pp, pp, p.x);        // Q - X3
-  f30_carry(pp);
-  f30_neg(p.y, p.y);           // -Y1
-  f30_mul2(p.y, r, pp, p.y, ppp);  // Y3
+  fp30 u, r, pp, ppp, v;
+  f30_mul_inj<-1>(u, x2, p.zz, p.x);        // P (|P| < 3.9 p)
+  if (f30_maybe_zero(u)) return false;
+  f30_mul_inj<-1>(r, y2, p.zzz, p.y);       // R
+  f30_sqr(pp, u);                           // PP
+  f30_mul(ppp, u, pp);                      // PPP
+  f30_mul(p.zz, p.zz, pp);                  // ZZ3
+  f30_mul(p.zzz, p.zzz, ppp);               // ZZZ3
+  f30_mul(pp, p.x, pp);                     // Q = X1 PP (L x C; X1 and PP are dead from here)
+  f30_sqr_inj2<-1, -3>(v, r, ppp, pp);      // V = X3 - Q (|V| < 2.7 p)
+  f30_add(p.x, v, pp);                      // X3
+  f30_mul2(p.y, r, v, p.y, ppp);            // -Y3
+  p.yneg ^= 1u;
   return true;
 }
 
@@ -497,13 +527,14 @@ KZG_HD_NOINLINE void xyzz30_madd_complete(g1_xyzz30& p, const fp30& x2, const fp
   if (p.inf) {
     const fp30 one = f30_one();
     p.x = x2;
-    p.y = y2;
+    p.y = y2;  // with the sign the flag asked for
     p.zz = one;
     p.zzz = one;
     p.inf = 0;
     return;
   }
   if (xyzz30_madd_fast(p, x2, y2)) return;
+  f30_carry(p.x);  // L-form -> C-form: the formulas below are the plain ones (raw coordinates, the sign flag stays)
   fp30 u2, r;
   f30_mul(u2, x2, p.zz);
   f30_mul(r, y2, p.zzz);
@@ -543,6 +574,7 @@ KZG_HD void xyzz30_dbl_inl(g1_xyzz30& p) {
     return;
   }
   fp30 u, v, w, s, m, t, x3;
+  f30_carry(p.x);  // L-form -> C-form: it is squared
   f30_add(u, p.y, p.y);
   f30_carry(u);
   f30_sqr(v, u);
@@ -575,6 +607,7 @@ KZG_HD void xyzz30_to_xyzz(g1_xyzz& r, const g1_xyzz30& p) {
   }
   f30_to_fp(r.x, p.x);
   f30_to_fp(r.y, p.y);
+  if (p.yneg) fp_neg(r.y, r.y);
   f30_to_fp(r.zz, p.zz);
   f30_to_fp(r.zzz, p.zzz);
 }

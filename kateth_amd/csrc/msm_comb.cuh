@@ -230,7 +230,7 @@ static __global__ __launch_bounds__(64, 2) void k_msm_comb30(const uint64_t* __r
   for (uint32_t t = 0; t < total; t++) {
     if (g.fair) issue_fair_tick_low(g.fair);
     fp30 cx, cy;
-    f30_load_entry(cx, cy, nx.v, ny.v, nneg);
+    f30_load_entry(cx, cy, nx.v, ny.v, xyzz30_entry_neg(acc, nneg));
     const bool cneg = nneg, cdbl = ndbl;
     const uint32_t cidx = nidx;
     if (t + 1u < total) {
@@ -253,7 +253,7 @@ static __global__ __launch_bounds__(64, 2) void k_msm_comb30(const uint64_t* __r
       fp_t rx, ry;
       load_affine96(rx, ry, tgrp, cidx);
       fp30 sx, sy;  // separate objects: the call takes their address
-      f30_load_entry(sx, sy, rx.v, ry.v, cneg);
+      f30_load_entry(sx, sy, rx.v, ry.v, xyzz30_entry_neg(tmp, cneg));
       xyzz30_madd_complete(tmp, sx, sy);
       acc = tmp;
     }

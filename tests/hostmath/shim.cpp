@@ -572,6 +572,8 @@ extern "C" void hm_f30_op(int op, int32_t* out13, const int32_t* a13, const int3
       break;
     }
     case 8: r.l[0] = f30_is_zero(a) ? 1 : 0; break;
+    case 10: f30_mul_inj<-1>(r, a, b, c); break;          // a b / 2^390 - c
+    case 11: f30_sqr_inj2<-1, -3>(r, a, c, d); break;     // a^2 / 2^390 - c - 3 d
     case 9: {
       fp_t v;
       for (int i = 0; i < 12; i++) v.v[i] = (uint32_t)a13[i];
@@ -601,7 +603,7 @@ extern "C" int32_t hm_g1_sum30(uint8_t* out48, const uint8_t* pts48, const uint8
     fp_to_packed30(wx, x);
     fp_to_packed30(wy, y);
     fp30 x2, y2;
-    f30_load_entry(x2, y2, wx, wy, signs[i] != 0);
+    f30_load_entry(x2, y2, wx, wy, xyzz30_entry_neg(acc, signs[i] != 0));
     if (force_complete || acc.inf || !xyzz30_madd_fast(acc, x2, y2)) {
       g_fp30_slow_calls++;
       xyzz30_madd_complete(acc, x2, y2);

@@ -417,6 +417,28 @@ def test_fp30_field_ops(hm):
             ok_product(_f30(hm, 0, lazy, b), _v30(lazy) * _v30(b))
             ok_product(_f30(hm, 2, a, b, b, a), 2 * _v30(a) * _v30(b))
             ok_product(_f30(hm, 2, a, b, [-t for t in b], a), 0)
+    # products with injected differences (the fast addition's P, R and V): the exact integer a b / 2^390 + k c [+ k' d], digits centred
+    def ok_injected(r, want_times_R, bound):
+        v = _v30(r)
+        assert (v * Rm - want_times_R) % P == 0
+        assert abs(v) < bound * P and all(-F30_H <= t < F30_H for t in r[:12]) and abs(r[12]) < 1 << 25
+
+    for _ in range(200):
+        x, y, z, w = (rnd.randrange(-3 * P, 3 * P) for _ in range(4))
+        a, b, c, d = _c30(x), _c30(y), _c30(z), _c30(w)
+        lazy_c = [p_ + q_ for p_, q_ in zip(c, d)]  # an L-form injected value
+        ok_injected(_f30(hm, 10, a, b, c), x * y - z * Rm, 3.6)
+        ok_injected(_f30(hm, 10, a, b, lazy_c), x * y - (z + w) * Rm, 6.6)
+        ok_injected(_f30(hm, 11, a, a, c, d), x * x - (z + 3 * w) * Rm, 12.6)
+        got = _f30(hm, 10, a, b, c)
+        plain = _f30(hm, 0, a, b)
+        assert _v30(got) == _v30(plain) - z  # the integer itself, not only its residue
+    for sa in (1, -1):
+        for sc in (1, -1):
+            a = [sa * (F30_H + 2)] * 12 + [sa * (1 << 21)]
+            c = [sc * (2 * F30_H + 4)] * 12 + [sc * (1 << 22)]
+            ok_injected(_f30(hm, 10, a, a, c), _v30(a) ** 2 - _v30(c) * Rm, 40)
+            ok_injected(_f30(hm, 11, a, a, c, c), _v30(a) ** 2 - 4 * _v30(c) * Rm, 160)
     # carry passes: value preserved, limbs back in range
     for _ in range(100):
         l = [rnd.randrange(-(1 << 31) + (1 << 29) + 1, (1 << 31) - (1 << 29)) for _ in range(12)] + [rnd.randrange(-(1 << 24), 1 << 24)]

@@ -78,12 +78,12 @@ __global__ __launch_bounds__(64, 2) void k_madd30(uint32_t* out, const fp_t* pts
     const bool neg = ((it * 0x9e3779b9u + t) >> 13) & 1u;
     fp_t x = pts[2 * k], y = pts[2 * k + 1];  // packed 30-bit digits: 12 words each
     fp30 x2, y2;
-    f30_load_entry(x2, y2, x.v, y.v, neg);
+    f30_load_entry(x2, y2, x.v, y.v, xyzz30_entry_neg(acc, neg));
     if (acc.inf || !xyzz30_madd_fast(acc, x2, y2)) {
       g1_xyzz30 tmp = acc;
       fp_t rx = pts[2 * k], ry = pts[2 * k + 1];
       fp30 sx, sy;
-      f30_load_entry(sx, sy, rx.v, ry.v, neg);
+      f30_load_entry(sx, sy, rx.v, ry.v, xyzz30_entry_neg(tmp, neg));
       xyzz30_madd_complete(tmp, sx, sy);
       acc = tmp;
     }
@@ -112,11 +112,11 @@ __global__ __launch_bounds__(64, 2) void k_madd30_unpacked(uint32_t* out, const 
     const uint32_t k = (it * 7u + t) % npts;
     const bool neg = ((it * 0x9e3779b9u + t) >> 13) & 1u;
     fp30 x2, y2;
-    load(x2, y2, k, neg);
+    load(x2, y2, k, xyzz30_entry_neg(acc, neg));
     if (acc.inf || !xyzz30_madd_fast(acc, x2, y2)) {
       g1_xyzz30 tmp = acc;
       fp30 sx, sy;
-      load(sx, sy, k, neg);
+      load(sx, sy, k, xyzz30_entry_neg(tmp, neg));
       xyzz30_madd_complete(tmp, sx, sy);
       acc = tmp;
     }
