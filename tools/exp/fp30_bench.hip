@@ -66,7 +66,8 @@ __global__ __launch_bounds__(64, 2) void k_madd28(uint32_t* out, const fp_t* pts
     }
   }
   g1_xyzz r; xyzz28_to_xyzz(r, acc);
-  uint32_t x = 0; for (int q = 0; q < 12; q++) x ^= r.x.v[q] ^ r.y.v[q] ^ r.zz.v[q];
+  fp_t yz; fp_mul(yz, r.y, r.zzz);  // (X, Y, ZZ, ZZZ) and (X, -Y, ZZ, -ZZZ) are the same point: the fp30 adder may hold either
+  uint32_t x = 0; for (int q = 0; q < 12; q++) x ^= r.x.v[q] ^ yz.v[q] ^ r.zz.v[q];
   out[t] = x;
 }
 __global__ __launch_bounds__(64, 2) void k_madd30(uint32_t* out, const fp_t* pts, uint32_t npts, uint32_t iters) {
@@ -89,7 +90,8 @@ __global__ __launch_bounds__(64, 2) void k_madd30(uint32_t* out, const fp_t* pts
     }
   }
   g1_xyzz r; xyzz30_to_xyzz(r, acc);
-  uint32_t x = 0; for (int q = 0; q < 12; q++) x ^= r.x.v[q] ^ r.y.v[q] ^ r.zz.v[q];
+  fp_t yz; fp_mul(yz, r.y, r.zzz);  // (X, Y, ZZ, ZZZ) and (X, -Y, ZZ, -ZZZ) are the same point: the fp30 adder may hold either
+  uint32_t x = 0; for (int q = 0; q < 12; q++) x ^= r.x.v[q] ^ yz.v[q] ^ r.zz.v[q];
   out[t] = x;
 }
 
@@ -122,7 +124,8 @@ __global__ __launch_bounds__(64, 2) void k_madd30_unpacked(uint32_t* out, const 
     }
   }
   g1_xyzz r; xyzz30_to_xyzz(r, acc);
-  uint32_t x = 0; for (int q = 0; q < 12; q++) x ^= r.x.v[q] ^ r.y.v[q] ^ r.zz.v[q];
+  fp_t yz; fp_mul(yz, r.y, r.zzz);  // (X, Y, ZZ, ZZZ) and (X, -Y, ZZ, -ZZZ) are the same point: the fp30 adder may hold either
+  uint32_t x = 0; for (int q = 0; q < 12; q++) x ^= r.x.v[q] ^ yz.v[q] ^ r.zz.v[q];
   out[t] = x;
 }
 
