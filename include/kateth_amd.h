@@ -73,6 +73,9 @@ extern "C" {
  * at infinity (repeated / opposite points).  The reference would load it; no ceremony output or set of independent points
  * is affected.  Rejected at creation instead of producing wrong commitments. */
 #define KZG_FAIL_SETUP_UNSUPPORTED (-6)
+/* The host side of a call failed: out of host memory, or a C++ exception nobody expected (kzg_last_error() has its text).
+ * Every int32_t entry point catches what its body throws -- nothing unwinds into the caller's frames. */
+#define KZG_FAIL_HOST (-7)
 
 typedef struct kzg_ctx kzg_ctx;
 
@@ -359,6 +362,9 @@ int32_t kzg_clock_probe_read(const kzg_ctx* ctx, double* ghz_mean, double* ghz_m
  * with the 32-bit-limb result.  Expected: 0.
  */
 int32_t kzg_selftest_field_mul(const kzg_ctx* ctx, uint64_t lanes, uint64_t iters, uint64_t* mismatches);
+/* Test hook for the guard described at KZG_FAIL_HOST: throws std::bad_alloc (kind 0), std::runtime_error (1) or an int (2) inside
+ * an entry point; expected return KZG_FAIL_HOST with the exception's text in kzg_last_error().  Touches no GPU. */
+int32_t kzg_selftest_exception_guard(int32_t kind);
 
 /*
  * Kernel timing for bench.py's `roofline` object: between begin and end every

@@ -4,6 +4,9 @@
 // verification, runs the single two-pairing check per call -- pairing.hpp).
 // There is NO CPU compute fallback: without a HIP device every entry point
 // fails with KZG_FAIL_NO_DEVICE / KZG_FAIL_HIP.
+#include <new>
+#include <stdexcept>
+
 #include "engine_internal.hpp"
 #include "msm_comb.cuh"            // this translation unit owns the fixed-base MSM kernels,
 #include "msm_reduce_kernels.cuh"  // the lane-sum trees / encoder, and their launchers
@@ -103,6 +106,33 @@ int32_t fail(int32_t code, const std::string& msg) {
   // must not be found again by the launch check of this thread's NEXT, unrelated call
   if (code == KZG_FAIL_HIP) (void)hipGetLastError();
   return code;
+}
+int32_t abi_exception() noexcept {
+  const char* what = "unexpected C++ exception";
+  char text[160];
+  try {
+    throw;
+  } catch (const std::bad_alloc&) {
+    what = "out of host memory (std::bad_alloc)";
+  } catch (const std::exception& e) {
+    snprintf(text, sizeof text, "%s", e.what());
+    what = text;
+  } catch (...) {
+  }
+  try {
+    g_last_error = std::string("host failure: ") + what;
+  } catch (...) {  // no memory for the message either: keep whatever text is there
+  }
+  g_last_detail = 0;
+  return KZG_FAIL_HOST;
+}
+extern "C" int32_t kzg_selftest_exception_guard(int32_t kind) try {
+  if (kind == 0) throw std::bad_alloc();
+  if (kind == 1) throw std::runtime_error("selftest: a runtime_error inside an entry point");
+  if (kind == 2) throw 42;
+  return 0;
+} catch (...) {
+  return abi_exception();
 }
 // a failure caused by a rejected input: `detail` is the KZG_ERR_* code of that input
 static int32_t fail_detail(int32_t code, int32_t detail, const std::string& msg) {
@@ -263,26 +293,30 @@ extern "C" uint64_t kzg_ctx_adds_per_blob(const kzg_ctx* ctx) {
   return ctx->use_comb ? (uint64_t)256u * 64u * ctx->comb.nb : ctx->msm_override->adds_per_blob;
 }
 
-extern "C" int32_t kzg_profile_begin(const kzg_ctx* ctx) {
+extern "C" int32_t kzg_profile_begin(const kzg_ctx* ctx) try {
   if (!ctx) return fail(KZG_FAIL_ARGUMENT, "null argument");
   std::lock_guard<std::mutex> guard(ctx->prof_lock);
   ctx->prof_used = 0;
   ctx->profiling.store(true);
   return 0;
+} catch (...) {
+  return abi_exception();
 }
 
 static const char* const PROF_NAMES[PROF_KINDS] = {"k_msm_comb30", "k_challenge*", "k_eval_frac", "k_g1_decompress", "k_poly",
                                                     "k_var_* (two lincombs)", "k_msm_reduce* + k_g1_compress", "k_comb_transpose"};
 
 extern "C" const char* kzg_ctx_msm_kernel_name(const kzg_ctx* ctx) { return (ctx && ctx->msm_override) ? ctx->msm_override->kernel_name : "k_msm_comb30"; }
-extern "C" int32_t kzg_ctx_plane_groups(const kzg_ctx* ctx) {
+extern "C" int32_t kzg_ctx_plane_groups(const kzg_ctx* ctx) try {
   if (!ctx || !ctx->use_comb) return 0;
   std::lock_guard<std::mutex> guard(ctx->lock);
   return (int32_t)ctx->comb.G;
+} catch (...) {
+  return abi_exception();
 }
 extern "C" const char* kzg_profile_kind_name(int32_t kind) { return (kind >= 0 && kind < PROF_KINDS) ? PROF_NAMES[kind] : ""; }
 
-extern "C" int32_t kzg_profile_end_kinds(const kzg_ctx* ctx, double* ms_out, uint64_t* launches) {
+extern "C" int32_t kzg_profile_end_kinds(const kzg_ctx* ctx, double* ms_out, uint64_t* launches) try {
   if (!ctx || !ms_out || !launches) return fail(KZG_FAIL_ARGUMENT, "null argument");
   std::lock_guard<std::mutex> guard(ctx->prof_lock);
   HIP_TRY(hipSetDevice(ctx->device));
@@ -305,9 +339,11 @@ extern "C" int32_t kzg_profile_end_kinds(const kzg_ctx* ctx, double* ms_out, uin
   }
   ctx->prof_used = 0;
   return 0;
+} catch (...) {
+  return abi_exception();
 }
 
-extern "C" int32_t kzg_profile_end(const kzg_ctx* ctx, double* msm_ms_total, uint64_t* msm_launches) {
+extern "C" int32_t kzg_profile_end(const kzg_ctx* ctx, double* msm_ms_total, uint64_t* msm_launches) try {
   if (!ctx || !msm_ms_total || !msm_launches) return fail(KZG_FAIL_ARGUMENT, "null argument");
   double ms[PROF_KINDS];
   uint64_t cnt[PROF_KINDS];
@@ -316,6 +352,8 @@ extern "C" int32_t kzg_profile_end(const kzg_ctx* ctx, double* msm_ms_total, uin
   *msm_ms_total = ms[PROF_MSM_FIXED];
   *msm_launches = cnt[PROF_MSM_FIXED];
   return 0;
+} catch (...) {
+  return abi_exception();
 }
 
 // returns the event pair to record around the next launch of class `kind` (or nullptrs)
@@ -363,10 +401,12 @@ EnvKnobs read_env_knobs() {
 }
 
 // the table fields may be swapped by the background build (KZG_CFG_BUILD_ASYNC): read under the lock
-extern "C" int32_t kzg_ctx_window_bits(const kzg_ctx* ctx) {
+extern "C" int32_t kzg_ctx_window_bits(const kzg_ctx* ctx) try {
   if (!ctx) return 0;
   std::lock_guard<std::mutex> guard(ctx->lock);
   return (int32_t)ctx->window_class;
+} catch (...) {
+  return abi_exception();
 }
 extern "C" uint64_t kzg_ctx_table_bytes(const kzg_ctx* ctx) {
   if (!ctx) return 0;
@@ -383,9 +423,11 @@ extern "C" const kzg_ctx* kzg_ctx_member(const kzg_ctx* ctx, uint32_t k) {
   if (!ctx || k > ctx->peers.size()) return nullptr;
   return k == 0 ? ctx : ctx->peers[k - 1];
 }
-extern "C" int32_t kzg_ctx_member_device(const kzg_ctx* ctx, uint32_t k) {
+extern "C" int32_t kzg_ctx_member_device(const kzg_ctx* ctx, uint32_t k) try {
   const kzg_ctx* m = kzg_ctx_member(ctx, k);
   return m ? m->device : -1;
+} catch (...) {
+  return abi_exception();
 }
 
 extern "C" void kzg_ctx_destroy(kzg_ctx* ctx) {
@@ -763,7 +805,7 @@ static void build_thread_main(kzg_ctx* ctx, std::vector<TableChoice> ladder, boo
   ctx->build_cv.notify_all();
 }
 
-extern "C" int32_t kzg_ctx_ready(const kzg_ctx* ctx) {
+extern "C" int32_t kzg_ctx_ready(const kzg_ctx* ctx) try {
   if (!ctx) return 0;
   {
     std::lock_guard<std::mutex> guard(ctx->build_mu);
@@ -772,8 +814,10 @@ extern "C" int32_t kzg_ctx_ready(const kzg_ctx* ctx) {
   for (const kzg_ctx* p : ctx->peers)
     if (!kzg_ctx_ready(p)) return 0;
   return 1;
+} catch (...) {
+  return abi_exception();
 }
-extern "C" int32_t kzg_ctx_wait_ready(const kzg_ctx* ctx) {
+extern "C" int32_t kzg_ctx_wait_ready(const kzg_ctx* ctx) try {
   if (!ctx) return fail(KZG_FAIL_ARGUMENT, "null argument");
   int32_t rc = 0;
   {
@@ -787,13 +831,17 @@ extern "C" int32_t kzg_ctx_wait_ready(const kzg_ctx* ctx) {
     if (rc == 0) rc = rp;
   }
   return rc;
+} catch (...) {
+  return abi_exception();
 }
 
-extern "C" int32_t kzg_device_count(void) {
+extern "C" int32_t kzg_device_count(void) try {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(KZG_FAIL_NO_DEVICE, "no HIP device visible: the kateth_amd engine has no CPU fallback");
   return ndev;
+} catch (...) {
+  return abi_exception();
 }
 
 // A single-device context on `device` (cfg's device / devices / ndev are not read here).
@@ -898,7 +946,7 @@ static int32_t cfg_check(const kzg_config* cfg) {
   return 0;
 }
 
-extern "C" int32_t kzg_ctx_create(const uint8_t* g1_lagrange, const uint8_t* g2_monomial, const kzg_config* cfg, kzg_ctx** out) {
+extern "C" int32_t kzg_ctx_create(const uint8_t* g1_lagrange, const uint8_t* g2_monomial, const kzg_config* cfg, kzg_ctx** out) try {
   if (!g1_lagrange || !g2_monomial || !out) return fail(KZG_FAIL_ARGUMENT, "null argument");
   *out = nullptr;
   if (int32_t rcc = cfg_check(cfg)) return rcc;
@@ -908,10 +956,12 @@ extern "C" int32_t kzg_ctx_create(const uint8_t* g1_lagrange, const uint8_t* g2_
   const int device = cfg ? cfg->device : 0;
   if (device < 0 || device >= ndev) return fail(KZG_FAIL_ARGUMENT, "device ordinal out of range");
   return ctx_create_single(g1_lagrange, g2_monomial, cfg, device, out);
+} catch (...) {
+  return abi_exception();
 }
 
 extern "C" int32_t kzg_ctx_create_multi(const uint8_t* g1_lagrange, const uint8_t* g2_monomial, const int32_t* devices, uint32_t ndev,
-                                        const kzg_config* cfg, kzg_ctx** out) {
+                                        const kzg_config* cfg, kzg_ctx** out) try {
   kzg_config c = KZG_CONFIG_INIT;
   if (int32_t rcc = cfg_check(cfg)) return rcc;
   if (cfg) c = *cfg;
@@ -919,6 +969,8 @@ extern "C" int32_t kzg_ctx_create_multi(const uint8_t* g1_lagrange, const uint8_
   c.ndev = ndev;
   if (ndev == 0) return fail(KZG_FAIL_ARGUMENT, "kzg_ctx_create_multi: ndev must not be 0 (KZG_ALL_DEVICES = every visible device)");
   return kzg_ctx_create(g1_lagrange, g2_monomial, &c, out);
+} catch (...) {
+  return abi_exception();
 }
 
 // ---------------------------------------------------------------------------
@@ -1016,7 +1068,7 @@ static int32_t commit_dev_locked(const kzg_ctx* ctx, const void* d_blobs, uint64
 }
 
 extern "C" int32_t kzg_blob_to_commitment_batch_dev(const kzg_ctx* ctx, const void* d_blobs, uint64_t n, void* d_out48, void* d_status,
-                                                    void* hip_stream) {
+                                                    void* hip_stream) try {
   if (!ctx || (n && (!d_blobs || !d_out48 || !d_status))) return fail(KZG_FAIL_ARGUMENT, "null argument");
   HIP_TRY(hipSetDevice(ctx->device));
   std::lock_guard<std::mutex> guard(ctx->lock);
@@ -1026,6 +1078,8 @@ extern "C" int32_t kzg_blob_to_commitment_batch_dev(const kzg_ctx* ctx, const vo
   if (rc == 0) rc = commit_dev_locked(ctx, d_blobs, n, d_out48, nullptr, reinterpret_cast<int32_t*>(d_status), st);
   if (rc == 0) rc = ws.end();
   return rc;
+} catch (...) {
+  return abi_exception();
 }
 
 // Host-buffer entry point.  The blobs cross PCIe in chunks through two device staging buffers: while the MSM of chunk k runs
@@ -1156,27 +1210,33 @@ int32_t commit_host(const kzg_ctx* ctx, const uint8_t* blobs, uint64_t n, uint8_
   return rc;
 }
 
-extern "C" int32_t kzg_blob_to_commitment_batch(const kzg_ctx* ctx, const uint8_t* blobs, uint64_t n, uint8_t* out48, int32_t* status) {
+extern "C" int32_t kzg_blob_to_commitment_batch(const kzg_ctx* ctx, const uint8_t* blobs, uint64_t n, uint8_t* out48, int32_t* status) try {
   if (n && !out48) return fail(KZG_FAIL_ARGUMENT, "null argument");
   if (is_group(ctx)) return multi_commit(ctx, blobs, n, out48, nullptr, status);
   return commit_host(ctx, blobs, n, out48, nullptr, status);
+} catch (...) {
+  return abi_exception();
 }
-extern "C" int32_t kzg_blob_to_commitment_batch_affine(const kzg_ctx* ctx, const uint8_t* blobs, uint64_t n, uint8_t* out_affine96, int32_t* status) {
+extern "C" int32_t kzg_blob_to_commitment_batch_affine(const kzg_ctx* ctx, const uint8_t* blobs, uint64_t n, uint8_t* out_affine96, int32_t* status) try {
   if (n && !out_affine96) return fail(KZG_FAIL_ARGUMENT, "null argument");
   if (is_group(ctx)) return multi_commit(ctx, blobs, n, nullptr, out_affine96, status);
   return commit_host(ctx, blobs, n, nullptr, out_affine96, status);
+} catch (...) {
+  return abi_exception();
 }
 
 // ---------------------------------------------------------------------------
 // synthetic blobs + micro-benchmarks
 // ---------------------------------------------------------------------------
-extern "C" int32_t kzg_synth_blobs_dev(const kzg_ctx* ctx, uint64_t seed, uint64_t first_index, uint64_t n, void* d_blobs, void* hip_stream) {
+extern "C" int32_t kzg_synth_blobs_dev(const kzg_ctx* ctx, uint64_t seed, uint64_t first_index, uint64_t n, void* d_blobs, void* hip_stream) try {
   if (!ctx || (n && !d_blobs)) return fail(KZG_FAIL_ARGUMENT, "null argument");
   if (n == 0) return 0;
   HIP_TRY(hipSetDevice(ctx->device));
   launch_synth_blobs(reinterpret_cast<hipStream_t>(hip_stream), seed, first_index, n, reinterpret_cast<uint8_t*>(d_blobs));
   HIP_TRY(hipGetLastError());
   return 0;
+} catch (...) {
+  return abi_exception();
 }
 
 // a chain of dependent products with the multiply of the radix-2^28 MSM kernel (fp28.cuh)
@@ -1201,7 +1261,7 @@ __global__ __launch_bounds__(256) void k_microbench_fp28_mul(uint32_t* out, uint
   out[t] = x;
 }
 
-extern "C" int32_t kzg_microbench_fp_mul(const kzg_ctx* ctx, uint64_t lanes, uint64_t iters, float* ms) {
+extern "C" int32_t kzg_microbench_fp_mul(const kzg_ctx* ctx, uint64_t lanes, uint64_t iters, float* ms) try {
   if (!ctx || !ms || lanes == 0) return fail(KZG_FAIL_ARGUMENT, "null argument");
   HIP_TRY(hipSetDevice(ctx->device));
   lanes = align_up(lanes, 256);
@@ -1221,6 +1281,8 @@ extern "C" int32_t kzg_microbench_fp_mul(const kzg_ctx* ctx, uint64_t lanes, uin
   (void)hipEventDestroy(e1);
   (void)hipFree(d_out);
   return 0;
+} catch (...) {
+  return abi_exception();
 }
 
 // ISSUE interval of the instruction the hot loops are made of (v_mad_u64_u32: 76-80 % of the MSM, evaluation and decoding
@@ -1259,7 +1321,7 @@ __global__ __launch_bounds__(1024) void k_microbench_valu_issue(uint32_t* out, u
   }
 }
 
-extern "C" int32_t kzg_microbench_valu_issue(const kzg_ctx* ctx, uint32_t waves_per_simd, uint32_t iters, double* cycles_per_inst, double* clock_ghz) {
+extern "C" int32_t kzg_microbench_valu_issue(const kzg_ctx* ctx, uint32_t waves_per_simd, uint32_t iters, double* cycles_per_inst, double* clock_ghz) try {
   if (!ctx || !cycles_per_inst || !clock_ghz || waves_per_simd < 1 || waves_per_simd > 4 || iters == 0) return fail(KZG_FAIL_ARGUMENT, "bad argument");
   HIP_TRY(hipSetDevice(ctx->device));
   const uint32_t blocks = ctx->num_cus, threads = 256 * waves_per_simd;
@@ -1289,6 +1351,8 @@ extern "C" int32_t kzg_microbench_valu_issue(const kzg_ctx* ctx, uint32_t waves_
   *cycles_per_inst = cyc[cyc.size() / 2];  // median over the waves
   *clock_ghz = ghz.empty() ? 0.0 : ghz[ghz.size() / 2];
   return 0;
+} catch (...) {
+  return abi_exception();
 }
 
 // Shader clock UNDER A REAL WORKLOAD: eight single-wave workgroups (dealt round-robin over the XCDs) that do nothing but
@@ -1309,7 +1373,7 @@ __global__ __launch_bounds__(64) void k_clock_probe(unsigned long long* out, uns
   out[2 * blockIdx.x + 1] = r1 - r0;
 }
 constexpr int KZG_CLOCK_PROBES = 8;
-extern "C" int32_t kzg_clock_probe_launch(const kzg_ctx* ctx, uint32_t duration_us) {
+extern "C" int32_t kzg_clock_probe_launch(const kzg_ctx* ctx, uint32_t duration_us) try {
   if (!ctx || duration_us == 0 || duration_us > 10000000u) return fail(KZG_FAIL_ARGUMENT, "bad argument");
   HIP_TRY(hipSetDevice(ctx->device));
   std::lock_guard<std::mutex> guard(ctx->prof_lock);
@@ -1321,8 +1385,10 @@ extern "C" int32_t kzg_clock_probe_launch(const kzg_ctx* ctx, uint32_t duration_
   hipLaunchKernelGGL(k_clock_probe, dim3(KZG_CLOCK_PROBES), dim3(64), 0, ctx->probe_stream, ctx->d_clock_probe, (unsigned long long)duration_us * 100ull);
   HIP_TRY(hipGetLastError());
   return 0;
+} catch (...) {
+  return abi_exception();
 }
-extern "C" int32_t kzg_clock_probe_read(const kzg_ctx* ctx, double* ghz_mean, double* ghz_min, double* ghz_max) {
+extern "C" int32_t kzg_clock_probe_read(const kzg_ctx* ctx, double* ghz_mean, double* ghz_min, double* ghz_max) try {
   if (!ctx || !ghz_mean || !ghz_min || !ghz_max) return fail(KZG_FAIL_ARGUMENT, "null argument");
   HIP_TRY(hipSetDevice(ctx->device));
   std::lock_guard<std::mutex> guard(ctx->prof_lock);
@@ -1346,6 +1412,8 @@ extern "C" int32_t kzg_clock_probe_read(const kzg_ctx* ctx, double* ghz_mean, do
   *ghz_min = lo;
   *ghz_max = hi;
   return 0;
+} catch (...) {
+  return abi_exception();
 }
 
 template <class F>
@@ -1466,7 +1534,7 @@ __global__ __launch_bounds__(64) void k_selftest_field_mul(uint64_t iters, unsig
   if (bad) atomicAdd(mismatches, (unsigned long long)bad);
 }
 
-extern "C" int32_t kzg_selftest_field_mul(const kzg_ctx* ctx, uint64_t lanes, uint64_t iters, uint64_t* mismatches) {
+extern "C" int32_t kzg_selftest_field_mul(const kzg_ctx* ctx, uint64_t lanes, uint64_t iters, uint64_t* mismatches) try {
   if (!ctx || !mismatches || lanes == 0) return fail(KZG_FAIL_ARGUMENT, "null argument");
   HIP_TRY(hipSetDevice(ctx->device));
   unsigned long long* d = nullptr;
@@ -1479,5 +1547,7 @@ extern "C" int32_t kzg_selftest_field_mul(const kzg_ctx* ctx, uint64_t lanes, ui
   (void)hipFree(d);
   *mismatches = h;
   return 0;
+} catch (...) {
+  return abi_exception();
 }
 

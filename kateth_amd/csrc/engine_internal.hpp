@@ -34,6 +34,10 @@
 using namespace kzg;
 
 int32_t fail(int32_t code, const std::string& msg);
+// The handler of every int32_t entry point's function-try-block: an exception on its way out of the library (std::bad_alloc from a
+// std::vector, std::system_error from a thread start) becomes KZG_FAIL_HOST with its text as kzg_last_error(); nothing unwinds
+// into the caller's C frames.
+int32_t abi_exception() noexcept;
 const std::string& last_error_text();
 // kzg_last_error / kzg_last_error_code are thread-local: work done on a helper thread hands its error to the calling thread
 struct ErrorSnapshot {

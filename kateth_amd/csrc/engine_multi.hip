@@ -166,23 +166,27 @@ int32_t group_enqueue(const kzg_ctx* ctx, const uint64_t* n_local, Call&& call) 
 }  // namespace
 
 extern "C" int32_t kzg_blob_to_commitment_batch_group_dev(const kzg_ctx* ctx, const void* const* d_blobs, const uint64_t* n_local, void* const* d_out48,
-                                                          void* const* d_status, void* const* hip_streams) {
+                                                          void* const* d_status, void* const* hip_streams) try {
   if (!ctx || !d_blobs || !n_local || !d_out48 || !d_status) return fail(KZG_FAIL_ARGUMENT, "null argument");
   return group_enqueue(ctx, n_local, [&](uint32_t k, const kzg_ctx* m) -> int32_t {
     return kzg_blob_to_commitment_batch_dev(m, d_blobs[k], n_local[k], d_out48[k], d_status[k], hip_streams ? hip_streams[k] : nullptr);
   });
+} catch (...) {
+  return abi_exception();
 }
 
 extern "C" int32_t kzg_compute_blob_proof_batch_group_dev(const kzg_ctx* ctx, const void* const* d_blobs, const void* const* d_commitments48,
-                                                          const uint64_t* n_local, void* const* d_out48, void* const* d_status, void* const* hip_streams) {
+                                                          const uint64_t* n_local, void* const* d_out48, void* const* d_status, void* const* hip_streams) try {
   if (!ctx || !d_blobs || !d_commitments48 || !n_local || !d_out48 || !d_status) return fail(KZG_FAIL_ARGUMENT, "null argument");
   return group_enqueue(ctx, n_local, [&](uint32_t k, const kzg_ctx* m) -> int32_t {
     return kzg_compute_blob_proof_batch_dev(m, d_blobs[k], d_commitments48[k], n_local[k], d_out48[k], d_status[k], hip_streams ? hip_streams[k] : nullptr);
   });
+} catch (...) {
+  return abi_exception();
 }
 
 extern "C" int32_t kzg_verify_blob_proof_batch_group_dev(const kzg_ctx* ctx, const void* const* d_blobs, const void* const* d_commitments48,
-                                                         const void* const* d_proofs48, const uint64_t* n_local, int32_t* ok, void* const* hip_streams) {
+                                                         const void* const* d_proofs48, const uint64_t* n_local, int32_t* ok, void* const* hip_streams) try {
   if (!ctx || !ok || !d_blobs || !d_commitments48 || !d_proofs48 || !n_local) return fail(KZG_FAIL_ARGUMENT, "null argument");
   *ok = 0;
   const uint32_t S = 1u + (uint32_t)ctx->peers.size();
@@ -196,4 +200,6 @@ extern "C" int32_t kzg_verify_blob_proof_batch_group_dev(const kzg_ctx* ctx, con
     total += n_local[k];
   }
   return verify_group_dev(ctx, shares, total, ok);
+} catch (...) {
+  return abi_exception();
 }

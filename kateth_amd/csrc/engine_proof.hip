@@ -144,7 +144,7 @@ static int32_t proof_dev_locked(const kzg_ctx* ctx, const uint8_t* d_blobs, cons
 }
 
 extern "C" int32_t kzg_compute_blob_proof_batch_dev(const kzg_ctx* ctx, const void* d_blobs, const void* d_commitments48, uint64_t n,
-                                                    void* d_out48, void* d_status, void* hip_stream) {
+                                                    void* d_out48, void* d_status, void* hip_stream) try {
   if (!ctx || (n && (!d_blobs || !d_commitments48 || !d_out48 || !d_status))) return fail(KZG_FAIL_ARGUMENT, "null argument");
   HIP_TRY(hipSetDevice(ctx->device));
   std::lock_guard<std::mutex> guard(ctx->lock);
@@ -156,6 +156,8 @@ extern "C" int32_t kzg_compute_blob_proof_batch_dev(const kzg_ctx* ctx, const vo
                           (int32_t*)d_status, st);
   if (rc == 0) rc = ws.end();
   return rc;
+} catch (...) {
+  return abi_exception();
 }
 
 // Host-buffer wrapper shared by the proof entry points.  Device buffers come from the context's pools (stage_lock): two
@@ -256,25 +258,33 @@ int32_t proof_host(const kzg_ctx* ctx, const uint8_t* blobs, const uint8_t* side
 }
 
 extern "C" int32_t kzg_compute_blob_proof_batch(const kzg_ctx* ctx, const uint8_t* blobs, const uint8_t* commitments48, uint64_t n,
-                                                uint8_t* out48, int32_t* status) {
+                                                uint8_t* out48, int32_t* status) try {
   if (!ctx || (n && (!blobs || !commitments48 || !out48 || !status))) return fail(KZG_FAIL_ARGUMENT, "null argument");
   return (is_group(ctx) ? multi_proof : proof_host)(ctx, blobs, commitments48, 48, true, n, out48, nullptr, nullptr, status);
+} catch (...) {
+  return abi_exception();
 }
 extern "C" int32_t kzg_compute_blob_proof_batch_affine(const kzg_ctx* ctx, const uint8_t* blobs, const uint8_t* commitments48, uint64_t n,
-                                                       uint8_t* out_affine96, int32_t* status) {
+                                                       uint8_t* out_affine96, int32_t* status) try {
   if (!ctx || (n && (!blobs || !commitments48 || !out_affine96 || !status))) return fail(KZG_FAIL_ARGUMENT, "null argument");
   return (is_group(ctx) ? multi_proof : proof_host)(ctx, blobs, commitments48, 48, true, n, nullptr, out_affine96, nullptr, status);
+} catch (...) {
+  return abi_exception();
 }
 
 extern "C" int32_t kzg_compute_proof_batch(const kzg_ctx* ctx, const uint8_t* blobs, const uint8_t* z32, uint64_t n, uint8_t* out_proof48,
-                                           uint8_t* out_y32, int32_t* status) {
+                                           uint8_t* out_y32, int32_t* status) try {
   if (!ctx || (n && (!blobs || !z32 || !out_proof48 || !out_y32 || !status))) return fail(KZG_FAIL_ARGUMENT, "null argument");
   return (is_group(ctx) ? multi_proof : proof_host)(ctx, blobs, z32, 32, false, n, out_proof48, nullptr, out_y32, status);
+} catch (...) {
+  return abi_exception();
 }
 extern "C" int32_t kzg_compute_proof_batch_affine(const kzg_ctx* ctx, const uint8_t* blobs, const uint8_t* z32, uint64_t n, uint8_t* out_proof_affine96,
-                                                  uint8_t* out_y32, int32_t* status) {
+                                                  uint8_t* out_y32, int32_t* status) try {
   if (!ctx || (n && (!blobs || !z32 || !out_proof_affine96 || !out_y32 || !status))) return fail(KZG_FAIL_ARGUMENT, "null argument");
   return (is_group(ctx) ? multi_proof : proof_host)(ctx, blobs, z32, 32, false, n, nullptr, out_proof_affine96, out_y32, status);
+} catch (...) {
+  return abi_exception();
 }
 
 void warm_code_object_proof() {

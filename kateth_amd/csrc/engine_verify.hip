@@ -610,7 +610,7 @@ static int32_t phase1_finish(kzg_verify_session* s, const uint8_t* com, const ui
 }
 
 extern "C" int32_t kzg_verify_phase1_dev(const kzg_ctx* ctx, const void* d_blobs, const void* d_commitments48, const void* d_proofs48,
-                                         uint64_t n, uint8_t* out_root32, int32_t* err6, kzg_verify_session** session, void* hip_stream) {
+                                         uint64_t n, uint8_t* out_root32, int32_t* err6, kzg_verify_session** session, void* hip_stream) try {
   if (!ctx || !out_root32 || !err6 || !session || (n && (!d_blobs || !d_commitments48 || !d_proofs48)))
     return fail(KZG_FAIL_ARGUMENT, "null argument");
   *session = nullptr;
@@ -637,6 +637,8 @@ extern "C" int32_t kzg_verify_phase1_dev(const kzg_ctx* ctx, const void* d_blobs
   }
   *session = s;
   return 0;
+} catch (...) {
+  return abi_exception();
 }
 
 int32_t stage_init(const kzg_ctx* ctx) {  // caller holds stage_lock
@@ -850,10 +852,12 @@ __global__ __launch_bounds__(64) void k_g1_decompress_public(const uint8_t* __re
   }
 }
 
-extern "C" int32_t kzg_g1_decompress_batch(const kzg_ctx* ctx, const uint8_t* in48, uint64_t n, uint8_t* out_affine96, int32_t* status) {
+extern "C" int32_t kzg_g1_decompress_batch(const kzg_ctx* ctx, const uint8_t* in48, uint64_t n, uint8_t* out_affine96, int32_t* status) try {
   if (!ctx || (n && (!in48 || !out_affine96 || !status))) return fail(KZG_FAIL_ARGUMENT, "null argument");
   if (n == 0) return 0;
   return (is_group(ctx) ? multi_g1_decompress : g1_decompress_single)(ctx, in48, n, out_affine96, status);
+} catch (...) {
+  return abi_exception();
 }
 int32_t g1_decompress_single(const kzg_ctx* ctx, const uint8_t* in48, uint64_t n, uint8_t* out_affine96, int32_t* status) {
   HIP_TRY(hipSetDevice(ctx->device));
@@ -882,10 +886,12 @@ int32_t g1_decompress_single(const kzg_ctx* ctx, const uint8_t* in48, uint64_t n
 // Polynomial::evaluate (src/kzg/poly.rs:10-33) for n (blob, z) pairs from host buffers, through the evaluation kernel of the
 // verification path.  (In verify_blob_kzg_proof_batch z is a hash output; an evaluation point ON the domain -- poly.rs:14-18 --
 // reaches k_eval_frac only through this entry point.)
-extern "C" int32_t kzg_evaluate_blobs(const kzg_ctx* ctx, const uint8_t* blobs, const uint8_t* z32, uint64_t n, uint8_t* out_y32, int32_t* status) {
+extern "C" int32_t kzg_evaluate_blobs(const kzg_ctx* ctx, const uint8_t* blobs, const uint8_t* z32, uint64_t n, uint8_t* out_y32, int32_t* status) try {
   if (!ctx || (n && (!blobs || !z32 || !out_y32 || !status))) return fail(KZG_FAIL_ARGUMENT, "null argument");
   if (n == 0) return 0;
   return (is_group(ctx) ? multi_evaluate_blobs : evaluate_blobs_single)(ctx, blobs, z32, n, out_y32, status);
+} catch (...) {
+  return abi_exception();
 }
 // The blobs cross PCIe through the staging arena in chunks of up to 2,048 (two slots: the copy of chunk k+1 beside the
 // evaluation of chunk k); only z, y and the statuses live in the small host-i/o pool, so a large call pins nothing.
@@ -1150,7 +1156,7 @@ static int32_t p2_finish_and_pair(kzg_verify_session* s, Phase2& p2, int32_t* ok
 }
 
 extern "C" int32_t kzg_verify_phase2_dev(kzg_verify_session* s, const uint8_t* roots32, uint64_t world, uint64_t first_index, uint64_t n_total,
-                                         uint8_t* out192) {
+                                         uint8_t* out192) try {
   if (!s || !roots32 || !out192 || world == 0) return fail(KZG_FAIL_ARGUMENT, "null argument");
   const kzg_ctx* ctx = s->ctx;
   TraceTimer tt(ctx->knobs.trace, "phase2");
@@ -1171,6 +1177,8 @@ extern "C" int32_t kzg_verify_phase2_dev(kzg_verify_session* s, const uint8_t* r
     (void)hipStreamSynchronize(s->aux);
   }
   return rc;
+} catch (...) {
+  return abi_exception();
 }
 
 // one item of a single-context call after phase 1: read back the two decoded points, z, y and the three statuses; the rest on the host
@@ -1237,7 +1245,7 @@ static int32_t verify_fused(kzg_verify_session* s, const uint8_t* com, const uin
 }
 
 // introspection: challenge z_i and evaluation y_i of items [first, first + count) of a session after phase 1
-extern "C" int32_t kzg_verify_session_zy(kzg_verify_session* s, uint64_t first, uint64_t count, uint8_t* out_z32, uint8_t* out_y32) {
+extern "C" int32_t kzg_verify_session_zy(kzg_verify_session* s, uint64_t first, uint64_t count, uint8_t* out_z32, uint8_t* out_y32) try {
   if (!s || !out_z32 || !out_y32 || first + count > s->n) return fail(KZG_FAIL_ARGUMENT, "bad argument");
   if (count == 0) return 0;
   HIP_TRY(hipSetDevice(s->ctx->device));
@@ -1251,9 +1259,11 @@ extern "C" int32_t kzg_verify_session_zy(kzg_verify_session* s, uint64_t first, 
       store_be32(out_y32 + 32 * i + 4 * q, hy[i].v[7 - q]);
     }
   return 0;
+} catch (...) {
+  return abi_exception();
 }
 
-extern "C" int32_t kzg_verify_batch_finish(const kzg_ctx* ctx, const uint8_t* partials192, uint64_t world, int32_t* ok) {
+extern "C" int32_t kzg_verify_batch_finish(const kzg_ctx* ctx, const uint8_t* partials192, uint64_t world, int32_t* ok) try {
   if (!ctx || !ok || (world && !partials192)) return fail(KZG_FAIL_ARGUMENT, "null argument");
   *ok = 0;
   g1_xyzz A, B;
@@ -1273,6 +1283,8 @@ extern "C" int32_t kzg_verify_batch_finish(const kzg_ctx* ctx, const uint8_t* pa
   *ok = host::verify_pairings_fixed(*ctx->pairing, a, b) ? 1 : 0;
   tt.mark("pairing");
   return 0;
+} catch (...) {
+  return abi_exception();
 }
 
 // first-error-wins order of the reference (src/kzg/setup.rs:259-271)
@@ -1284,7 +1296,7 @@ static int32_t first_error_code(const int32_t* err6) {
 }
 
 extern "C" int32_t kzg_verify_blob_proof_batch_dev(const kzg_ctx* ctx, const void* d_blobs, const void* d_commitments48, const void* d_proofs48,
-                                                   uint64_t n, int32_t* ok, void* hip_stream) {
+                                                   uint64_t n, int32_t* ok, void* hip_stream) try {
   if (!ctx || !ok || (n && (!d_blobs || !d_commitments48 || !d_proofs48))) return fail(KZG_FAIL_ARGUMENT, "null argument");
   *ok = 0;
   if (n == 0) {  // reference quirk Q4: the spec answer for an empty batch is true
@@ -1301,6 +1313,8 @@ extern "C" int32_t kzg_verify_blob_proof_batch_dev(const kzg_ctx* ctx, const voi
   if (rc == 0) rc = verify_fused(s, com, prf, ok);
   kzg_verify_session_destroy(s);
   return rc;
+} catch (...) {
+  return abi_exception();
 }
 
 // Setup::verify_blob_proof_batch (src/kzg/setup.rs:223-275) over device-resident shares of a group context, phases
@@ -1389,7 +1403,7 @@ int32_t verify_group_dev(const kzg_ctx* ctx, const std::vector<GroupDevShare>& s
 }
 
 extern "C" int32_t kzg_verify_blob_proof_batch(const kzg_ctx* ctx, const uint8_t* blobs, const uint8_t* commitments48, const uint8_t* proofs48,
-                                               uint64_t n, int32_t* ok) {
+                                               uint64_t n, int32_t* ok) try {
   if (!ctx || !ok || (n && (!blobs || !commitments48 || !proofs48))) return fail(KZG_FAIL_ARGUMENT, "null argument");
   *ok = 0;
   if (n == 0) {
@@ -1397,6 +1411,8 @@ extern "C" int32_t kzg_verify_blob_proof_batch(const kzg_ctx* ctx, const uint8_t
     return 0;
   }
   return (is_group(ctx) ? multi_verify_batch : verify_batch_host_single)(ctx, blobs, commitments48, proofs48, n, ok);
+} catch (...) {
+  return abi_exception();
 }
 int32_t verify_batch_host_single(const kzg_ctx* ctx, const uint8_t* blobs, const uint8_t* commitments48, const uint8_t* proofs48, uint64_t n, int32_t* ok) {
   *ok = 0;
@@ -1412,8 +1428,10 @@ int32_t verify_batch_host_single(const kzg_ctx* ctx, const uint8_t* blobs, const
 
 // Setup::verify_blob_proof (src/kzg/setup.rs:208-221): a batch of one (the random
 // coefficient is r^0 = 1, so this is exactly verify_proof_inner's equation)
-extern "C" int32_t kzg_verify_blob_proof(const kzg_ctx* ctx, const uint8_t* blob, const uint8_t* commitment48, const uint8_t* proof48, int32_t* ok) {
+extern "C" int32_t kzg_verify_blob_proof(const kzg_ctx* ctx, const uint8_t* blob, const uint8_t* commitment48, const uint8_t* proof48, int32_t* ok) try {
   return kzg_verify_blob_proof_batch(ctx, blob, commitment48, proof48, 1, ok);
+} catch (...) {
+  return abi_exception();
 }
 
 // Setup::verify_proof (src/kzg/setup.rs:96-113).  e(pi, [tau]_2 - z G2) == e(C - y G, G2)
@@ -1421,9 +1439,11 @@ extern "C" int32_t kzg_verify_blob_proof(const kzg_ctx* ctx, const uint8_t* blob
 // come from the caller instead of the challenge/evaluation kernels (the batch coefficient of item 0 is r^0 = 1).
 // Error order of the reference: proof, commitment, z, y.
 extern "C" int32_t kzg_verify_proof(const kzg_ctx* ctx, const uint8_t* proof48, const uint8_t* commitment48, const uint8_t* z32, const uint8_t* y32,
-                                    int32_t* ok) {
+                                    int32_t* ok) try {
   if (!ctx || !proof48 || !commitment48 || !z32 || !y32 || !ok) return fail(KZG_FAIL_ARGUMENT, "null argument");
   return (is_group(ctx) ? multi_verify_proof : verify_proof_single)(ctx, proof48, commitment48, z32, y32, ok);
+} catch (...) {
+  return abi_exception();
 }
 int32_t verify_proof_single(const kzg_ctx* ctx, const uint8_t* proof48, const uint8_t* commitment48, const uint8_t* z32, const uint8_t* y32, int32_t* ok) {
   *ok = 0;

@@ -172,6 +172,7 @@ _SIGNATURES = {
     "kzg_profile_kind_name": (ctypes.c_char_p, [ctypes.c_int32]),
     "kzg_ctx_adds_per_blob": (ctypes.c_uint64, [ctypes.c_void_p]),
     "kzg_selftest_field_mul": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]),
+    "kzg_selftest_exception_guard": (ctypes.c_int32, [ctypes.c_int32]),
     "kzg_microbench_fp_mul": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(ctypes.c_float)]),
     "kzg_clock_probe_launch": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_uint32]),
     "kzg_clock_probe_read": (ctypes.c_int32, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),

@@ -270,3 +270,29 @@ def test_every_kernel_is_compiled_once(lib):
     twice = {k: v for k, v in seen.items() if len(v) > 1}
     assert not twice, twice
     assert any("k_msm_comb30" in k for k in seen) and any("k_challenge_pair" in k for k in seen) and any("k_eval_frac" in k for k in seen)
+
+
+def test_no_exception_leaves_an_entry_point(lib):
+    """'never unwind across the boundary'.  Every extern "C" function that returns int32_t and has a body of its own is
+    a function-try-block whose handler turns what was thrown into KZG_FAIL_HOST (abi_exception); the test hook throws a
+    std::bad_alloc, a std::runtime_error and an int inside one such function (no GPU involved)."""
+    import ctypes
+
+    csrc = os.path.join(ROOT, "kateth_amd", "csrc")
+    checked = 0
+    for name in sorted(os.listdir(csrc)):
+        if not (name.startswith("engine") and name.endswith(".hip")):
+            continue
+        text = open(os.path.join(csrc, name)).read()
+        for m in re.finditer(r'^extern "C" int32_t (kzg_\w+)\(([^{};]*)\)\s*(try\s*)?\{[^\n]*$', text, flags=re.M):
+            if m.group(0).rstrip().endswith("}"):
+                continue  # a one-line getter: nothing in it can throw
+            assert m.group(3), "%s: %s is not a function-try-block" % (name, m.group(1))
+            checked += 1
+    assert checked >= 38
+    assert text.count("abi_exception()") >= 1
+    lib.kzg_last_error.restype = ctypes.c_char_p
+    for kind, needle in ((0, b"bad_alloc"), (1, b"runtime_error inside an entry point"), (2, b"unexpected C++ exception")):
+        assert lib.kzg_selftest_exception_guard(kind) == -7
+        assert needle in lib.kzg_last_error(), lib.kzg_last_error()
+    assert lib.kzg_selftest_exception_guard(3) == 0
