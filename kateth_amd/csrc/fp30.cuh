@@ -74,6 +74,11 @@ struct f30_col {
     (A).v = ((A).v + (int64_t)F30_H) >> 30;       \
     (A).wide = (A).v;                             \
   } while (0)
+#define F30_SHIFT_FLOOR(A) \
+  do {                     \
+    (A).v >>= 30;          \
+    (A).wide = (A).v;      \
+  } while (0)
 #define F30_TOP(A) ((int32_t)(A).v)
 #define F30_LIMBCHK(x, bound)                                                             \
   do {                                                                                    \
@@ -85,6 +90,7 @@ struct f30_col {
 #define F30_LO(A) ((uint32_t)(A))
 #define F30_SHIFT_EXACT(A) (A) >>= 30
 #define F30_SHIFT_ROUND(A) (A) = ((A) + (int64_t)F30_H) >> 30
+#define F30_SHIFT_FLOOR(A) (A) >>= 30
 #define F30_TOP(A) ((int32_t)(A))
 #define F30_LIMBCHK(x, bound) \
   do {                        \
@@ -106,7 +112,9 @@ KZG_HD int32_t f30_sbfe(uint32_t x) {
 // columns the result's digits are cut from -- so a difference like P = X2 ZZ1 / 2^390 - X1 comes out of the product ALREADY
 // C-form (centred digits), for one multiply-add per limb where a separate subtraction costs one instruction per limb too and a
 // carry pass four more.  inj0 / inj1: any limbs within +-2^31 (C- or L-form); |r| < 0.53 p + |C0 inj0| + |C1 inj1|.
-template <bool SQR, bool TWO, int C0 = 0, int C1 = 0>
+// UFORM: the result's digits 0..11 are cut with FLOOR instead of round -- [0, 2^30), "U-form": the same integer, limbs within the
+// L-form bound, so it may only ever meet a C-form in a product -- which saves the rounding add of every output column.
+template <bool SQR, bool TWO, int C0 = 0, int C1 = 0, bool UFORM = false>
 KZG_HD void f30_mul_core_c(fp30& r, const fp30& a, const fp30& b, const fp30& c, const fp30& d, const fp30& inj0, const fp30& inj1) {
   constexpr int N_ = F30_N;
   int32_t q[N_];
@@ -150,8 +158,13 @@ KZG_HD void f30_mul_core_c(fp30& r, const fp30& a, const fp30& b, const fp30& c,
       if (C0 != 0) F30_MAC(A, inj0.l[k - N_], C0);
       if (C1 != 0) F30_MAC(A, inj1.l[k - N_], C1);
       if (k < 2 * N_ - 1) {
-        r.l[k - N_] = f30_sbfe(F30_LO(A));  // r may alias an operand: limb k-13 of every operand was last read in column k-1
-        F30_SHIFT_ROUND(A);                 // (A - digit) / 2^30
+        if (UFORM) {
+          r.l[k - N_] = (int32_t)(F30_LO(A) & F30_MASK);
+          F30_SHIFT_FLOOR(A);
+        } else {
+          r.l[k - N_] = f30_sbfe(F30_LO(A));  // r may alias an operand: limb k-13 of every operand was last read in column k-1
+          F30_SHIFT_ROUND(A);                 // (A - digit) / 2^30
+        }
       } else {
         r.l[N_ - 1] = F30_TOP(A);
       }
@@ -166,7 +179,7 @@ namespace kzg {
 #if defined(__HIP_DEVICE_COMPILE__)
 // Device version: every column is issued as explicit v_mad_i64_i32 chains that START from the carry of the previous column
 // (rdx_mont.cuh has the reasons).  Same arithmetic as f30_mul_core_c, which the CPU tests run.
-template <bool SQR, bool TWO, int C0, int C1, int K>
+template <bool SQR, bool TWO, int C0, int C1, bool UFORM, int K>
 KZG_HD void f30_column(int64_t& A, int32_t* q, fp30& r, const fp30& a, const int32_t* a2, const fp30& b, const fp30& c, const fp30& d,
                        const fp30& inj0, const fp30& inj1) {
   constexpr int N_ = F30_N;
@@ -237,12 +250,17 @@ KZG_HD void f30_column(int64_t& A, int32_t* q, fp30& r, const fp30& a, const int
       ps[cnt + ninj - 1] = C1;
     }
     mad30_chain<cnt + ninj, true>::run(A, qs, ps);
-    r.l[K - N_] = f30_sbfe((uint32_t)A);
-    A = (A + (int64_t)F30_H) >> 30;
+    if constexpr (UFORM) {
+      r.l[K - N_] = (int32_t)((uint32_t)A & F30_MASK);
+      A >>= 30;
+    } else {
+      r.l[K - N_] = f30_sbfe((uint32_t)A);
+      A = (A + (int64_t)F30_H) >> 30;
+    }
   }
-  if constexpr (K + 1 < 2 * N_ - 1) f30_column<SQR, TWO, C0, C1, K + 1>(A, q, r, a, a2, b, c, d, inj0, inj1);
+  if constexpr (K + 1 < 2 * N_ - 1) f30_column<SQR, TWO, C0, C1, UFORM, K + 1>(A, q, r, a, a2, b, c, d, inj0, inj1);
 }
-template <bool SQR, bool TWO, int C0 = 0, int C1 = 0>
+template <bool SQR, bool TWO, int C0 = 0, int C1 = 0, bool UFORM = false>
 KZG_HD void f30_mul_core(fp30& r, const fp30& a, const fp30& b, const fp30& c, const fp30& d, const fp30& inj0, const fp30& inj1) {
   constexpr int N_ = F30_N;
   int32_t q[N_];
@@ -255,19 +273,21 @@ KZG_HD void f30_mul_core(fp30& r, const fp30& a, const fp30& b, const fp30& c, c
   if (C0 != 0) top += C0 * inj0.l[N_ - 1];
   if (C1 != 0) top += C1 * inj1.l[N_ - 1];
   int64_t A = 0;
-  f30_column<SQR, TWO, C0, C1, 0>(A, q, r, a, a2, b, c, d, inj0, inj1);
+  f30_column<SQR, TWO, C0, C1, UFORM, 0>(A, q, r, a, a2, b, c, d, inj0, inj1);
   r.l[N_ - 1] = (int32_t)A + top;  // column 25 holds only the carry
 }
 #else
-template <bool SQR, bool TWO, int C0 = 0, int C1 = 0>
+template <bool SQR, bool TWO, int C0 = 0, int C1 = 0, bool UFORM = false>
 KZG_HD void f30_mul_core(fp30& r, const fp30& a, const fp30& b, const fp30& c, const fp30& d, const fp30& inj0, const fp30& inj1) {
-  f30_mul_core_c<SQR, TWO, C0, C1>(r, a, b, c, d, inj0, inj1);
+  f30_mul_core_c<SQR, TWO, C0, C1, UFORM>(r, a, b, c, d, inj0, inj1);
 }
 #endif
 
 KZG_HD void f30_mul(fp30& r, const fp30& a, const fp30& b) { f30_mul_core<false, false>(r, a, b, a, b, a, a); }   // C x C or L x C
 KZG_HD void f30_sqr(fp30& r, const fp30& a) { f30_mul_core<true, false>(r, a, a, a, a, a, a); }                   // C
 KZG_HD void f30_mul2(fp30& r, const fp30& a, const fp30& b, const fp30& c, const fp30& d) { f30_mul_core<false, true>(r, a, b, c, d, a, a); }  // all C
+// U-form result (f30_mul_core_c's header): for a value whose every later use is a product with a C-form (the accumulator's ZZ, ZZZ)
+KZG_HD void f30_mul_u(fp30& r, const fp30& a, const fp30& b) { f30_mul_core<false, false, 0, 0, true>(r, a, b, a, b, a, a); }   // C x C, L x C or U x C
 // with injection (f30_mul_core_c's header): r = a b / 2^390 + C0 i0, and r = a^2 / 2^390 + C0 i0 + C1 i1, C-form
 template <int C0>
 KZG_HD void f30_mul_inj(fp30& r, const fp30& a, const fp30& b, const fp30& i0) { f30_mul_core<false, false, C0, 0>(r, a, b, a, b, i0, i0); }
@@ -452,7 +472,7 @@ KZG_HD void f30_load_entry(fp30& x, fp30& y, const uint32_t* wx, const uint32_t*
 // sum behind (its last product is then a sum of two products instead of a difference, which would need a negated operand) and
 // flips the flag; an entry to add is therefore loaded with the sign xyzz30_entry_neg() gives.  Doubling and the complete addition
 // work on the raw coordinates and keep the flag.
-// Invariant between additions: y, zz, zzz C-form, |value| < 0.53 p; x L-form (a sum of two C-forms), |value| < 3.3 p.
+// Invariant between additions: y C-form, zz and zzz C- or U-form, |value| < 0.53 p; x L-form (a sum of two C-forms), |value| < 3.3 p.
 struct g1_xyzz30 {
   fp30 x, y, zz, zzz;
   uint32_t inf;
@@ -512,8 +532,8 @@ KZG_HD bool xyzz30_madd_fast(g1_xyzz30& p, const fp30& x2, const fp30& y2) {
   f30_mul_inj<-1>(r, y2, p.zzz, p.y);       // R
   f30_sqr(pp, u);                           // PP
   f30_mul(ppp, u, pp);                      // PPP
-  f30_mul(p.zz, p.zz, pp);                  // ZZ3
-  f30_mul(p.zzz, p.zzz, ppp);               // ZZZ3
+  f30_mul_u(p.zz, p.zz, pp);                // ZZ3   (U-form: ZZ only ever meets a table entry's x and PP)
+  f30_mul_u(p.zzz, p.zzz, ppp);             // ZZZ3  (U-form: ZZZ only ever meets a table entry's y and PPP)
   f30_mul(pp, p.x, pp);                     // Q = X1 PP (L x C; X1 and PP are dead from here)
   f30_sqr_inj2<-1, -3>(v, r, ppp, pp);      // V = X3 - Q (|V| < 2.7 p)
   f30_add(p.x, v, pp);                      // X3

@@ -574,6 +574,7 @@ extern "C" void hm_f30_op(int op, int32_t* out13, const int32_t* a13, const int3
     case 8: r.l[0] = f30_is_zero(a) ? 1 : 0; break;
     case 10: f30_mul_inj<-1>(r, a, b, c); break;          // a b / 2^390 - c
     case 11: f30_sqr_inj2<-1, -3>(r, a, c, d); break;     // a^2 / 2^390 - c - 3 d
+    case 12: f30_mul_u(r, a, b); break;                   // a b / 2^390 with floor digits (U-form)
     case 9: {
       fp_t v;
       for (int i = 0; i < 12; i++) v.v[i] = (uint32_t)a13[i];

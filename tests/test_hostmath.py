@@ -439,6 +439,24 @@ def test_fp30_field_ops(hm):
             c = [sc * (2 * F30_H + 4)] * 12 + [sc * (1 << 22)]
             ok_injected(_f30(hm, 10, a, a, c), _v30(a) ** 2 - _v30(c) * Rm, 40)
             ok_injected(_f30(hm, 11, a, a, c, c), _v30(a) ** 2 - 4 * _v30(c) * Rm, 160)
+    # U-form results (floor digits: the accumulator's ZZ / ZZZ): the same integer as the centred result, limbs 0..11 in [0, 2^30);
+    # a U-form operand with a C-form one, at the extremes of both
+    for _ in range(200):
+        x, y = rnd.randrange(-3 * P, 3 * P), rnd.randrange(-3 * P, 3 * P)
+        a, b = _c30(x), _c30(y)
+        u = _f30(hm, 12, a, b)
+        assert _v30(u) == _v30(_f30(hm, 0, a, b)) and all(0 <= t < 1 << 30 for t in u[:12]) and abs(u[12]) < 1 << 22
+        ok_product(_f30(hm, 0, u, b), _v30(u) * y)
+        uu = _f30(hm, 12, u, b)  # U x C -> U, as ZZ3 = ZZ1 * PP
+        assert (_v30(uu) * Rm - _v30(u) * y) % P == 0 and all(0 <= t < 1 << 30 for t in uu[:12])
+    for sb in (1, -1):
+        top = [(1 << 30) - 1] * 12 + [1 << 21]
+        b = [sb * (F30_H + 2)] * 12 + [sb * (1 << 21)]
+        ok_product(_f30(hm, 0, top, b), _v30(top) * _v30(b))
+        ok_product(_f30(hm, 0, b, top), _v30(top) * _v30(b))
+        ok_injected(_f30(hm, 10, top, b, b), _v30(top) * _v30(b) - _v30(b) * Rm, 8)
+        uu = _f30(hm, 12, top, b)
+        assert (_v30(uu) * Rm - _v30(top) * _v30(b)) % P == 0 and all(0 <= t < 1 << 30 for t in uu[:12])
     # carry passes: value preserved, limbs back in range
     for _ in range(100):
         l = [rnd.randrange(-(1 << 31) + (1 << 29) + 1, (1 << 31) - (1 << 29)) for _ in range(12)] + [rnd.randrange(-(1 << 24), 1 << 24)]
