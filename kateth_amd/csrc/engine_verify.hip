@@ -96,10 +96,13 @@ extern "C" void kzg_verify_session_destroy(kzg_verify_session* s) {
 // long (A: 40,960 threads x 32 entries instead of 81,920 x 16 on a chip with 131,072 lanes at this register budget): the bucket
 // kernels went from 1.13 / 0.53 ms to 1.43 / 1.26 ms, against 0.1 ms saved in the host's Horner loops.
 static bool use_glv(const kzg_ctx* ctx, uint64_t n_items) { return n_items >= 32768 && !ctx->knobs.var_msm_classic && ctx->knobs.var_glv; }
-static VarGeom choose_var_geom(const kzg_ctx* ctx, uint64_t nterms, bool glv = false) {
+// seg_total: the terms of ALL the lincombs whose bucket kernels run side by side (batch verification: n + 2 n + 1), so that their
+// lanes together are one round of the chip: 0 = this lincomb alone.
+static VarGeom choose_var_geom(const kzg_ctx* ctx, uint64_t nterms, bool glv = false, uint64_t seg_total = 0) {
   VarGeom g;
   g.top_n = 0;
   g.ktop = 1;
+  g.seg = 0;
   if (glv) {
     g.c = 13u;
     g.W = 10u;
@@ -114,6 +117,13 @@ static VarGeom choose_var_geom(const kzg_ctx* ctx, uint64_t nterms, bool glv = f
     g.half = 1u << 12;
     g.top_n = 256u;
     g.ktop = 16u;  // top_n * ktop = half: the top window costs k_var_bitsums what a full window does
+    if (ctx->knobs.var_seg) {
+      // equal shares of the sorted entry list per lane (k_var_buckets_seg): the chip holds 2,048 waves of these kernels (two per
+      // SIMD) = 131,072 lanes; 8,192 of them are the two top windows' threads, the rest is left a margin of one wave in sixteen
+      const uint64_t entries = (seg_total ? seg_total : nterms) * (uint64_t)(g.W - 1u);
+      const uint64_t lanes = 114688;
+      g.seg = (uint32_t)std::min<uint64_t>(std::max<uint64_t>((entries + lanes - 1) / lanes, 16), 4096);
+    }
     return g;
   }
   g.c = nterms >= 64 ? 8u : 4u;
@@ -184,12 +194,13 @@ static bool host_affine_from_be96(host::g1_host_affine& a, const uint8_t* in96) 
 struct MsmVarLayout {
   VarGeom g{};
   uint32_t nb = 0, K = 1;
-  size_t o_counts = 0, o_offsets = 0, o_cursors = 0, o_entries = 0, o_part = 0, o_bsum = 0, o_win = 0, total = 0;
+  size_t o_counts = 0, o_offsets = 0, o_cursors = 0, o_entries = 0, o_part = 0, o_bsum = 0, o_win = 0, o_seg = 0, total = 0;
+  uint32_t nseg = 0;  // lanes of the balanced bucket kernel (an upper bound: digits that are zero make no entry)
 };
-static MsmVarLayout msm_var_layout(const kzg_ctx* ctx, uint64_t nterms, bool glv = false) {
+static MsmVarLayout msm_var_layout(const kzg_ctx* ctx, uint64_t nterms, bool glv = false, uint64_t seg_total = 0) {
   MsmVarLayout L;
   if (nterms == 0) return L;
-  L.g = choose_var_geom(ctx, nterms, glv);
+  L.g = choose_var_geom(ctx, nterms, glv, seg_total);
   L.nb = L.g.W * L.g.half;
   size_t off = 0;
   auto take = [&](size_t bytes) {
@@ -206,6 +217,10 @@ static MsmVarLayout msm_var_layout(const kzg_ctx* ctx, uint64_t nterms, bool glv
     L.o_part = take((size_t)L.g.top_n * L.g.ktop * sizeof(g1_xyzz28));
     L.o_bsum = take((size_t)L.nb * sizeof(g1_xyzz28));
     L.o_win = take((size_t)L.g.W * L.g.c * sizeof(g1_xyzz));
+    if (L.g.seg) {
+      L.nseg = (uint32_t)((nterms * (uint64_t)(L.g.W - 1u) + L.g.seg - 1u) / L.g.seg);
+      L.o_seg = take((size_t)L.nseg * 2u * sizeof(g1_xyzz28));
+    }
     L.total = off;
     return L;
   }
@@ -240,14 +255,14 @@ struct MsmVarJob {
 // `glv`: the scalars are the 128-bit halves of a GLV split (k_glv_split): terms [0, split) on points [0, split), terms [split, nterms)
 // on the [z^2]-images at second_base + (t - split) (k_glv_points).
 static int32_t msm_var_sort(const kzg_ctx* ctx, MsmVarJob& job, const uint8_t* d_inf, const fr_t* d_scalars, uint64_t nterms, hipStream_t st,
-                            uint8_t* prealloc, bool lean, bool glv = false, uint64_t split = 0, uint64_t second_base = 0) {
+                            uint8_t* prealloc, bool lean, bool glv = false, uint64_t split = 0, uint64_t second_base = 0, uint64_t seg_total = 0) {
   job.active = false;
   job.st = st;
   job.nterms = nterms;
   job.trace = ctx->knobs.trace;
   if (nterms == 0) return 0;
   if (!glv) split = nterms;
-  job.L = msm_var_layout(ctx, nterms, glv);
+  job.L = msm_var_layout(ctx, nterms, glv, seg_total);
   const MsmVarLayout& L = job.L;
   const VarGeom g = L.g;
   job.g = g;
@@ -297,8 +312,15 @@ static int32_t msm_var_accumulate(const kzg_ctx* ctx, MsmVarJob& job, const uint
   g1_xyzz* winsum = (g1_xyzz*)(buf + L.o_win);
   if (g.top_n) {
     const uint32_t regular = (g.W - 1) * g.half;
-    hipLaunchKernelGGL(k_var_buckets_flat, dim3(blocks_for((uint64_t)regular + (uint64_t)g.top_n * g.ktop, 64)), dim3(64), 0, st, d_points, offsets,
-                       entries, regular, g.top_n, g.ktop, bsum, bpart);
+    if (g.seg) {
+      g1_xyzz28* segpart = (g1_xyzz28*)(buf + L.o_seg);
+      hipLaunchKernelGGL(k_var_buckets_seg, dim3(blocks_for((uint64_t)L.nseg + (uint64_t)g.top_n * g.ktop, 64)), dim3(64), 0, st, d_points, offsets, entries,
+                         regular, g.seg, L.nseg, g.top_n, g.ktop, bsum, bpart, segpart);
+      hipLaunchKernelGGL(k_var_seg_fixup, dim3(blocks_for(regular, 64)), dim3(64), 0, st, offsets, regular, g.seg, segpart, bsum);
+    } else {
+      hipLaunchKernelGGL(k_var_buckets_flat, dim3(blocks_for((uint64_t)regular + (uint64_t)g.top_n * g.ktop, 64)), dim3(64), 0, st, d_points, offsets,
+                         entries, regular, g.top_n, g.ktop, bsum, bpart);
+    }
     hipLaunchKernelGGL(k_var_bitsums, dim3(g.W * g.c), dim3(256), 0, st, bsum, bpart, g, winsum);
   } else {
     hipLaunchKernelGGL(k_var_buckets, dim3(blocks_for((uint64_t)nb * K, 64)), dim3(64), 0, st, d_points, offsets, entries, nb, K, bpart);
@@ -384,8 +406,8 @@ static SessionLayout session_layout(const kzg_ctx* ctx, uint64_t n) {
   L.o_mids = take((n / 16 + 1) * 32 + 32);
   L.o_nodes = take(groups * 32 + 32);
   L.o_pts = take(2 * n * 48 + 48);
-  L.o_msm_a = take((glv ? msm_var_layout(ctx, 2 * n, true) : msm_var_layout(ctx, n)).total + 256);
-  L.o_msm_b = take((glv ? msm_var_layout(ctx, 2 * (2 * n + 1), true) : msm_var_layout(ctx, 2 * n + 1)).total + 256);
+  L.o_msm_a = take((glv ? msm_var_layout(ctx, 2 * n, true) : msm_var_layout(ctx, n, false, 3 * n + 1)).total + 256);
+  L.o_msm_b = take((glv ? msm_var_layout(ctx, 2 * (2 * n + 1), true) : msm_var_layout(ctx, 2 * n + 1, false, 3 * n + 1)).total + 256);
   L.o_rpow = take(64 * 32);
   L.o_ysum = take(((n + 255) / 256 + 1) * 32);
   L.total = off;
@@ -1059,11 +1081,11 @@ static int32_t p2_sort(kzg_verify_session* s, Phase2& p2, bool beside_decoder) {
   }
   {
     ProfScope psb(ctx, PROF_VAR_MSM, s->st);
-    rc = msm_var_sort(ctx, p2.jb, inf, s->scal, 2 * n + 1, s->st, s->msm_b, beside_decoder);
+    rc = msm_var_sort(ctx, p2.jb, inf, s->scal, 2 * n + 1, s->st, s->msm_b, beside_decoder, false, 0, 0, 3 * n + 1);
   }
   if (rc == 0) {
     ProfScope psa(ctx, PROF_VAR_MSM, s->aux);
-    rc = msm_var_sort(ctx, p2.ja, inf, s->scal + n, n, s->aux, s->msm_a, beside_decoder);
+    rc = msm_var_sort(ctx, p2.ja, inf, s->scal + n, n, s->aux, s->msm_a, beside_decoder, false, 0, 0, 3 * n + 1);
   }
   return rc;
 }

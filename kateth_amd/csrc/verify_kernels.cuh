@@ -497,6 +497,7 @@ struct VarGeom {
   // (8 scalar bits: at most top_n magnitudes, each with 2^(c-8) times the load) split over ktop threads per bucket, and the
   // per-window sum_d d*B_d replaced by bit sums (k_var_bitsums) that the host folds into its Horner loop.
   uint32_t top_n, ktop;
+  uint32_t seg;  // flat path: entries per lane of the balanced bucket kernel (k_var_buckets_seg); 0 = one thread per bucket
 };
 
 // signed digits of one scalar, all windows, through a callback
@@ -784,6 +785,123 @@ static __global__ __launch_bounds__(64, 2) void k_var_buckets_flat(const uint4* 
     var_bucket_chain(acc, points, entries, offsets[bkt], offsets[bkt + 1], (uint32_t)(t % ktop), ktop);
     top_partials[t] = acc;
   }
+}
+
+// ---- flat path, BALANCED ("segmented"): every lane sums the same number of entries --------------------------------------------
+// With one thread per bucket a wave runs until its LONGEST bucket is done: bucket sizes are Poisson (mean 16 / 32 entries for the
+// two lincombs of 65,536 triples), the longest of 64 is 26 / 46, so 30-40 % of the lanes of every instruction are idle -- and the
+// 5,120 waves of the two kernels are 2.5 rounds of the chip's 2,048 wave slots at this register budget.  Here the full windows'
+// sorted entry list [0, offsets[regular]) is cut into equal shares of E consecutive entries, one per lane (E chosen by the host so
+// that both lincombs' lanes are ONE round); a lane walks its share and, where a bucket's list ends inside it, stores that bucket's
+// sum and starts the next.  A bucket that lies inside one share is written to bucket_sums directly; one that crosses share
+// boundaries leaves partial sums -- seg_part[2 l + 1]: the bucket that BEGINS in share l and runs past its end; seg_part[2 l]: the
+// one that was already running when share l began (its middle or its end) -- which k_var_seg_fixup adds up, one thread per bucket
+// (it also writes the identity for empty buckets, which no share visits).  The top window's threads are those of
+// k_var_buckets_flat.
+static __global__ __launch_bounds__(64, 2) void k_var_buckets_seg(const uint4* __restrict__ points, const uint32_t* __restrict__ offsets,
+                                                                  const uint32_t* __restrict__ entries, uint32_t regular, uint32_t E, uint32_t nseg,
+                                                                  uint32_t top_n, uint32_t ktop, g1_xyzz28* __restrict__ bucket_sums,
+                                                                  g1_xyzz28* __restrict__ top_partials, g1_xyzz28* __restrict__ seg_part) {
+  const uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  g1_xyzz28 acc;
+  if (id >= nseg) {
+    const uint64_t t = id - nseg;
+    if (t >= (uint64_t)top_n * ktop) return;
+    const uint32_t bkt = regular + (uint32_t)(t / ktop);
+    var_bucket_chain(acc, points, entries, offsets[bkt], offsets[bkt + 1], (uint32_t)(t % ktop), ktop);
+    top_partials[t] = acc;
+    return;
+  }
+  const uint32_t T = offsets[regular];
+  const uint64_t lo64 = id * E;
+  if (lo64 >= T) return;
+  const uint32_t lo = (uint32_t)lo64;
+  const uint32_t hi = (T - lo > E) ? lo + E : T;
+  // the bucket of entry lo: offsets[b] <= lo < offsets[b + 1]   (offsets[0] = 0 <= lo < T = offsets[regular])
+  uint32_t b = 0, z = regular;
+  while (z - b > 1u) {
+    const uint32_t m = (b + z) >> 1;
+    if (offsets[m] <= lo)
+      b = m;
+    else
+      z = m;
+  }
+  bool started = offsets[b] == lo;  // the bucket's list begins with this share's first entry
+  uint32_t bstop = offsets[b + 1];  // end of the current bucket's list
+  // ... and of the next one's, read one bucket AHEAD: a load issued at a boundary and consumed there would wait, in order, for the
+  // point gather issued just before it -- in nearly every step of a wave, since some lane of 64 is at a boundary in nearly every step
+  uint32_t bnext = offsets[(b + 2u < regular) ? b + 2u : regular];
+  xyzz28_set_inf(acc);
+  fp_t nx, ny;
+  uint32_t ne = entries[lo];
+  load_affine96(nx, ny, points, ne >> 1);
+#pragma unroll 1
+  for (uint32_t k = lo; k < hi; k++) {
+    const uint32_t e = ne;
+    const bool skip = bn_is_zero(nx) && bn_is_zero(ny);  // an all-zero entry is the point at infinity (var_bucket_chain)
+    fp28 cx, cy;
+    f28_load_entry(cx, cy, nx, ny, (e & 1u) != 0);
+    if (k + 1u < hi) {
+      ne = entries[k + 1u];
+      load_affine96(nx, ny, points, ne >> 1);
+    }
+    if (!skip) {
+      if (acc.inf) {  // a bucket's first point, inline: some lane of a wave is at one in nearly every step
+        acc.x = cx;
+        acc.y = cy;
+        f28_normalize(acc.y);  // a negated y (2p - y, limbs < 2^29) -> limbs < 2^28: N-form
+        acc.zz = f28_one();
+        acc.zzz = acc.zz;
+        acc.inf = 0;
+      } else if (!xyzz28_madd_fast(acc, cx, cy)) {
+        g1_xyzz28 tmp = acc;  // copy: the call takes addresses
+        fp_t rx, ry;
+        load_affine96(rx, ry, points, e >> 1);
+        fp28 sx, sy;
+        f28_load_entry(sx, sy, rx, ry, (e & 1u) != 0);
+        xyzz28_madd_complete(tmp, sx, sy);
+        acc = tmp;
+      }
+    }
+    if (k + 1u == bstop || k + 1u == hi) {  // the bucket's list, or the share, ends here
+      const bool ends = bstop <= hi;        // ... the bucket's list (it may end exactly with the share)
+      g1_xyzz28* dst = (started && ends) ? bucket_sums + b : seg_part + (2 * id + (started ? 1u : 0u));
+      *dst = acc;
+      if (k + 1u < hi) {  // next non-empty bucket (it begins at k + 1)
+        b++;
+        bstop = bnext;
+        while (bstop == k + 1u) {  // an empty bucket (e^-16 of them at 65,536 triples)
+          b++;
+          bstop = offsets[b + 1];
+        }
+        bnext = offsets[(b + 2u < regular) ? b + 2u : regular];
+        started = true;
+        xyzz28_set_inf(acc);
+      }
+    }
+  }
+}
+// one thread per full-window bucket: the identity for an empty one, the sum of the partial sums of one that crosses share boundaries
+static __global__ __launch_bounds__(64) void k_var_seg_fixup(const uint32_t* __restrict__ offsets, uint32_t regular, uint32_t E,
+                                                             const g1_xyzz28* __restrict__ seg_part, g1_xyzz28* __restrict__ bucket_sums) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= regular) return;
+  const uint32_t lo = offsets[b], hi = offsets[b + 1];
+  g1_xyzz28 acc;
+  if (lo == hi) {
+    xyzz28_set_inf(acc);
+    bucket_sums[b] = acc;
+    return;
+  }
+  const uint32_t first = lo / E, last = (hi - 1u) / E;
+  if (first == last) return;  // inside one share: that lane wrote the sum
+  acc = seg_part[2 * (uint64_t)first + 1u];
+#pragma unroll 1
+  for (uint32_t l = first + 1u; l <= last; l++) {
+    const g1_xyzz28 other = seg_part[2 * (uint64_t)l];
+    xyzz28_add_complete_inl<true>(acc, other);
+  }
+  bucket_sums[b] = acc;
 }
 
 // One wave folds the K partial sums of 64/K buckets: K is a power of two <= 64, lanes

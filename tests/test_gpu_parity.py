@@ -728,16 +728,20 @@ def test_flat_and_classic_variable_base_msm_agree(engine, torch_cuda, monkeypatc
     monkeypatch.delenv("KATETH_AMD_VAR_MSM")
     noglv = _engine_with_env(monkeypatch, {"KATETH_AMD_VAR_GLV": "1"})
     monkeypatch.delenv("KATETH_AMD_VAR_GLV")
+    # the default flat path gives every LANE the same number of entries (k_var_buckets_seg + k_var_seg_fixup); KATETH_AMD_VAR_SEG=0 is
+    # the flat path with one thread per bucket: a fourth way to the same two sums
+    perbucket = _engine_with_env(monkeypatch, {"KATETH_AMD_VAR_SEG": "0"})
+    monkeypatch.delenv("KATETH_AMD_VAR_SEG")
     try:
         sums = []
-        for e in (engine, classic, noglv):
+        for e in (engine, classic, noglv, perbucket):
             sess, root, err = e.verify_phase1_dev(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n)
             assert err[0] == err[2] == err[4] == -1
             sums.append(e.verify_phase2_dev(sess, root, 0, n))
             e.verify_session_destroy(sess)
             assert e.verify_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n) is True
             assert e.verify_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), bad_p.data_ptr(), n) is False
-        assert sums[0] == sums[1] == sums[2] and len(sums[0]) == 192
+        assert sums[0] == sums[1] == sums[2] == sums[3] and len(sums[0]) == 192
         # every triple the same: all buckets collect multiples of ONE point, so the complete adder's P == Q branch is taken in
         # the bucket chains (second entry of every list) and between equal bucket sums in the bit-sum trees
         d_blobs.view(n, 131072)[:] = d_blobs.view(n, 131072)[0].clone()
@@ -745,16 +749,17 @@ def test_flat_and_classic_variable_base_msm_agree(engine, torch_cuda, monkeypatc
         d_p.view(n, 48)[:] = d_p.view(n, 48)[0].clone()
         torch.cuda.synchronize()
         sums = []
-        for e in (engine, classic, noglv):
+        for e in (engine, classic, noglv, perbucket):
             sess, root, err = e.verify_phase1_dev(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n)
             assert err[0] == err[2] == err[4] == -1
             sums.append(e.verify_phase2_dev(sess, root, 0, n))
             e.verify_session_destroy(sess)
             assert e.verify_blob_proof_batch_dev(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n) is True
-        assert sums[0] == sums[1] == sums[2]
+        assert sums[0] == sums[1] == sums[2] == sums[3]
     finally:
         classic.close()
         noglv.close()
+        perbucket.close()
 
 
 def test_evaluation_kernel_group_shapes_agree(engine, golden, torch_cuda, monkeypatch):
