@@ -1047,7 +1047,9 @@ def run_rank(args, rank, local_rank, world):
                              "proof_frac": rp.get("frac"),
                              "verify_longest_kernel_by_duration": "%s %.2f ms (beside k_eval_frac on a second stream); `kernel` of the verify roofline = %s %.2f ms, alone on the chip"
                              % (rv.get("longest_kernel_by_duration"), rv.get("longest_kernel_ms") or 0.0, rv.get("dominant_kernel_by_bytes"), rv.get("kernel_ms") or 0.0)
-                             if rv.get("longest_kernel_by_duration") else None})
+                             if rv.get("longest_kernel_by_duration") else None,
+                             "verify_valu_issue_note": "the floor counts WAVE instructions: until the balanced bucket kernel (round 5, k_var_buckets_seg) it contained the "
+                             "idle lanes of one-thread-per-bucket waves -- 11.9 ms then, 11.2 ms now, while the call itself got 0.2-0.3 ms shorter (DESIGN.md 5.4)"})
             flatten_valu_issue(roof)
         if roof is not None:
             result["roofline"] = ordered_roofline(roof)
