@@ -123,6 +123,12 @@ static VarGeom choose_var_geom(const kzg_ctx* ctx, uint64_t nterms, bool glv = f
       const uint64_t entries = (seg_total ? seg_total : nterms) * (uint64_t)(g.W - 1u);
       const uint64_t lanes = 114688;
       g.seg = (uint32_t)std::min<uint64_t>(std::max<uint64_t>((entries + lanes - 1) / lanes, 16), 4096);
+      // the top window's 232 possible magnitudes (231 + a carry) over 20 threads each: a thread's strided list is then SHORTER than a
+      // share (2 n / 232 / 20 = n / 2,320 entries against 3 n * 19 / 114,688 = n / 2,012) -- with 16 it was the longer lincomb's
+      // longest chain (35-40 entries at 65,536 triples against shares of 33); k_var_bitsums sums 2,340 instead of 2,064 stored points
+      // per top-window bit: one addition more in 18
+      g.top_n = 232u;
+      g.ktop = 20u;
     }
     return g;
   }
@@ -285,7 +291,7 @@ static int32_t msm_var_sort(const kzg_ctx* ctx, MsmVarJob& job, const uint8_t* d
   HIP_TRY(hipMemsetAsync(counts, 0, (size_t)(nb + 1) * 4, st));
   hipLaunchKernelGGL(k_var_count, dim3(blocks_for(nterms, 256)), dim3(256), 0, st, d_scalars, d_inf, nterms, g, counts);
   if (g.top_n) {
-    if (nb > 1024u * 80u || g.top_n * g.ktop > g.half + 64u) return fail(KZG_FAIL_ARGUMENT, "flat MSM geometry out of range");
+    if (nb > 1024u * 80u || g.top_n * g.ktop > g.half + 1024u) return fail(KZG_FAIL_ARGUMENT, "flat MSM geometry out of range");
     if (lean)
       hipLaunchKernelGGL(k_var_scan_lean, dim3(1), dim3(256), 0, st, counts, nb, (nb / 256u + 3u) & ~3u, offsets, cursors);  // nb = 20 * 4096 = 256 * 320
     else

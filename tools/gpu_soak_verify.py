@@ -22,7 +22,7 @@ os.environ["KATETH_AMD_VAR_MSM"] = "classic"
 classic = kateth_amd.Setup.load_json(SETUP, window_bits=8)
 del os.environ["KATETH_AMD_VAR_MSM"]
 rnd = random.Random(0x50AC)
-sizes = [1, 2, 63, 64, 65, 130, 1000, 4095, 4096, 4097, 8192, 9000, 16384, 16500, 32767, 32768, 33001, 50000]
+sizes = [1, 2, 63, 64, 65, 130, 1000, 4095, 4096, 4097, 8192, 9000, 16384, 16500, 32767, 32768, 33001, 50000, 65536, 100000, 131072]  # from 32,768 on: the balanced bucket kernel (E = 16 ... 65 entries per lane)
 bad = 0
 t0 = time.time()
 for rd in range(rounds):
