@@ -87,6 +87,9 @@ extern "C" void kzg_verify_session_destroy(kzg_verify_session* s) {
 // 65,536 items 17.9 / 18.7) the FLAT path: c = 13, 20 windows, 4,096 buckets
 // per full window = enough buckets for one thread each (no fold), 37 % fewer bucket additions, the top window's <= 232
 // magnitudes handled with 16 threads per bucket, and bit sums instead of running sums (k_var_bitsums).
+// Since late round 5 the flat path's full windows are summed by EQUAL SHARES of the sorted entry list per lane (k_var_buckets_seg,
+// verify_kernels.cuh; g.seg entries per lane, chosen below so that all the lincombs that run side by side are one round of waves) and a
+// fix-up pass for the buckets that cross share boundaries; KATETH_AMD_VAR_SEG=0 keeps one thread per bucket (k_var_buckets_flat).
 // GLV (glv.cuh, round 5; KATETH_AMD_VAR_GLV=1 -- measured and NOT the default): both lincombs take their scalars split at z^2 --
 // twice the terms, 128-bit scalars: c = 13, TEN windows (nine full + bits 117..127: both halves are < z^2 = 0.673 * 2^128, so a
 // raw top digit <= 1,378, + 1 carry, never negated: 1,379 magnitudes with three times a full window's load each -> 3 threads per
