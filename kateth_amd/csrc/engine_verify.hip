@@ -121,10 +121,11 @@ static VarGeom choose_var_geom(const kzg_ctx* ctx, uint64_t nterms, bool glv = f
     g.top_n = 256u;
     g.ktop = 16u;  // top_n * ktop = half: the top window costs k_var_bitsums what a full window does
     if (ctx->knobs.var_seg) {
-      // equal shares of the sorted entry list per lane (k_var_buckets_seg): the chip holds 2,048 waves of these kernels (two per
-      // SIMD) = 131,072 lanes; 8,192 of them are the two top windows' threads, the rest is left a margin of one wave in sixteen
+      // equal shares of the sorted entry list per lane (k_var_buckets_seg): the chip holds two waves of these kernels per SIMD
+      // (232 VGPRs) = 131,072 lanes on 256 CUs; 9,280 of them are the two top windows' threads, the rest is left a margin of
+      // one wave in sixteen: 7/8 of the lanes for the shares (114,688 on an MI355X)
       const uint64_t entries = (seg_total ? seg_total : nterms) * (uint64_t)(g.W - 1u);
-      const uint64_t lanes = 114688;
+      const uint64_t lanes = (uint64_t)ctx->num_cus * 4u * 2u * 64u * 7u / 8u;
       g.seg = (uint32_t)std::min<uint64_t>(std::max<uint64_t>((entries + lanes - 1) / lanes, 16), 4096);
       // the top window's 232 possible magnitudes (231 + a carry) over 20 threads each: a thread's strided list is then SHORTER than a
       // share (2 n / 232 / 20 = n / 2,320 entries against 3 n * 19 / 114,688 = n / 2,012) -- with 16 it was the longer lincomb's
