@@ -386,7 +386,7 @@ EnvKnobs read_env_knobs() {
     k.single_via_batch = getenv("KATETH_AMD_SINGLE_VIA_BATCH") != nullptr;
     if (const char* e = getenv("KATETH_AMD_VAR_MSM")) k.var_msm_classic = std::string(e) == "classic";
     if (const char* e = getenv("KATETH_AMD_VAR_GLV")) k.var_glv = atoi(e) != 0;
-    if (const char* e = getenv("KATETH_AMD_VAR_SEG")) k.var_seg = atoi(e) != 0;
+    if (const char* e = getenv("KATETH_AMD_VAR_SEG")) k.var_seg = (uint32_t)std::max(0, atoi(e));
     if (const char* e = getenv("KATETH_AMD_VERIFY_STREAMS")) k.verify_streams = (uint32_t)atoi(e) <= (uint32_t)KZG_STAGE_STREAMS ? (uint32_t)atoi(e) : 0u;
     if (const char* e = getenv("KATETH_AMD_VERIFY_CHUNK")) k.verify_chunk = (uint64_t)atoll(e) > 0 ? (uint64_t)atoll(e) : 0;
     k.comb_full_wave = getenv("KATETH_AMD_COMB_FULL_WAVE") != nullptr;

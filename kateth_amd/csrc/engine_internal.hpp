@@ -124,7 +124,7 @@ struct EnvKnobs {
   bool single_via_batch = false; // KATETH_AMD_SINGLE_VIA_BATCH: a single-item verification takes the batch machinery (the cross-check of the host lincomb)
   bool var_glv = false;          // KATETH_AMD_VAR_GLV=1: both lincombs of a batch of >= 32,768 items take their scalars GLV-split (built, measured and
                                  // NOT adopted in round 5: +0.2 ms per 65,536 triples, profiles/r05/verify_glv_rejected.json; kept as an independent cross-check)
-  bool var_seg = true;           // KATETH_AMD_VAR_SEG=0: the flat path's bucket sums with one thread per bucket (k_var_buckets_flat) instead of equal shares of
+  uint32_t var_seg = 1;          // 1 = on, share size chosen by the engine; >= 2: that many entries per lane (tuning sweeps); KATETH_AMD_VAR_SEG=0: the flat path's bucket sums with one thread per bucket (k_var_buckets_flat) instead of equal shares of
                                  // the sorted entry list per lane (k_var_buckets_seg): the cross-check of the balanced kernel
   bool var_msm_classic = false;  // KATETH_AMD_VAR_MSM=classic: c = 8 with per-bucket partials for every batch size (cross-check of the flat path)
   uint64_t verify_chunk = 0;     // KATETH_AMD_VERIFY_CHUNK: blobs per host-buffer staging chunk (0 = default)

@@ -127,6 +127,7 @@ static VarGeom choose_var_geom(const kzg_ctx* ctx, uint64_t nterms, bool glv = f
       const uint64_t entries = (seg_total ? seg_total : nterms) * (uint64_t)(g.W - 1u);
       const uint64_t lanes = (uint64_t)ctx->num_cus * 4u * 2u * 64u * 7u / 8u;
       g.seg = (uint32_t)std::min<uint64_t>(std::max<uint64_t>((entries + lanes - 1) / lanes, 16), 4096);
+      if (ctx->knobs.var_seg >= 2u) g.seg = ctx->knobs.var_seg;
       // the top window's 232 possible magnitudes (231 + a carry) over 20 threads each: a thread's strided list is then SHORTER than a
       // share (2 n / 232 / 20 = n / 2,320 entries against 3 n * 19 / 114,688 = n / 2,012) -- with 16 it was the longer lincomb's
       // longest chain (35-40 entries at 65,536 triples against shares of 33); k_var_bitsums sums 2,340 instead of 2,064 stored points
